@@ -1,0 +1,171 @@
+/*
+ * tbnn.h -- C ABI of the MI355X-native HMC sampler for dense Bayesian neural
+ * networks (drop-in for the HMC hot path of alpha-davidson/TensorBNN).
+ *
+ * The reference has no FFI boundary of its own: its hot path is Python calling
+ * TensorFlow-Probability.  Each entry point below
+ * names the reference interface (file:line under /root/reference) it replaces.
+ * A reference maintainer binds these with ctypes; the stub is shown in
+ * INTEGRATION.md and shipped as tensorbnn_amd/_native.py.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success, <0 on error
+ *     (message via tbnn_last_error(), thread-local).
+ *   - caller owns all host buffers, the library owns all device buffers.
+ *   - one handle = one chain = one HIP device + one HIP stream.  A handle is
+ *     not thread-safe; distinct handles are.
+ *   - every call returns after its stream work has completed.
+ *   - there is NO CPU fallback: tbnn_create fails when no gfx950 device is
+ *     visible.  tbnn_adapter_* is host-only C++ (the reference's adapter is
+ *     host-side TF-eager code as well) and works without a GPU.
+ *
+ * State-vector contract:
+ *   theta = concat over dense layers of ( W row-major [out,in], b [out] )
+ *   eta   = concat over dense layers of ( loc_w, g_w, loc_b, g_b ), then
+ *           sqrt(sd) when the likelihood is TBNN_LIK_GAUSSIAN.
+ */
+#ifndef TBNN_H
+#define TBNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBNN_MAX_LAYERS 16
+#define TBNN_ABI_VERSION 1
+
+/* activation layer that follows a dense layer
+ * (tensorBNN/activationFunctions.py:27-63) */
+enum { TBNN_ACT_NONE = 0, TBNN_ACT_RELU = 1, TBNN_ACT_TANH = 2, TBNN_ACT_SIGMOID = 3 };
+/* prior family of a dense layer: CauchyDenseLayer (= DenseLayer) layer.py:101,
+ * GaussianDenseLayer layer.py:282 */
+enum { TBNN_PRIOR_CAUCHY = 0, TBNN_PRIOR_GAUSSIAN = 1 };
+/* likelihood.py:63 (Gaussian), :136 (FixedGaussian), :205 (Bernoulli) */
+enum { TBNN_LIK_GAUSSIAN = 0, TBNN_LIK_FIXED_GAUSSIAN = 1, TBNN_LIK_BERNOULLI = 2 };
+
+/* kernel selection for the fused forward+backward pass */
+enum { TBNN_KERNEL_AUTO = 0, TBNN_KERNEL_GENERIC = 1, TBNN_KERNEL_FAST = 2 };
+
+typedef struct tbnn_layer_desc {
+    int32_t in_dim;   /* layer.py:110 inputDims  */
+    int32_t out_dim;  /* layer.py:111 outputDims */
+    int32_t act;      /* TBNN_ACT_*   */
+    int32_t prior;    /* TBNN_PRIOR_* */
+} tbnn_layer_desc;
+
+typedef struct tbnn_net_desc {
+    int32_t n_layers;
+    const tbnn_layer_desc* layers;
+    int32_t likelihood;  /* TBNN_LIK_* */
+    float fixed_sd;      /* FixedGaussianLikelihood(sd=) likelihood.py:138-141 */
+    int32_t kernel;      /* TBNN_KERNEL_* */
+    int32_t reserved;
+} tbnn_net_desc;
+
+/* per-transition results: what network.train prints/threads through
+ * (network.py:410-411 acceptRate; :596-600 prints; paramAdapter.py:219-222 SJD) */
+typedef struct tbnn_step_out {
+    int32_t accepted;          /* Metropolis decision */
+    int32_t n_leapfrog;        /* leapfrog steps executed (= L) */
+    float log_accept_ratio;    /* TFP log_accept_ratio (non-finite -> -inf) */
+    float accept_prob;         /* lar<0 ? exp(lar) : 1   network.py:410-411 */
+    double logp_old;           /* target log-prob at the start state */
+    double logp_new;           /* target log-prob at the proposal */
+    double kinetic_old;        /* 1/2 |p0|^2 */
+    double kinetic_new;        /* 1/2 |p_L|^2 */
+    double sjd;                /* sum (new-old)^2 over theta (0 when rejected) */
+    float device_us;           /* hipEvent time of the whole transition */
+    float fwdbwd_us;           /* hipEvent time summed over the fused fwd+bwd launches */
+} tbnn_step_out;
+
+typedef struct tbnn_ctx* tbnn_handle;
+
+const char* tbnn_last_error(void);
+int tbnn_abi_version(void);
+/* number of visible HIP devices (<0: error) */
+int tbnn_device_count(void);
+
+/* network.__init__/add/setupMCMC state on the device (network.py:19-58,
+ * :173-191).  seed/chain_id key the Philox4x32-10 chain RNG that replaces
+ * tf.random.set_seed(50) (network.py:562). */
+int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed, uint32_t chain_id,
+                tbnn_handle* out);
+int tbnn_destroy(tbnn_handle h);
+int tbnn_param_count(tbnn_handle h);  /* P */
+int tbnn_hyper_count(tbnn_handle h);  /* H */
+/* name of the fused kernel variant in use ("generic", "fast<...>") */
+const char* tbnn_kernel_name(tbnn_handle h);
+
+/* trainX / trainY staging, network.py:41-45.  X [n,d_in] row-major, Y [n,d_out]. */
+int tbnn_set_data(tbnn_handle h, const float* X, const float* Y, int64_t n);
+/* same, from device pointers (e.g. a torch tensor's data_ptr on this device) */
+int tbnn_set_data_device(tbnn_handle h, const float* dX, const float* dY, int64_t n);
+
+/* network.states / network.hyperStates, network.py:53-56 */
+int tbnn_set_state(tbnn_handle h, const float* theta);
+int tbnn_get_state(tbnn_handle h, float* theta);
+int tbnn_set_hypers(tbnn_handle h, const float* eta);
+int tbnn_get_hypers(tbnn_handle h, float* eta);
+
+/* the target closure calculateProbs (network.py:370-392) and its gradient
+ * (TF autodiff inside TFP).  theta/eta may be NULL = use the
+ * handle's current state.  stat (optional) receives the data-term statistic:
+ * sum((y-f)^2) for the Gaussian likelihoods, the log-likelihood for Bernoulli. */
+int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* eta, double* logp,
+                   float* grad, double* stat);
+
+/* network.predict, network.py:141-171: out is [d_out, n] like the reference. */
+int tbnn_forward(tbnn_handle h, const float* theta, const float* X, int64_t n, float* out);
+
+/* One weight transition = InnerStepMain (network.py:368-412):
+ * tfp.mcmc.HamiltonianMonteCarlo + sample_chain(num_results=1), call sites
+ * network.py:394-408.  p0 (P floats) / log_u (1 float) may be NULL (device
+ * Philox draw) or injected for parity tests.  trace_logp (optional, L+1
+ * doubles) receives the target log-prob at q_0..q_L. */
+int tbnn_hmc_step(tbnn_handle h, float eps, int32_t L, const float* p0, const float* log_u,
+                  tbnn_step_out* out, double* trace_logp);
+
+/* n_epochs transitions back to back with fixed (eps, L) and no host
+ * round-trip in between (adapter bypassed).  outs: n_epochs records. */
+int tbnn_hmc_run(tbnn_handle h, float eps, int32_t L, int32_t n_epochs, tbnn_step_out* outs);
+
+/* One hyper-parameter transition = the HMC part of InnerStepHyper
+ * (network.py:414-456); dual averaging (:457-469) stays with the caller. */
+int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const float* p0, const float* log_u,
+                    tbnn_step_out* out);
+/* the hyper target (network.py:416-440) and its gradient w.r.t. eta */
+int tbnn_hyper_logp_grad(tbnn_handle h, const float* eta, double* logp, float* grad);
+
+/* checkpoint export: writes theta (P floats) then eta (H floats) to a device
+ * buffer of P+H floats (feeds the RCCL all-gather at sample time). */
+int tbnn_export_sample_device(tbnn_handle h, float* d_out);
+
+/* the chain RNG, exposed for tests: n standard normals / one log-uniform for
+ * (epoch, purpose) exactly as tbnn_hmc_step would draw them. */
+int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, int32_t n, float* out_normals,
+                    float* out_log_u);
+/* epoch counter that keys the RNG (incremented by every tbnn_hmc_step) */
+int tbnn_set_epoch(tbnn_handle h, uint32_t epoch);
+/* record a hipEvent pair around every fused fwd+bwd launch (fills fwdbwd_us) */
+int tbnn_set_profiling(tbnn_handle h, int on);
+
+/* ---- (eps, L) adapter: paramAdapter (tensorBNN/paramAdapter.py:11-292), host C++ ---- */
+typedef struct tbnn_adapter* tbnn_adapter_handle;
+/* paramAdapter.__init__ :39-93 (k = burnin/averagingSteps, network.py:229-230) */
+int tbnn_adapter_create(float e1, int32_t L1, float el, float eu, int32_t eNumber, int32_t Ll,
+                        int32_t Lu, int32_t lStep, int32_t m, double k, float a, float delta,
+                        int32_t randomSteps, uint64_t seed, tbnn_adapter_handle* out);
+int tbnn_adapter_destroy(tbnn_adapter_handle a);
+/* paramAdapter.update :199-292.  state: P floats (the new theta).  inject_u
+ * (<0: draw) replaces tf.random.uniform :232; inject_e/inject_l (<0: draw)
+ * replace random.choice :283-284 with grid indices.  Outputs next (eps, L). */
+int tbnn_adapter_update(tbnn_adapter_handle a, const float* state, int32_t P, float inject_u,
+                        int32_t inject_e, int32_t inject_l, float* eps_out, int32_t* L_out,
+                        float* sjd_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBNN_H */

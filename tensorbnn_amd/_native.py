@@ -1,0 +1,275 @@
+"""ctypes binding of libtbnn (include/tbnn.h) -- the only route to the HMC path.
+
+There is no CPU fallback: if ``libtbnn.so`` is missing this module raises at
+import time, and ``Chain`` raises when no gfx950 device is visible.  The
+binding mirrors the header one to one; ``Chain`` is a thin object wrapper used
+by ``tensorbnn_amd.network``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtbnn.so")
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+PRIOR_CAUCHY, PRIOR_GAUSSIAN = 0, 1
+LIK_GAUSSIAN, LIK_FIXED_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST = 0, 1, 2
+MAX_LAYERS = 16
+
+
+class TbnnError(RuntimeError):
+    pass
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32), ("act", C.c_int32), ("prior", C.c_int32)]
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("layers", C.POINTER(LayerDesc)), ("likelihood", C.c_int32),
+                ("fixed_sd", C.c_float), ("kernel", C.c_int32), ("reserved", C.c_int32)]
+
+
+class StepOut(C.Structure):
+    _fields_ = [("accepted", C.c_int32), ("n_leapfrog", C.c_int32), ("log_accept_ratio", C.c_float),
+                ("accept_prob", C.c_float), ("logp_old", C.c_double), ("logp_new", C.c_double),
+                ("kinetic_old", C.c_double), ("kinetic_new", C.c_double), ("sjd", C.c_double),
+                ("device_us", C.c_float), ("fwdbwd_us", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/tbnn.h declares: (name, restype, argtypes)
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+_H = C.c_void_p
+SYMBOLS = [
+    ("tbnn_last_error", C.c_char_p, []),
+    ("tbnn_abi_version", C.c_int, []),
+    ("tbnn_device_count", C.c_int, []),
+    ("tbnn_create", C.c_int, [C.POINTER(NetDesc), C.c_int, C.c_uint64, C.c_uint32, C.POINTER(_H)]),
+    ("tbnn_destroy", C.c_int, [_H]),
+    ("tbnn_param_count", C.c_int, [_H]),
+    ("tbnn_hyper_count", C.c_int, [_H]),
+    ("tbnn_kernel_name", C.c_char_p, [_H]),
+    ("tbnn_set_data", C.c_int, [_H, _fp, _fp, C.c_int64]),
+    ("tbnn_set_data_device", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
+    ("tbnn_set_state", C.c_int, [_H, _fp]),
+    ("tbnn_get_state", C.c_int, [_H, _fp]),
+    ("tbnn_set_hypers", C.c_int, [_H, _fp]),
+    ("tbnn_get_hypers", C.c_int, [_H, _fp]),
+    ("tbnn_logp_grad", C.c_int, [_H, _fp, _fp, _dp, _fp, _dp]),
+    ("tbnn_forward", C.c_int, [_H, _fp, _fp, C.c_int64, _fp]),
+    ("tbnn_hmc_step", C.c_int, [_H, C.c_float, C.c_int32, _fp, _fp, C.POINTER(StepOut), _dp]),
+    ("tbnn_hmc_run", C.c_int, [_H, C.c_float, C.c_int32, C.c_int32, C.POINTER(StepOut)]),
+    ("tbnn_hyper_step", C.c_int, [_H, C.c_float, C.c_int32, _fp, _fp, C.POINTER(StepOut)]),
+    ("tbnn_hyper_logp_grad", C.c_int, [_H, _fp, _dp, _fp]),
+    ("tbnn_export_sample_device", C.c_int, [_H, C.c_void_p]),
+    ("tbnn_debug_draw", C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_int32, _fp, _fp]),
+    ("tbnn_set_epoch", C.c_int, [_H, C.c_uint32]),
+    ("tbnn_set_profiling", C.c_int, [_H, C.c_int]),
+    ("tbnn_adapter_create", C.c_int, [C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_double, C.c_float, C.c_float, C.c_int32,
+                                      C.c_uint64, C.POINTER(_H)]),
+    ("tbnn_adapter_destroy", C.c_int, [_H]),
+    ("tbnn_adapter_update", C.c_int, [_H, _fp, C.c_int32, C.c_float, C.c_int32, C.c_int32, _fp,
+                                      C.POINTER(C.c_int32), _fp]),
+]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m tensorbnn_amd.build` "
+            "(hipcc --offload-arch=gfx950).  tensorbnn_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def _check(rc: int):
+    if rc < 0:
+        raise TbnnError(f"libtbnn error {rc}: {lib.tbnn_last_error().decode()}")
+    return rc
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_fp)
+
+
+def device_count() -> int:
+    rc = lib.tbnn_device_count()
+    return max(rc, 0)
+
+
+class Chain:
+    """One HMC chain on one device (tbnn_handle)."""
+
+    def __init__(self, layers: Sequence[tuple], likelihood: int = LIK_GAUSSIAN, fixed_sd: float = 0.1,
+                 device: int = 0, seed: int = 50, chain_id: int = 0, kernel: int = KERNEL_AUTO):
+        arr = (LayerDesc * len(layers))(*[LayerDesc(*map(int, l)) for l in layers])
+        self._layers_keepalive = arr
+        desc = NetDesc(len(layers), arr, int(likelihood), float(fixed_sd), int(kernel), 0)
+        h = _H()
+        _check(lib.tbnn_create(C.byref(desc), int(device), int(seed), int(chain_id), C.byref(h)))
+        self._h = h
+        self.P = lib.tbnn_param_count(h)
+        self.H = lib.tbnn_hyper_count(h)
+        self.d_in = int(layers[0][0])
+        self.d_out = int(layers[-1][1])
+        self.n = 0
+
+    @property
+    def kernel_name(self) -> str:
+        return lib.tbnn_kernel_name(self._h).decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.tbnn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data / state
+    def set_data(self, X, Y):
+        X = _f32(X).reshape(-1, self.d_in)
+        Y = _f32(Y).reshape(X.shape[0], self.d_out)
+        self.n = X.shape[0]
+        _check(lib.tbnn_set_data(self._h, _p(X), _p(Y), self.n))
+
+    def set_data_device(self, dX_ptr: int, dY_ptr: int, n: int):
+        self.n = int(n)
+        _check(lib.tbnn_set_data_device(self._h, C.c_void_p(dX_ptr), C.c_void_p(dY_ptr), self.n))
+
+    def set_state(self, theta):
+        theta = _f32(theta).reshape(-1)
+        assert theta.size == self.P, (theta.size, self.P)
+        _check(lib.tbnn_set_state(self._h, _p(theta)))
+
+    def get_state(self) -> np.ndarray:
+        out = np.empty(self.P, dtype=np.float32)
+        _check(lib.tbnn_get_state(self._h, _p(out)))
+        return out
+
+    def set_hypers(self, eta):
+        eta = _f32(eta).reshape(-1)
+        assert eta.size == self.H, (eta.size, self.H)
+        _check(lib.tbnn_set_hypers(self._h, _p(eta)))
+
+    def get_hypers(self) -> np.ndarray:
+        out = np.empty(self.H, dtype=np.float32)
+        _check(lib.tbnn_get_hypers(self._h, _p(out)))
+        return out
+
+    # ---- evaluation
+    def logp_grad(self, theta=None, eta=None):
+        th = None if theta is None else _f32(theta).reshape(-1)
+        et = None if eta is None else _f32(eta).reshape(-1)
+        lp, st = C.c_double(), C.c_double()
+        g = np.empty(self.P, dtype=np.float32)
+        _check(lib.tbnn_logp_grad(self._h, _p(th), _p(et), C.byref(lp), _p(g), C.byref(st)))
+        return lp.value, g, st.value
+
+    def forward(self, X, theta=None) -> np.ndarray:
+        X = _f32(X).reshape(-1, self.d_in)
+        th = None if theta is None else _f32(theta).reshape(-1)
+        out = np.empty((self.d_out, X.shape[0]), dtype=np.float32)
+        _check(lib.tbnn_forward(self._h, _p(th), _p(X), X.shape[0], _p(out)))
+        return out
+
+    def hyper_logp_grad(self, eta=None):
+        et = None if eta is None else _f32(eta).reshape(-1)
+        lp = C.c_double()
+        g = np.empty(self.H, dtype=np.float32)
+        _check(lib.tbnn_hyper_logp_grad(self._h, _p(et), C.byref(lp), _p(g)))
+        return lp.value, g
+
+    # ---- transitions
+    def hmc_step(self, eps: float, L: int, p0=None, log_u=None, trace: bool = False):
+        p0a = None if p0 is None else _f32(p0).reshape(-1)
+        lua = None if log_u is None else _f32([log_u])
+        out = StepOut()
+        tr = np.empty(L + 1, dtype=np.float64) if trace else None
+        _check(lib.tbnn_hmc_step(self._h, float(eps), int(L), _p(p0a), _p(lua), C.byref(out),
+                                 None if tr is None else tr.ctypes.data_as(_dp)))
+        d = out.as_dict()
+        if trace:
+            d["trace_logp"] = tr
+        return d
+
+    def hmc_run(self, eps: float, L: int, n_epochs: int):
+        outs = (StepOut * n_epochs)()
+        _check(lib.tbnn_hmc_run(self._h, float(eps), int(L), int(n_epochs), outs))
+        return [o.as_dict() for o in outs]
+
+    def hyper_step(self, eps_h: float, L_h: int, p0=None, log_u=None):
+        p0a = None if p0 is None else _f32(p0).reshape(-1)
+        lua = None if log_u is None else _f32([log_u])
+        out = StepOut()
+        _check(lib.tbnn_hyper_step(self._h, float(eps_h), int(L_h), _p(p0a), _p(lua), C.byref(out)))
+        return out.as_dict()
+
+    def export_sample_device(self, d_ptr: int):
+        _check(lib.tbnn_export_sample_device(self._h, C.c_void_p(d_ptr)))
+
+    def debug_draw(self, epoch: int, purpose: int, n: int):
+        out = np.empty(n, dtype=np.float32)
+        lu = C.c_float()
+        _check(lib.tbnn_debug_draw(self._h, epoch, purpose, n, _p(out), C.byref(lu)))
+        return out, lu.value
+
+    def set_epoch(self, epoch: int):
+        _check(lib.tbnn_set_epoch(self._h, int(epoch)))
+
+    def set_profiling(self, on: bool):
+        _check(lib.tbnn_set_profiling(self._h, int(bool(on))))
+
+
+class Adapter:
+    """tbnn_adapter_* : the (eps, L) GP-UCB adapter (paramAdapter.py:11-292) in host C++."""
+
+    def __init__(self, e1, L1, el, eu, eNumber, Ll, Lu, lStep, m, k, a=4, delta=0.1, randomSteps=10, seed=0):
+        h = _H()
+        _check(lib.tbnn_adapter_create(float(e1), int(L1), float(el), float(eu), int(eNumber), int(Ll), int(Lu),
+                                       int(lStep), int(m), float(k), float(a), float(delta), int(randomSteps),
+                                       int(seed), C.byref(h)))
+        self._h = h
+
+    def update(self, state, inject_u: float = -1.0, inject_e: int = -1, inject_l: int = -1):
+        s = _f32(state).reshape(-1)
+        e, L, sjd = C.c_float(), C.c_int32(), C.c_float()
+        _check(lib.tbnn_adapter_update(self._h, _p(s), s.size, float(inject_u), int(inject_e), int(inject_l),
+                                       C.byref(e), C.byref(L), C.byref(sjd)))
+        return e.value, L.value, sjd.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.tbnn_adapter_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,134 @@
+// Shared device/host definitions for libtbnn (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/tbnn.h"
+
+#define TBNN_WAVE 64
+
+// Network descriptor passed BY VALUE as a kernel argument (lives in SGPRs /
+// the kernarg segment: every lookup is wave-uniform).
+struct NetDev {
+    int nl;                       // dense layers
+    int in[TBNN_MAX_LAYERS];      // inputDims   (layer.py:110)
+    int out[TBNN_MAX_LAYERS];     // outputDims  (layer.py:111)
+    int act[TBNN_MAX_LAYERS];     // activation following the layer
+    int prior[TBNN_MAX_LAYERS];   // TBNN_PRIOR_*
+    int offW[TBNN_MAX_LAYERS];    // offset of W_l in theta
+    int offB[TBNN_MAX_LAYERS];    // offset of b_l in theta
+    int actOff[TBNN_MAX_LAYERS];  // offset (in floats per row) of a_{l+1} in the per-row activation record
+    int P, H;
+    int lik;                      // TBNN_LIK_*
+    int d_in, d_out;
+    int sumOut;                   // sum of out dims = floats per row in the activation record
+    int maxW;                     // widest layer (in or out)
+    float fixed_sd;
+};
+
+// Per-chain scalar record kept on the device (doubles: energies are summed
+// and differenced in fp64 -- strictly more accurate than the reference's fp32).
+struct Scal {
+    double stat_cur, prior_cur, logp_cur;   // at the current (accepted) state
+    double stat_new, prior_new, logp_new;   // at the proposal
+    double k0, k1;                          // kinetic energies
+    double lar;                             // log accept ratio
+    double logu;                            // log U(0,1)
+    double d2;                              // |q_prop - q_cur|^2
+    double sjd;                             // d2 if accepted else 0
+    int accepted;
+    int pad;
+};
+
+// Likelihood standard deviation used on the hot path.
+// Gaussian: clip(eta_last^2, 1e-8, 1e8) (likelihood.py:88 + BNN_functions.py:23-24);
+// FixedGaussian: sd as given (likelihood.py:162), same clip inside multivariateLogProb.
+__device__ __forceinline__ float lik_sigma(const NetDev& nd, const float* __restrict__ eta) {
+    float s = (nd.lik == TBNN_LIK_GAUSSIAN) ? eta[nd.H - 1] * eta[nd.H - 1] : nd.fixed_sd;
+    s = fmaxf(s, 1e-8f);
+    s = fminf(s, 1e8f);
+    return s;
+}
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    switch (act) {
+        case TBNN_ACT_RELU: return fmaxf(z, 0.f);                  // activationFunctions.py:36
+        case TBNN_ACT_TANH: return tanhf(z);                       // :62
+        case TBNN_ACT_SIGMOID: return 1.f / (1.f + expf(-z));      // :49
+        default: return z;
+    }
+}
+// derivative expressed through the activation OUTPUT a
+__device__ __forceinline__ float act_bwd(float a, int act) {
+    switch (act) {
+        case TBNN_ACT_RELU: return a > 0.f ? 1.f : 0.f;
+        case TBNN_ACT_TANH: return 1.f - a * a;
+        case TBNN_ACT_SIGMOID: return a * (1.f - a);
+        default: return 1.f;
+    }
+}
+
+// wave (64-lane) and block reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sumf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// sum over the whole block; result valid in thread 0.  red: >= blockDim/64 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (w == 0) {
+        t = lane < nw ? red[lane] : 0.0;
+        t = wave_sum(t);
+    }
+    return t;
+}
+
+// Philox4x32-10 chain RNG (replaces tf.random.set_seed(50), network.py:562).
+// key = (seed, chain_id); counter = (block, epoch, purpose, 0).
+struct Philox4 { uint32_t v[4]; };
+__host__ __device__ __forceinline__ uint32_t tb_mulhi(uint32_t a, uint32_t b) {
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+}
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                           uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t p0h = tb_mulhi(0xD2511F53u, c0), p0l = 0xD2511F53u * c0;
+        const uint32_t p1h = tb_mulhi(0xCD9E8D57u, c2), p1l = 0xCD9E8D57u * c2;
+        const uint32_t n0 = p1h ^ c1 ^ k0, n1 = p1l, n2 = p0h ^ c3 ^ k1, n3 = p0l;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Philox4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+__host__ __device__ __forceinline__ float u01(uint32_t x) {   // (0,1)
+    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+// j-th standard normal of (epoch, purpose): block j/4, Box-Muller pair (j%4)/2
+__device__ __forceinline__ float philox_normal(uint32_t j, uint32_t epoch, uint32_t purpose, uint32_t k0, uint32_t k1) {
+    const Philox4 r = philox4x32_10(j >> 2, epoch, purpose, 0u, k0, k1);
+    const int h = (j >> 1) & 1;
+    const float u1 = u01(r.v[2 * h]), u2 = u01(r.v[2 * h + 1]);
+    const float rad = sqrtf(-2.f * logf(u1));
+    const float ang = 6.28318530717958647692f * u2;
+    return (j & 1) ? rad * sinf(ang) : rad * cosf(ang);
+}
+__device__ __forceinline__ float philox_logu(uint32_t epoch, uint32_t purpose, uint32_t k0, uint32_t k1) {
+    const Philox4 r = philox4x32_10(0u, epoch, purpose, 0u, k0, k1);
+    return logf(u01(r.v[0]));
+}
+
+#define PURPOSE_MOMENTUM 0u
+#define PURPOSE_LOGU 1u
+#define PURPOSE_HYPER_MOMENTUM 2u
+#define PURPOSE_HYPER_LOGU 3u

@@ -1,0 +1,211 @@
+// Leapfrog / energy / Metropolis kernels: everything of one HMC transition that
+// is not the fused forward+backward pass.  All of it runs on the device, queued
+// on one stream; the host reads one small record per transition.
+//
+// Restates tfp.mcmc.HamiltonianMonteCarlo (un-vendored; call sites
+// network.py:394-408) in the SimpleLeapfrogIntegrator ordering:
+//   p = p0 + eps/2 g0 ; L x { q += eps p ; g = grad(q) ; p += eps g } ; p -= eps/2 g
+//   lar = logp_L - logp_0 + 1/2|p0|^2 - 1/2|p_L|^2 (non-finite -> -inf); accept iff log u < lar
+// and the weight priors layer.py:166-197 / :346-377 with BNN_functions.py:7-57.
+#pragma once
+#include "common.hpp"
+
+enum { UPD_GRAD_ONLY = 0, UPD_FIRST = 1, UPD_MID = 2, UPD_LAST = 3 };
+
+// which (layer, W-or-b) group a flat parameter index belongs to -> (loc, scale)
+__device__ __forceinline__ void prior_params(const NetDev& nd, const float* __restrict__ eta, int j,
+                                             int& prior, float& loc, float& scale) {
+    int l = 0;
+#pragma unroll 1
+    for (int m = 1; m < nd.nl; ++m) if (j >= nd.offW[m]) l = m;
+    const bool isb = j >= nd.offB[l];
+    prior = nd.prior[l];
+    loc = eta[4 * l + (isb ? 2 : 0)];
+    const float g = eta[4 * l + (isb ? 3 : 1)];
+    scale = g * g;                                   // layer.py:178,180 / :358,360 (Q3)
+}
+
+// d/dx of the reference's prior log-density (Q1 sign kept)
+__device__ __forceinline__ float prior_grad(int prior, float loc, float scale, float x) {
+    if (prior == TBNN_PRIOR_CAUCHY) {
+        const float z = (x - loc) / scale;           // BNN_functions.py:51
+        return 2.f * z / (scale * (1.f + z * z));
+    }
+    const float s = fminf(fmaxf(scale, 1e-8f), 1e8f);   // BNN_functions.py:23-24
+    return -(x - loc) / (s * s);
+}
+
+// Reduce the per-workgroup gradient slabs, add the prior gradient, then kick /
+// drift.  block = (64, 4): x = parameter, y = slab quarter.
+__global__ __launch_bounds__(256) void k_update(
+    NetDev nd, int mode, float eps, const float* __restrict__ eta,
+    const float* __restrict__ slabs, int nslab,
+    const float* __restrict__ q_cur, const float* __restrict__ g_cur,
+    float* __restrict__ q, float* __restrict__ p, float* __restrict__ g)
+{
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int j = blockIdx.x * 64 + tx;
+    float gj = 0.f;
+    if (mode != UPD_FIRST) {
+        float s = 0.f;
+        if (j < nd.P)
+            for (int w = ty; w < nslab; w += 4) s += slabs[(size_t)w * nd.P + j];
+        part[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && j < nd.P) {
+            // fixed order ((0+1)+(2+3)): deterministic
+            gj = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+            int prior; float loc, scale;
+            prior_params(nd, eta, j, prior, loc, scale);
+            gj += prior_grad(prior, loc, scale, q[j]);
+        }
+    }
+    if (ty != 0 || j >= nd.P) return;
+    if (mode == UPD_GRAD_ONLY) { g[j] = gj; return; }
+    if (mode == UPD_FIRST) {
+        const float pj = p[j] + 0.5f * eps * g_cur[j];       // half kick
+        p[j] = pj;
+        q[j] = q_cur[j] + eps * pj;                           // drift
+        return;
+    }
+    float pj = p[j] + eps * gj;                               // full kick
+    g[j] = gj;
+    if (mode == UPD_MID) {
+        p[j] = pj;
+        q[j] = q[j] + eps * pj;                               // drift
+    } else {
+        pj = pj - 0.5f * eps * gj;                            // undo half kick
+        p[j] = pj;
+    }
+}
+
+// data-term log-likelihood from the reduced statistic
+__device__ __forceinline__ double data_logp(const NetDev& nd, const float* __restrict__ eta, double stat, long n) {
+    if (nd.lik == TBNN_LIK_BERNOULLI) return stat;
+    // multivariateLogProb with sigma broadcast to [n, d_out] (likelihood.py:92, BNN_functions.py:25-32)
+    const double s = (double)lik_sigma(nd, eta);
+    const double nel = (double)n * (double)nd.d_out;
+    return -0.5 * (2.0 * nel * log(s) + stat / (s * s) + nel * 1.8378770664093453 /* log 2pi */);
+}
+
+// weight-prior log-density of the whole theta; every thread returns its
+// partial, caller block-reduces.  (layer.py:187-195 / :367-375)
+__device__ __forceinline__ double prior_logp_partial(const NetDev& nd, const float* __restrict__ eta,
+                                                     const float* __restrict__ q) {
+    double acc = 0.0;
+    for (int l = 0; l < nd.nl; ++l) {
+        for (int part = 0; part < 2; ++part) {
+            const int off = part ? nd.offB[l] : nd.offW[l];
+            const int cnt = part ? nd.out[l] : nd.out[l] * nd.in[l];
+            const float loc = eta[4 * l + 2 * part];
+            const float gg = eta[4 * l + 2 * part + 1];
+            const float scale = gg * gg;
+            if (nd.prior[l] == TBNN_PRIOR_CAUCHY) {
+                const float lb = logf(3.14159265358979323846f * scale);   // BNN_functions.py:52
+                for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+                    const float z = (q[off + e] - loc) / scale;
+                    acc += (double)(logf(1.f + z * z) - lb);               // :51-55 (Q1)
+                }
+            } else {
+                const float s = fminf(fmaxf(scale, 1e-8f), 1e8f);
+                for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+                    const float d = (q[off + e] - loc) / s;
+                    acc += -0.5 * (double)(d * d);
+                }
+                // Q2: the normaliser counted once per call (k = size(sigma) = 1)
+                if (threadIdx.x == 0) acc += -0.5 * (2.0 * (double)logf(s) + 1.8378770664093453);
+            }
+        }
+    }
+    return acc;
+}
+
+// Single-workgroup kernel: momentum draw + K0 + log u.
+__global__ __launch_bounds__(1024) void k_begin(
+    NetDev nd, const float* __restrict__ p0_inj, const float* __restrict__ logu_inj,
+    uint32_t epoch, uint32_t key0, uint32_t key1, float* __restrict__ p, Scal* __restrict__ sc)
+{
+    __shared__ double red[16];
+    double k = 0.0;
+    for (int j = threadIdx.x; j < nd.P; j += blockDim.x) {
+        const float v = p0_inj ? p0_inj[j] : philox_normal((uint32_t)j, epoch, PURPOSE_MOMENTUM, key0, key1);
+        p[j] = v;
+        k += (double)v * (double)v;
+    }
+    k = block_sum(k, red);
+    if (threadIdx.x == 0) {
+        sc->k0 = 0.5 * k;
+        sc->logu = logu_inj ? (double)logu_inj[0] : (double)philox_logu(epoch, PURPOSE_LOGU, key0, key1);
+    }
+}
+
+enum { EN_CUR = 0, EN_NEW = 1, EN_TRACE = 2 };
+// Single-workgroup kernel: total target log-prob (+ kinetic energy and the
+// Metropolis decision when which == EN_NEW).
+__global__ __launch_bounds__(1024) void k_energy(
+    NetDev nd, int which, const float* __restrict__ eta, const float* __restrict__ q,
+    const float* __restrict__ p, const float* __restrict__ q_cur,
+    const double* __restrict__ partial_stat, int nslab, long n,
+    Scal* __restrict__ sc, double* __restrict__ trace_slot)
+{
+    __shared__ double red[16];
+    double st = 0.0;
+    for (int w = threadIdx.x; w < nslab; w += blockDim.x) st += partial_stat[w];
+    st = block_sum(st, red);
+    double pr = prior_logp_partial(nd, eta, q);
+    pr = block_sum(pr, red);
+    double k1 = 0.0, d2 = 0.0;
+    if (which == EN_NEW) {
+        for (int j = threadIdx.x; j < nd.P; j += blockDim.x) {
+            const double pj = (double)p[j];
+            const double dq = (double)q[j] - (double)q_cur[j];
+            k1 += pj * pj;
+            d2 += dq * dq;
+        }
+        k1 = block_sum(k1, red);
+        d2 = block_sum(d2, red);
+    }
+    if (threadIdx.x != 0) return;
+    const double lp = pr + data_logp(nd, eta, st, n);
+    if (which == EN_TRACE) { *trace_slot = lp; return; }
+    if (which == EN_CUR) {
+        sc->stat_cur = st; sc->prior_cur = pr; sc->logp_cur = lp;
+        if (trace_slot) *trace_slot = lp;
+        return;
+    }
+    sc->stat_new = st; sc->prior_new = pr; sc->logp_new = lp;
+    sc->k1 = 0.5 * k1; sc->d2 = d2;
+    double lar = lp - sc->logp_cur + sc->k0 - 0.5 * k1;
+    if (!isfinite(lar)) lar = -INFINITY;                       // TFP safe_sum / non-finite => reject
+    sc->lar = lar;
+    const int acc = sc->logu < lar ? 1 : 0;
+    sc->accepted = acc;
+    sc->sjd = acc ? d2 : 0.0;
+    if (trace_slot) *trace_slot = lp;
+}
+
+// After EN_NEW: commit the proposal when accepted.  (scalars are committed by
+// k_commit_scal afterwards so that logp_old stays readable for the host.)
+__global__ __launch_bounds__(256) void k_commit(
+    int P, const Scal* __restrict__ sc, const float* __restrict__ q, const float* __restrict__ g,
+    float* __restrict__ q_cur, float* __restrict__ g_cur)
+{
+    if (!sc->accepted) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < P) { q_cur[j] = q[j]; g_cur[j] = g[j]; }
+}
+// copies the record for the host, then rolls cur <- new when accepted
+__global__ void k_commit_scal(Scal* __restrict__ sc, Scal* __restrict__ host_copy) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    *host_copy = *sc;
+    if (sc->accepted) { sc->stat_cur = sc->stat_new; sc->prior_cur = sc->prior_new; sc->logp_cur = sc->logp_new; }
+}
+
+// debug: the chain RNG as tbnn_hmc_step draws it
+__global__ void k_debug_draw(uint32_t epoch, uint32_t purpose, uint32_t key0, uint32_t key1, int n,
+                             float* __restrict__ normals, float* __restrict__ logu) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) normals[j] = philox_normal((uint32_t)j, epoch, purpose, key0, key1);
+    if (j == 0) logu[0] = philox_logu(epoch, purpose + 1u, key0, key1);
+}

@@ -1,0 +1,545 @@
+// libtbnn: C-ABI host driver (include/tbnn.h) for the gfx950 HMC kernels.
+// One handle = one chain = one device + one stream; a whole transition is
+// enqueued without a host round-trip and one small record is read back.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels_generic.hpp"
+#include "kernels_hmc.hpp"
+#include "kernels_hyper.hpp"
+#include "kernels_fast.hpp"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+#define NEED(h)                                                                                \
+    do { if (!(h)) return fail(-1, "null handle"); } while (0)
+
+struct tbnn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    NetDev nd{};
+    uint32_t key0 = 0, key1 = 0, epoch = 0;
+    int kernel = TBNN_KERNEL_GENERIC;     // resolved variant
+    int fast_id = -1;
+    std::string kernel_name;
+    // data
+    float* dX = nullptr; float* dY = nullptr; bool own_data = false; long n = 0;
+    // chain state
+    float *q_cur = nullptr, *g_cur = nullptr, *q = nullptr, *p = nullptr, *g = nullptr, *eta = nullptr;
+    float *p0_inj = nullptr, *logu_inj = nullptr, *tmp = nullptr;
+    bool cur_valid = false;               // (logp, grad, stat) cached at q_cur for the current eta/data
+    // fused-pass workspace
+    int grid = 0; float* slabs = nullptr; double* pstat = nullptr; float* scratch = nullptr;
+    size_t scratchPerWG = 0;
+    Scal* sc = nullptr; Scal* sc_host = nullptr; Scal* sc_out = nullptr;   // sc_out: device copy for host
+    double* trace = nullptr; int trace_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profile = false; std::vector<hipEvent_t> pev;
+    // hyper workspace
+    float* hyp_ws = nullptr;
+};
+
+extern "C" const char* tbnn_last_error(void) { return g_err.c_str(); }
+extern "C" int tbnn_abi_version(void) { return TBNN_ABI_VERSION; }
+extern "C" int tbnn_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(-2, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+static int build_netdev(const tbnn_net_desc* d, NetDev& nd) {
+    if (!d || !d->layers) return fail(-1, "null descriptor");
+    if (d->n_layers < 1 || d->n_layers > TBNN_MAX_LAYERS) return fail(-1, "n_layers must be in [1,16]");
+    memset(&nd, 0, sizeof(nd));
+    nd.nl = d->n_layers;
+    int off = 0, so = 0, mw = 0;
+    for (int l = 0; l < nd.nl; ++l) {
+        const tbnn_layer_desc& L = d->layers[l];
+        if (L.in_dim < 1 || L.out_dim < 1) return fail(-1, "layer dims must be >= 1");
+        if (l > 0 && L.in_dim != d->layers[l - 1].out_dim) return fail(-1, "layer dims do not chain");
+        if (L.act < TBNN_ACT_NONE || L.act > TBNN_ACT_SIGMOID) return fail(-1, "unknown activation");
+        if (L.prior != TBNN_PRIOR_CAUCHY && L.prior != TBNN_PRIOR_GAUSSIAN) return fail(-1, "unknown prior");
+        nd.in[l] = L.in_dim; nd.out[l] = L.out_dim; nd.act[l] = L.act; nd.prior[l] = L.prior;
+        nd.offW[l] = off; off += L.in_dim * L.out_dim;
+        nd.offB[l] = off; off += L.out_dim;
+        nd.actOff[l] = so; so += L.out_dim;
+        mw = std::max(mw, std::max(L.in_dim, L.out_dim));
+    }
+    if (d->likelihood < TBNN_LIK_GAUSSIAN || d->likelihood > TBNN_LIK_BERNOULLI) return fail(-1, "unknown likelihood");
+    nd.P = off;
+    nd.lik = d->likelihood;
+    nd.H = 4 * nd.nl + (nd.lik == TBNN_LIK_GAUSSIAN ? 1 : 0);
+    nd.d_in = nd.in[0]; nd.d_out = nd.out[nd.nl - 1];
+    nd.sumOut = so; nd.maxW = mw;
+    nd.fixed_sd = d->fixed_sd;
+    if (nd.lik == TBNN_LIK_FIXED_GAUSSIAN && !(d->fixed_sd > 0.f)) return fail(-1, "fixed_sd must be > 0");
+    return 0;
+}
+
+static void default_eta(const NetDev& nd, std::vector<float>& eta) {
+    eta.assign(nd.H, 0.f);
+    for (int l = 0; l < nd.nl; ++l) {
+        if (nd.prior[l] == TBNN_PRIOR_CAUCHY) {          // layer.py:136-158
+            eta[4 * l + 1] = sqrtf(0.5f); eta[4 * l + 3] = sqrtf(0.5f);
+        } else {                                         // layer.py:316-339
+            eta[4 * l + 1] = 1.f; eta[4 * l + 3] = 1.f;
+        }
+    }
+    if (nd.lik == TBNN_LIK_GAUSSIAN) eta[nd.H - 1] = sqrtf(0.1f);   // GaussianLikelihood(sd=0.1)
+}
+
+extern "C" int tbnn_destroy(tbnn_handle h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->own_data) { hipFree(h->dX); hipFree(h->dY); }
+    float* bufs[] = {h->q_cur, h->g_cur, h->q, h->p, h->g, h->eta, h->p0_inj, h->logu_inj, h->tmp,
+                     h->slabs, h->scratch, h->hyp_ws};
+    for (float* b : bufs) if (b) hipFree(b);
+    if (h->pstat) hipFree(h->pstat);
+    if (h->sc) hipFree(h->sc);
+    if (h->sc_out) hipFree(h->sc_out);
+    if (h->trace) hipFree(h->trace);
+    if (h->sc_host) hipHostFree(h->sc_host);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    for (auto e : h->pev) hipEventDestroy(e);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed, uint32_t chain_id,
+                           tbnn_handle* out) {
+    if (!out) return fail(-1, "null out");
+    *out = nullptr;
+    NetDev nd;
+    int rc = build_netdev(desc, nd);
+    if (rc) return rc;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(-3, "no HIP device visible: libtbnn has no CPU fallback (the HMC path runs on gfx950 only)");
+    if (device < 0 || device >= ndev) return fail(-1, "device index out of range");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(-3, std::string("device is ") + prop.gcnArchName + ", libtbnn is built for gfx950 only");
+    HIPCHK(hipSetDevice(device));
+    tbnn_ctx* h = new (std::nothrow) tbnn_ctx();
+    if (!h) return fail(-4, "out of host memory");
+    h->device = device; h->nd = nd;
+    // Philox key = (seed, chain_id); the high seed word is folded into the key
+    h->key0 = (uint32_t)(seed & 0xFFFFFFFFull);
+    h->key1 = chain_id ^ (uint32_t)(seed >> 32);
+    auto bail = [&](int code, const std::string& m) { tbnn_destroy(h); return fail(code, m); };
+#define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(-2, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+    HIPB(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t PB = (size_t)nd.P * sizeof(float);
+    HIPB(hipMalloc(&h->q_cur, PB)); HIPB(hipMalloc(&h->g_cur, PB)); HIPB(hipMalloc(&h->q, PB));
+    HIPB(hipMalloc(&h->p, PB)); HIPB(hipMalloc(&h->g, PB)); HIPB(hipMalloc(&h->p0_inj, PB));
+    HIPB(hipMalloc(&h->tmp, PB + (size_t)nd.H * sizeof(float)));
+    HIPB(hipMalloc(&h->eta, (size_t)nd.H * sizeof(float)));
+    HIPB(hipMalloc(&h->logu_inj, sizeof(float)));
+    HIPB(hipMalloc(&h->sc, sizeof(Scal))); HIPB(hipMalloc(&h->sc_out, sizeof(Scal)));
+    HIPB(hipHostMalloc(&h->sc_host, sizeof(Scal)));
+    HIPB(hipMemset(h->sc, 0, sizeof(Scal)));
+    HIPB(hipMemset(h->q_cur, 0, PB));
+    HIPB(hipEventCreate(&h->ev0)); HIPB(hipEventCreate(&h->ev1));
+    HIPB(hipMalloc(&h->hyp_ws, hyper_ws_bytes(nd)));
+    std::vector<float> eta; default_eta(nd, eta);
+    HIPB(hipMemcpy(h->eta, eta.data(), eta.size() * sizeof(float), hipMemcpyHostToDevice));
+    // fused-kernel variant
+    h->kernel = TBNN_KERNEL_GENERIC; h->kernel_name = "generic";
+    const int want = desc->kernel;
+    const int fid = fast_lookup(nd);
+    if (want == TBNN_KERNEL_FAST && fid < 0) return bail(-1, "TBNN_KERNEL_FAST requested but no specialised kernel covers this shape");
+    if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && fid >= 0) {
+        h->kernel = TBNN_KERNEL_FAST; h->fast_id = fid; h->kernel_name = fast_name(fid);
+    }
+    const char* env = getenv("TBNN_PROFILE_FWDBWD");
+    h->profile = env && atoi(env) != 0;
+#undef HIPB
+    *out = h;
+    return 0;
+}
+
+extern "C" int tbnn_param_count(tbnn_handle h) { NEED(h); return h->nd.P; }
+extern "C" int tbnn_hyper_count(tbnn_handle h) { NEED(h); return h->nd.H; }
+extern "C" const char* tbnn_kernel_name(tbnn_handle h) { return h ? h->kernel_name.c_str() : ""; }
+extern "C" int tbnn_set_profiling(tbnn_handle h, int on) { NEED(h); h->profile = on != 0; return 0; }
+extern "C" int tbnn_set_epoch(tbnn_handle h, uint32_t epoch) { NEED(h); h->epoch = epoch; return 0; }
+
+// (re)allocate the fused-pass workspace for n rows
+static int alloc_workspace(tbnn_ctx* h, long n) {
+    const NetDev& nd = h->nd;
+    if (h->slabs) { hipFree(h->slabs); h->slabs = nullptr; }
+    if (h->pstat) { hipFree(h->pstat); h->pstat = nullptr; }
+    if (h->scratch) { hipFree(h->scratch); h->scratch = nullptr; }
+    int grid;
+    if (h->kernel == TBNN_KERNEL_FAST) {
+        grid = fast_grid(h->fast_id, n);
+        h->scratchPerWG = 0;
+    } else {
+        const long nblk = (n + GEN_RB - 1) / GEN_RB;
+        grid = (int)std::min<long>(nblk, 512);
+        h->scratchPerWG = generic_scratch_floats(nd);
+        HIPCHK(hipMalloc(&h->scratch, h->scratchPerWG * sizeof(float) * (size_t)grid));
+    }
+    // tbnn_forward always uses the generic forward kernel: keep a scratch for it
+    h->grid = grid;
+    HIPCHK(hipMalloc(&h->slabs, (size_t)grid * nd.P * sizeof(float)));
+    HIPCHK(hipMalloc(&h->pstat, (size_t)grid * sizeof(double)));
+    return 0;
+}
+
+extern "C" int tbnn_set_data_device(tbnn_handle h, const float* dX, const float* dY, int64_t n) {
+    NEED(h);
+    if (!dX || !dY || n < 1) return fail(-1, "set_data: null pointer or n < 1");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->own_data) { hipFree(h->dX); hipFree(h->dY); h->own_data = false; }
+    h->dX = const_cast<float*>(dX); h->dY = const_cast<float*>(dY); h->n = (long)n;
+    h->cur_valid = false;
+    return alloc_workspace(h, (long)n);
+}
+
+extern "C" int tbnn_set_data(tbnn_handle h, const float* X, const float* Y, int64_t n) {
+    NEED(h);
+    if (!X || !Y || n < 1) return fail(-1, "set_data: null pointer or n < 1");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->own_data) { hipFree(h->dX); hipFree(h->dY); h->own_data = false; h->dX = h->dY = nullptr; }
+    float *dX = nullptr, *dY = nullptr;
+    HIPCHK(hipMalloc(&dX, (size_t)n * h->nd.d_in * sizeof(float)));
+    HIPCHK(hipMalloc(&dY, (size_t)n * h->nd.d_out * sizeof(float)));
+    HIPCHK(hipMemcpy(dX, X, (size_t)n * h->nd.d_in * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dY, Y, (size_t)n * h->nd.d_out * sizeof(float), hipMemcpyHostToDevice));
+    h->dX = dX; h->dY = dY; h->own_data = true; h->n = (long)n;
+    h->cur_valid = false;
+    return alloc_workspace(h, (long)n);
+}
+
+extern "C" int tbnn_set_state(tbnn_handle h, const float* theta) {
+    NEED(h); if (!theta) return fail(-1, "null theta");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->q_cur, theta, (size_t)h->nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->cur_valid = false;
+    return 0;
+}
+extern "C" int tbnn_get_state(tbnn_handle h, float* theta) {
+    NEED(h); if (!theta) return fail(-1, "null theta");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(theta, h->q_cur, (size_t)h->nd.P * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int tbnn_set_hypers(tbnn_handle h, const float* eta) {
+    NEED(h); if (!eta) return fail(-1, "null eta");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->eta, eta, (size_t)h->nd.H * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->cur_valid = false;
+    return 0;
+}
+extern "C" int tbnn_get_hypers(tbnn_handle h, float* eta) {
+    NEED(h); if (!eta) return fail(-1, "null eta");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(eta, h->eta, (size_t)h->nd.H * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- launch helpers (all on h->stream, no sync) ----
+static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (h->profile) {
+        hipEventCreate(&a); hipEventCreate(&b); h->pev.push_back(a); h->pev.push_back(b);
+        hipEventRecord(a, h->stream);
+    }
+    if (h->kernel == TBNN_KERNEL_FAST) {
+        int rc = fast_launch(h->fast_id, h->grid, h->stream, h->nd, q, eta, h->dX, h->dY, h->n, h->slabs, h->pstat);
+        if (rc) return fail(-2, "fast kernel launch failed");
+    } else {
+        hipLaunchKernelGGL(k_fwd_bwd_generic, dim3(h->grid), dim3(GEN_RB), 0, h->stream, h->nd, q, eta, h->dX,
+                           h->dY, h->n, h->scratch, h->scratchPerWG, h->slabs, h->pstat);
+    }
+    if (h->profile) hipEventRecord(b, h->stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static void launch_update(tbnn_ctx* h, int mode, float eps, const float* eta, float* q, float* g) {
+    const int gx = (h->nd.P + 63) / 64;
+    hipLaunchKernelGGL(k_update, dim3(gx), dim3(64, 4), 0, h->stream, h->nd, mode, eps, eta, h->slabs, h->grid,
+                       h->q_cur, h->g_cur, q, h->p, g);
+}
+static void launch_energy(tbnn_ctx* h, int which, const float* eta, const float* q, double* slot) {
+    hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, h->nd, which, eta, q, h->p, h->q_cur, h->pstat,
+                       h->grid, h->n, h->sc, slot);
+}
+// make (logp, grad, stat) at q_cur valid
+static int ensure_current(tbnn_ctx* h, double* slot) {
+    if (h->cur_valid) return 0;
+    int rc = launch_fwd_bwd(h, h->q_cur, h->eta);
+    if (rc) return rc;
+    launch_update(h, UPD_GRAD_ONLY, 0.f, h->eta, h->q_cur, h->g_cur);
+    launch_energy(h, EN_CUR, h->eta, h->q_cur, slot);
+    h->cur_valid = true;
+    return 0;
+}
+static float drain_profile(tbnn_ctx* h) {
+    float tot = 0.f;
+    for (size_t i = 0; i + 1 < h->pev.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->pev[i], h->pev[i + 1]) == hipSuccess) tot += ms * 1000.f;
+    }
+    for (auto e : h->pev) hipEventDestroy(e);
+    h->pev.clear();
+    return tot;
+}
+
+extern "C" int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* eta, double* logp, float* grad,
+                              double* stat) {
+    NEED(h);
+    if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    const NetDev& nd = h->nd;
+    // evaluation happens on scratch copies (q, tmp-eta): the chain state is untouched
+    const float* dq = h->q_cur;
+    const float* de = h->eta;
+    if (theta) { HIPCHK(hipMemcpyAsync(h->q, theta, (size_t)nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream)); dq = h->q; }
+    if (eta) { HIPCHK(hipMemcpyAsync(h->tmp + nd.P, eta, (size_t)nd.H * sizeof(float), hipMemcpyHostToDevice, h->stream)); de = h->tmp + nd.P; }
+    int rc = launch_fwd_bwd(h, dq, de);
+    if (rc) return rc;
+    const int gx = (nd.P + 63) / 64;
+    hipLaunchKernelGGL(k_update, dim3(gx), dim3(64, 4), 0, h->stream, nd, (int)UPD_GRAD_ONLY, 0.f, de, h->slabs, h->grid,
+                       h->q_cur, h->g_cur, const_cast<float*>(dq), h->p, h->tmp);
+    // EN_TRACE leaves the chain's scalar record alone; stat comes from the slabs
+    if (!h->trace || h->trace_cap < 2) {
+        if (h->trace) hipFree(h->trace);
+        HIPCHK(hipMalloc(&h->trace, 4096 * sizeof(double))); h->trace_cap = 4096;
+    }
+    hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, nd, (int)EN_TRACE, de, dq, h->p, h->q_cur, h->pstat,
+                       h->grid, h->n, h->sc, h->trace);
+    HIPCHK(hipGetLastError());
+    double lp = 0.0;
+    HIPCHK(hipMemcpyAsync(&lp, h->trace, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (grad) HIPCHK(hipMemcpyAsync(grad, h->tmp, (size_t)nd.P * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> ps;
+    if (stat) { ps.resize(h->grid); HIPCHK(hipMemcpyAsync(ps.data(), h->pstat, (size_t)h->grid * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->profile) drain_profile(h);
+    if (logp) *logp = lp;
+    if (stat) { double s = 0; for (double v : ps) s += v; *stat = s; }
+    return 0;
+}
+
+extern "C" int tbnn_forward(tbnn_handle h, const float* theta, const float* X, int64_t n, float* out) {
+    NEED(h);
+    if (!X || !out || n < 1) return fail(-1, "forward: null pointer or n < 1");
+    HIPCHK(hipSetDevice(h->device));
+    const NetDev& nd = h->nd;
+    const float* dq = h->q_cur;
+    if (theta) { HIPCHK(hipMemcpyAsync(h->q, theta, (size_t)nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream)); dq = h->q; }
+    float *dXf = nullptr, *dOut = nullptr, *scr = nullptr;
+    const long nblk = (n + GEN_RB - 1) / GEN_RB;
+    const int grid = (int)std::min<long>(nblk, 512);
+    const size_t per = generic_scratch_floats(nd);
+    HIPCHK(hipMalloc(&dXf, (size_t)n * nd.d_in * sizeof(float)));
+    HIPCHK(hipMalloc(&dOut, (size_t)n * nd.d_out * sizeof(float)));
+    HIPCHK(hipMalloc(&scr, per * sizeof(float) * grid));
+    HIPCHK(hipMemcpyAsync(dXf, X, (size_t)n * nd.d_in * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_forward_generic, dim3(grid), dim3(GEN_RB), 0, h->stream, nd, dq, dXf, (long)n, scr, per, dOut);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dOut, (size_t)n * nd.d_out * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(dXf); hipFree(dOut); hipFree(scr);
+    return 0;
+}
+
+// enqueue one transition (no sync).  trace: device array of L+1 doubles or null.
+static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, const float* d_logu, double* d_trace,
+                              Scal* d_out) {
+    const NetDev& nd = h->nd;
+    int rc = ensure_current(h, nullptr);
+    if (rc) return rc;
+    if (d_trace) launch_energy(h, EN_CUR, h->eta, h->q_cur, d_trace);   // re-derives logp0 from the cached stat
+    hipLaunchKernelGGL(k_begin, dim3(1), dim3(1024), 0, h->stream, nd, d_p0, d_logu, h->epoch, h->key0, h->key1, h->p, h->sc);
+    launch_update(h, UPD_FIRST, eps, h->eta, h->q, h->g);
+    for (int t = 1; t <= L; ++t) {
+        rc = launch_fwd_bwd(h, h->q, h->eta);
+        if (rc) return rc;
+        if (d_trace && t < L) {
+            // logp at q_t needs the prior at q_t: evaluate before the drift
+            launch_update(h, UPD_GRAD_ONLY, 0.f, h->eta, h->q, h->g);
+            launch_energy(h, EN_TRACE, h->eta, h->q, d_trace + t);
+        }
+        launch_update(h, t < L ? UPD_MID : UPD_LAST, eps, h->eta, h->q, h->g);
+    }
+    launch_energy(h, EN_NEW, h->eta, h->q, d_trace ? d_trace + L : nullptr);
+    hipLaunchKernelGGL(k_commit, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, h->sc, h->q, h->g, h->q_cur, h->g_cur);
+    hipLaunchKernelGGL(k_commit_scal, dim3(1), dim3(64), 0, h->stream, h->sc, d_out);
+    HIPCHK(hipGetLastError());
+    h->epoch += 1;
+    return 0;
+}
+
+static void fill_out(const Scal& s, int L, float dev_us, float fb_us, tbnn_step_out* o) {
+    o->accepted = s.accepted; o->n_leapfrog = L;
+    o->log_accept_ratio = (float)s.lar;
+    o->accept_prob = s.lar < 0 ? (float)exp(s.lar) : 1.f;      // network.py:410-411
+    o->logp_old = s.logp_cur; o->logp_new = s.logp_new;
+    o->kinetic_old = s.k0; o->kinetic_new = s.k1;
+    o->sjd = s.sjd; o->device_us = dev_us; o->fwdbwd_us = fb_us;
+}
+
+extern "C" int tbnn_hmc_step(tbnn_handle h, float eps, int32_t L, const float* p0, const float* log_u,
+                             tbnn_step_out* out, double* trace_logp) {
+    NEED(h);
+    if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
+    if (L < 1) return fail(-1, "L must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    const NetDev& nd = h->nd;
+    const float* d_p0 = nullptr; const float* d_lu = nullptr;
+    if (p0) { HIPCHK(hipMemcpyAsync(h->p0_inj, p0, (size_t)nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream)); d_p0 = h->p0_inj; }
+    if (log_u) { HIPCHK(hipMemcpyAsync(h->logu_inj, log_u, sizeof(float), hipMemcpyHostToDevice, h->stream)); d_lu = h->logu_inj; }
+    double* d_trace = nullptr;
+    if (trace_logp) {
+        if (h->trace_cap < L + 1) {
+            if (h->trace) hipFree(h->trace);
+            h->trace = nullptr; h->trace_cap = 0;
+            HIPCHK(hipMalloc(&h->trace, (size_t)(L + 1 + 4096) * sizeof(double))); h->trace_cap = L + 1 + 4096;
+        }
+        d_trace = h->trace;
+    }
+    // the bootstrap evaluation (Q10: the reference pays it every epoch) is outside the timed events only
+    // when it is cached; ensure_current is part of enqueue_transition.
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    int rc = enqueue_transition(h, eps, L, d_p0, d_lu, d_trace, h->sc_out);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sc_host, h->sc_out, sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
+    if (trace_logp) HIPCHK(hipMemcpyAsync(trace_logp, h->trace, (size_t)(L + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    const float fb = h->profile ? drain_profile(h) : 0.f;
+    if (out) fill_out(*h->sc_host, L, ms * 1000.f, fb, out);
+    return 0;
+}
+
+extern "C" int tbnn_hmc_run(tbnn_handle h, float eps, int32_t L, int32_t n_epochs, tbnn_step_out* outs) {
+    NEED(h);
+    if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
+    if (L < 1 || n_epochs < 1) return fail(-1, "L and n_epochs must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    Scal* d_recs = nullptr;
+    HIPCHK(hipMalloc(&d_recs, (size_t)n_epochs * sizeof(Scal)));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int e = 0; e < n_epochs; ++e) {
+        int rc = enqueue_transition(h, eps, L, nullptr, nullptr, nullptr, d_recs + e);
+        if (rc) { hipFree(d_recs); return rc; }
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    std::vector<Scal> recs(n_epochs);
+    HIPCHK(hipMemcpyAsync(recs.data(), d_recs, (size_t)n_epochs * sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    const float fb = h->profile ? drain_profile(h) : 0.f;
+    if (outs)
+        for (int e = 0; e < n_epochs; ++e) fill_out(recs[e], L, ms * 1000.f / n_epochs, fb / n_epochs, outs + e);
+    hipFree(d_recs);
+    return 0;
+}
+
+extern "C" int tbnn_hyper_logp_grad(tbnn_handle h, const float* eta, double* logp, float* grad) {
+    NEED(h);
+    if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    const NetDev& nd = h->nd;
+    int rc = ensure_current(h, nullptr);   // stat_cur = sum (y-f)^2 at q_cur (closed-form data term)
+    if (rc) return rc;
+    float* de = h->eta;
+    if (eta) { HIPCHK(hipMemcpyAsync(h->tmp + nd.P, eta, (size_t)nd.H * sizeof(float), hipMemcpyHostToDevice, h->stream)); de = h->tmp + nd.P; }
+    hipLaunchKernelGGL(k_hyper, dim3(1), dim3(HYP_THREADS), 0, h->stream, nd, (int)HYP_EVAL, 0.f, 0, de, h->q_cur, h->n,
+                       (const float*)nullptr, (const float*)nullptr, 0u, h->key0, h->key1, h->sc, h->hyp_ws, h->sc_out);
+    HIPCHK(hipGetLastError());
+    std::vector<float> ws(hyper_ws_bytes(nd) / sizeof(float));
+    HIPCHK(hipMemcpyAsync(ws.data(), h->hyp_ws, hyper_ws_bytes(nd), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sc_host, h->sc_out, sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (logp) *logp = h->sc_host->logp_new;
+    if (grad) memcpy(grad, ws.data() + HYP_WS_GRAD * nd.H, (size_t)nd.H * sizeof(float));
+    return 0;
+}
+
+extern "C" int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const float* p0, const float* log_u,
+                               tbnn_step_out* out) {
+    NEED(h);
+    if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
+    if (L_h < 1) return fail(-1, "L_h must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    const NetDev& nd = h->nd;
+    int rc = ensure_current(h, nullptr);
+    if (rc) return rc;
+    const float* d_p0 = nullptr; const float* d_lu = nullptr;
+    if (p0) { HIPCHK(hipMemcpyAsync(h->p0_inj, p0, (size_t)nd.H * sizeof(float), hipMemcpyHostToDevice, h->stream)); d_p0 = h->p0_inj; }
+    if (log_u) { HIPCHK(hipMemcpyAsync(h->logu_inj, log_u, sizeof(float), hipMemcpyHostToDevice, h->stream)); d_lu = h->logu_inj; }
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    // the hyper transition uses the epoch counter of the weight transition that preceded it
+    const uint32_t ep = h->epoch > 0 ? h->epoch - 1 : 0;
+    hipLaunchKernelGGL(k_hyper, dim3(1), dim3(HYP_THREADS), 0, h->stream, nd, (int)HYP_STEP, eps_h, (int)L_h, h->eta, h->q_cur,
+                       h->n, d_p0, d_lu, ep, h->key0, h->key1, h->sc, h->hyp_ws, h->sc_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sc_host, h->sc_out, sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    if (out) fill_out(*h->sc_host, L_h, ms * 1000.f, 0.f, out);
+    // eta changed => the weight target changed: prior part of logp/grad at q_cur must be refreshed;
+    // the data statistic is unchanged but the simplest correct thing is a full refresh.
+    if (h->sc_host->accepted) h->cur_valid = false;
+    return 0;
+}
+
+extern "C" int tbnn_export_sample_device(tbnn_handle h, float* d_out) {
+    NEED(h); if (!d_out) return fail(-1, "null d_out");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(d_out, h->q_cur, (size_t)h->nd.P * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_out + h->nd.P, h->eta, (size_t)h->nd.H * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, int32_t n, float* out_normals,
+                               float* out_log_u) {
+    NEED(h);
+    if (n < 1 || !out_normals) return fail(-1, "debug_draw: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    float* d = nullptr;
+    HIPCHK(hipMalloc(&d, (size_t)(n + 1) * sizeof(float)));
+    hipLaunchKernelGGL(k_debug_draw, dim3((n + 255) / 256), dim3(256), 0, h->stream, epoch, purpose, h->key0, h->key1, (int)n, d, d + n);
+    HIPCHK(hipGetLastError());
+    std::vector<float> host(n + 1);
+    HIPCHK(hipMemcpyAsync(host.data(), d, (size_t)(n + 1) * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(d);
+    memcpy(out_normals, host.data(), (size_t)n * sizeof(float));
+    if (out_log_u) *out_log_u = host[n];
+    return 0;
+}

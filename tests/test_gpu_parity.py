@@ -1,0 +1,171 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerances (BASELINE.md section 5 / north_star "stated fp32 tolerance"):
+  * target log-prob: <= 4e-6 relative (+ 1e-3 absolute for tiny values)
+  * gradient: <= 1e-4 relative to the tensor's inf-norm
+  * accept decision / log-accept-ratio with injected p0, log u: |dlar| <= 2e-2 + 1e-4*|lar|
+The oracle arm is float64 (the exact value of the reference's formula); the
+float32 oracle arm (the reference's own arithmetic) must sit within the same
+band, which the CPU suite checks (tests/test_oracle.py).
+"""
+import numpy as np
+import pytest
+
+import tbnn_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+LOGP_RTOL = 4e-6
+GRAD_RTOL = 1e-4
+
+
+def make_chain(native, spec, kernel=None, **kw):
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    return native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd,
+                        kernel=native.KERNEL_AUTO if kernel is None else kernel, **kw)
+
+
+def check_logp_grad(native, spec, X, Y, theta, eta, kernel=None):
+    ch = make_chain(native, spec, kernel)
+    ch.set_data(X, Y)
+    lp, g, stat = ch.logp_grad(theta, eta)
+    lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)
+    assert abs(lp - lp64) <= LOGP_RTOL * abs(lp64) + 1e-3, (ch.kernel_name, lp, lp64)
+    for l, (ow, ob) in zip(spec.layers, spec.offsets()):
+        for a, b in ((ow, ob), (ob, ob + l.out_dim)):
+            ref = g64[a:b]
+            err = np.abs(g[a:b] - ref).max()
+            assert err <= GRAD_RTOL * max(np.abs(ref).max(), 1e-3), (ch.kernel_name, a, b, err, np.abs(ref).max())
+    ch.close()
+    return lp, g
+
+
+CASES = {
+    # BASELINE configs[0] (plumbing): 1->10->10->1, GaussianLikelihood, 1k rows
+    "c1": dict(dims=[1, 10, 10, 1], n=1000, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN),
+    # literal Examples/trainRegression.py shape: 1->10->10->10->1 Tanh, GaussianDenseLayer, FixedGaussian, 11 rows
+    "trainreg": dict(dims=[1, 10, 10, 10, 1], n=11, act=o.ACT_TANH, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_FIXED_GAUSSIAN),
+    # down-scaled configs[1]
+    "c2_small": dict(dims=[5, 50, 50, 50, 1], n=1000, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN),
+    # ragged: n not a multiple of any tile
+    "c2_ragged": dict(dims=[5, 50, 50, 50, 1], n=777, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN),
+    # down-scaled configs[4]: Bernoulli + sigmoid
+    "c5_small": dict(dims=[20, 100, 100, 2], n=600, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_BERNOULLI),
+    # down-scaled configs[3]
+    "c4_small": dict(dims=[10, 200, 200, 200, 1], n=300, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN),
+    # single row, single layer
+    "tiny": dict(dims=[3, 1], n=1, act=o.ACT_NONE, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN),
+    "sigmoid_hidden": dict(dims=[4, 7, 3], n=130, act=o.ACT_SIGMOID, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN),
+}
+
+
+def problem(case):
+    c = CASES[case]
+    return o.synth_problem(c["dims"], c["n"], c["act"], c["prior"], c["lik"])
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_logp_grad_generic(native, case):
+    spec, X, Y, theta, eta = problem(case)
+    check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_GENERIC)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_forward(native, case):
+    spec, X, Y, theta, eta = problem(case)
+    ch = make_chain(native, spec, native.KERNEL_GENERIC)
+    f = ch.forward(X, theta)
+    ref = o.forward(spec, theta, X, np.float64)
+    assert f.shape == ref.shape
+    np.testing.assert_allclose(f, ref, rtol=2e-5, atol=2e-5)
+    ch.close()
+
+
+@pytest.mark.parametrize("case", ["c1", "trainreg", "c2_small", "c5_small"])
+def test_hmc_step_injected(native, case):
+    """5-step leapfrog trajectory + accept decision with injected p0, log u."""
+    spec, X, Y, theta, eta = problem(case)
+    rng = np.random.default_rng(7)
+    p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+    eps = {"c1": 2e-4, "trainreg": 2e-3, "c2_small": 5e-5, "c5_small": 2e-4}[case]
+    L = 5
+    for log_u in (np.log(0.5), -1e30, 1e30):
+        ch = make_chain(native, spec, native.KERNEL_GENERIC)
+        ch.set_data(X, Y)
+        ch.set_state(theta)
+        ch.set_hypers(eta)
+        out = ch.hmc_step(eps, L, p0=p0, log_u=log_u, trace=True)
+        ref = o.weight_step(spec, theta, eta, X, Y, eps, L, p0, log_u, np.float32, energy_dtype=np.float64)
+        ref64 = o.weight_step(spec, theta, eta, X, Y, eps, L, p0, log_u, np.float64)
+        tr = np.asarray(out["trace_logp"])
+        np.testing.assert_allclose(tr, np.asarray(ref64.trace_logp), rtol=LOGP_RTOL, atol=2e-3)
+        assert abs(out["log_accept_ratio"] - ref64.log_accept_ratio) <= 2e-2 + 1e-4 * abs(ref64.log_accept_ratio)
+        if abs(ref64.log_accept_ratio - log_u) > 0.1:
+            assert bool(out["accepted"]) == ref64.accepted
+        new = ch.get_state()
+        expect = ref64.theta_proposed if out["accepted"] else theta
+        np.testing.assert_allclose(new, expect, rtol=0, atol=2e-5 * max(1.0, np.abs(expect).max()))
+        if out["accepted"]:
+            assert abs(out["sjd"] - ref64.sjd) <= 1e-3 * ref64.sjd + 1e-12
+        else:
+            assert out["sjd"] == 0.0
+        assert abs(out["accept_prob"] - ref64.accept_prob) <= 2e-2
+        ch.close()
+
+
+def test_chain_rng_matches_oracle(native):
+    spec, X, Y, theta, eta = problem("c1")
+    ch = make_chain(native, spec, native.KERNEL_GENERIC, seed=50, chain_id=3)
+    z, lu = ch.debug_draw(epoch=5, purpose=0, n=141)
+    ref = o.philox_normals(141, 50, 3, 5, 0)
+    np.testing.assert_allclose(z, ref, rtol=0, atol=2e-6)
+    assert abs(lu - o.philox_log_uniform(50, 3, 5, 1)) < 1e-6
+    ch.close()
+
+
+def test_hmc_run_matches_steps(native):
+    """tbnn_hmc_run (no host round trip) == the same epochs issued one by one."""
+    spec, X, Y, theta, eta = problem("c1")
+    res = []
+    for mode in ("run", "steps"):
+        ch = make_chain(native, spec, native.KERNEL_GENERIC, seed=50, chain_id=1)
+        ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+        if mode == "run":
+            outs = ch.hmc_run(2e-4, 7, 6)
+        else:
+            outs = [ch.hmc_step(2e-4, 7) for _ in range(6)]
+        res.append((ch.get_state(), [o_["log_accept_ratio"] for o_ in outs], [o_["accepted"] for o_ in outs]))
+        ch.close()
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert any(res[0][2])
+
+
+@pytest.mark.parametrize("case", ["c1", "trainreg", "c2_small", "c5_small"])
+def test_hyper_logp_grad(native, case):
+    spec, X, Y, theta, eta = problem(case)
+    ch = make_chain(native, spec, native.KERNEL_GENERIC)
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    rng = np.random.default_rng(3)
+    eta2 = (eta + 0.05 * rng.standard_normal(eta.size)).astype(np.float32)
+    lp, g = ch.hyper_logp_grad(eta2)
+    lp64, g64 = o.hyper_log_prob_and_grad(spec, eta2, theta, X, Y, np.float64)
+    assert abs(lp - lp64) <= LOGP_RTOL * abs(lp64) + 1e-3
+    np.testing.assert_allclose(g, g64, rtol=2e-4, atol=1e-3 + 2e-6 * np.abs(g64).max())
+    ch.close()
+
+
+@pytest.mark.parametrize("case", ["c1", "trainreg", "c5_small"])
+def test_hyper_step_injected(native, case):
+    spec, X, Y, theta, eta = problem(case)
+    rng = np.random.default_rng(11)
+    p0 = rng.standard_normal(spec.n_hypers).astype(np.float32)
+    for log_u in (-1e30, 1e30):
+        ch = make_chain(native, spec, native.KERNEL_GENERIC)
+        ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+        out = ch.hyper_step(1e-4, 20, p0=p0, log_u=log_u)
+        ref = o.hyper_step(spec, eta, theta, X, Y, 1e-4, 20, p0, log_u, np.float64)
+        assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-3 * abs(ref.log_accept_ratio)
+        assert bool(out["accepted"]) == ref.accepted
+        np.testing.assert_allclose(ch.get_hypers(), ref.theta, rtol=1e-4, atol=1e-5)
+        ch.close()
