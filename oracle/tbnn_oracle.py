@@ -826,7 +826,8 @@ def synth_problem(dims, n, act=ACT_RELU, prior=PRIOR_CAUCHY, likelihood=LIK_GAUS
         Y = (ng.random(f.T.shape) < f.T).astype(np.float32)
     else:
         Y = f.T + 0.1 * ng.standard_normal(f.T.shape).astype(np.float32)
-        Y = ((Y - Y.mean(0)) / Y.std(0)).astype(np.float32)
+        sd_y = Y.std(0)
+        Y = ((Y - Y.mean(0)) / np.where(sd_y > 0, sd_y, 1.0)).astype(np.float32)
     parts = []
     for i, l in enumerate(spec.layers):
         sd = (2.0 / l.out_dim) ** 0.5

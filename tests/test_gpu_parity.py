@@ -70,6 +70,31 @@ def test_logp_grad_generic(native, case):
     check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_GENERIC)
 
 
+FAST_CASES = ["c1", "trainreg", "c2_small", "c2_ragged"]
+
+
+@pytest.mark.parametrize("case", FAST_CASES)
+def test_logp_grad_fast(native, case):
+    """the shape-specialised MFMA kernel (TBNN_KERNEL_FAST must exist for these shapes)"""
+    spec, X, Y, theta, eta = problem(case)
+    check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 4096 + 3])
+def test_logp_grad_fast_ragged_rows(native, n):
+    spec, X, Y, theta, eta = o.synth_problem([5, 50, 50, 50, 1], n)
+    check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+
+
+def test_fast_vs_generic_full_size(native):
+    """BASELINE configs[1] at full size (n=1e5): MFMA kernel vs generic kernel vs fp64 oracle."""
+    spec, X, Y, theta, eta = o.synth_problem([5, 50, 50, 50, 1], 100000)
+    lp_f, g_f = check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+    lp_g, g_g = check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_GENERIC)
+    assert abs(lp_f - lp_g) <= 1e-6 * abs(lp_g)
+    assert np.abs(g_f - g_g).max() <= 2e-5 * np.abs(g_g).max()
+
+
 @pytest.mark.parametrize("case", list(CASES))
 def test_forward(native, case):
     spec, X, Y, theta, eta = problem(case)
@@ -81,16 +106,18 @@ def test_forward(native, case):
     ch.close()
 
 
+@pytest.mark.parametrize("kern", ["generic", "auto"])
 @pytest.mark.parametrize("case", ["c1", "trainreg", "c2_small", "c5_small"])
-def test_hmc_step_injected(native, case):
+def test_hmc_step_injected(native, case, kern):
     """5-step leapfrog trajectory + accept decision with injected p0, log u."""
     spec, X, Y, theta, eta = problem(case)
+    kernel = native.KERNEL_GENERIC if kern == "generic" else native.KERNEL_AUTO
     rng = np.random.default_rng(7)
     p0 = rng.standard_normal(spec.n_params).astype(np.float32)
     eps = {"c1": 2e-4, "trainreg": 2e-3, "c2_small": 5e-5, "c5_small": 2e-4}[case]
     L = 5
     for log_u in (np.log(0.5), -1e30, 1e30):
-        ch = make_chain(native, spec, native.KERNEL_GENERIC)
+        ch = make_chain(native, spec, kernel)
         ch.set_data(X, Y)
         ch.set_state(theta)
         ch.set_hypers(eta)
