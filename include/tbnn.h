@@ -77,7 +77,7 @@ typedef struct tbnn_step_out {
     double kinetic_new;        /* 1/2 |p_L|^2 */
     double sjd;                /* sum (new-old)^2 over theta (0 when rejected) */
     float device_us;           /* hipEvent time of the whole transition */
-    float fwdbwd_us;           /* hipEvent time summed over the fused fwd+bwd launches */
+    float fwdbwd_us;           /* mean hipEvent duration of the profiled fused fwd+bwd launches (0: profiling off) */
 } tbnn_step_out;
 
 typedef struct tbnn_ctx* tbnn_handle;
@@ -148,8 +148,9 @@ int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, int32_t n, 
                     float* out_log_u);
 /* epoch counter that keys the RNG (incremented by every tbnn_hmc_step) */
 int tbnn_set_epoch(tbnn_handle h, uint32_t epoch);
-/* record a hipEvent pair around every fused fwd+bwd launch (fills fwdbwd_us) */
-int tbnn_set_profiling(tbnn_handle h, int on);
+/* record a hipEvent pair around every stride-th fused fwd+bwd launch on the
+ * chain's stream (fills fwdbwd_us); stride <= 0 turns it off */
+int tbnn_set_profiling(tbnn_handle h, int stride);
 
 /* ---- (eps, L) adapter: paramAdapter (tensorBNN/paramAdapter.py:11-292), host C++ ---- */
 typedef struct tbnn_adapter* tbnn_adapter_handle;

@@ -242,8 +242,8 @@ class Chain:
     def set_epoch(self, epoch: int):
         _check(lib.tbnn_set_epoch(self._h, int(epoch)))
 
-    def set_profiling(self, on: bool):
-        _check(lib.tbnn_set_profiling(self._h, int(bool(on))))
+    def set_profiling(self, stride: int):
+        _check(lib.tbnn_set_profiling(self._h, int(stride)))
 
 
 class Adapter:

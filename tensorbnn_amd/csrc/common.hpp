@@ -23,6 +23,7 @@ struct NetDev {
     int sumOut;                   // sum of out dims = floats per row in the activation record
     int maxW;                     // widest layer (in or out)
     float fixed_sd;
+    int reserved_flags;           // bit 0: fast kernel processes one tile at a time (diagnostic)
 };
 
 // Per-chain scalar record kept on the device (doubles: energies are summed

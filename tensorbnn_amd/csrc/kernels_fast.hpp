@@ -2,8 +2,9 @@
 // f32 MFMA (v_mfma_f32_16x16x4_f32) for every contraction, weights resident in
 // LDS, activations and ALL dW accumulators resident in registers.
 //
-// One wave owns a 16-row tile of the training matrix at a time and needs no
-// cross-wave synchronisation inside the row loop:
+// One wave owns 16-row tiles of the training matrix (two at a time, interleaved
+// for ILP and shared weight-operand loads; a single one for the remainder) and
+// needs no cross-wave synchronisation inside the row loop:
 //   forward   Z_l[unit, row] = W_l . A_{l-1}      (A operand = W_l from LDS,
 //             B operand = the previous layer's accumulator registers AS THEY
 //             STAND: the MFMA's k index is mapped to unit 16kt+4g+s so that
@@ -27,12 +28,34 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FAST_WAVES 4
 #define FAST_THREADS (FAST_WAVES * 64)
+#define FAST_SLOTS 2     // tiles a wave works on at a time
 
-template <int... Ds>
+// HACT: activation after every hidden layer, LACT: after the last layer,
+// BERN: Bernoulli likelihood (else the Gaussian family) -- all compile-time so
+// the tile body is one straight-line block the scheduler can interleave.
+template <int HACT_, int LACT_, bool BERN_, int... Ds>
 struct Shape {
     static constexpr int NL = sizeof...(Ds) - 1;
     static constexpr int D[sizeof...(Ds)] = {Ds...};
+    static constexpr int HACT = HACT_, LACT = LACT_;
+    static constexpr bool BERN = BERN_;
+    static constexpr int act(int l) { return l == NL - 1 ? LACT_ : HACT_; }
 };
+
+template <int ACT>
+__device__ __forceinline__ float actc_fwd(float z) {
+    if constexpr (ACT == TBNN_ACT_RELU) return __builtin_amdgcn_fmed3f(z, 0.f, __builtin_inff());   // one v_med3_f32 (z finite)
+    else if constexpr (ACT == TBNN_ACT_TANH) return tanhf(z);
+    else if constexpr (ACT == TBNN_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
+    else return z;
+}
+template <int ACT>
+__device__ __forceinline__ float actc_bwd(float a) {
+    if constexpr (ACT == TBNN_ACT_RELU) return a > 0.f ? 1.f : 0.f;
+    else if constexpr (ACT == TBNN_ACT_TANH) return 1.f - a * a;
+    else if constexpr (ACT == TBNN_ACT_SIGMOID) return a * (1.f - a);
+    else return 1.f;
+}
 
 template <class S>
 struct FastCfg {
@@ -44,330 +67,479 @@ struct FastCfg {
     static constexpr int NT(int l) { return cdiv(in(l) + 1, 16); }       // N tiles of dW_l (+1: ones column -> db)
     static constexpr int KG(int l) { return cdiv(in(l), 16); }           // 16-unit k groups of layer l's input
     static constexpr int LDW(int l) { return 16 * KG(l) + 4; }           // pitch of the W_l image (== 4 mod 8)
-    static constexpr int PA(int l) { return 16 * NT(l) + 4; }            // pitch of the A_{l} (input of layer l) image
     static constexpr int maxMT() { int m = 0; for (int l = 0; l < NL; ++l) m = MT(l) > m ? MT(l) : m; return m; }
+    static constexpr int maxNT() { int m = 0; for (int l = 0; l < NL; ++l) m = NT(l) > m ? NT(l) : m; return m; }
+    static constexpr int PA = 16 * maxNT() + 4;                          // pitch of the A_{l-1} image (== 4 mod 8)
     static constexpr int PD = 16 * maxMT() + 4;                          // pitch of the delta image
     // number of valid k-steps s in group kt of a K dimension of size K (unit = 16kt+4g+s)
     static constexpr int ksteps(int K, int kt) { int rem = K - 16 * kt; return rem >= 4 ? 4 : (rem < 0 ? 0 : rem); }
-    // LDS layout (floats)
+    // LDS layout (floats): [W images][bias images][per wave: FAST_SLOTS x (A image, D image)]
     static constexpr int woff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += 16 * MT(m) * LDW(m); return o; }
     static constexpr int W_FLOATS = woff(NL);
     static constexpr int boff(int l) { int o = W_FLOATS; for (int m = 0; m < l; ++m) o += 16 * MT(m); return o; }
-    static constexpr int WB_FLOATS = boff(NL);
-    static constexpr int aoff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += 16 * PA(m); return o; }   // per wave
-    static constexpr int doff = aoff(NL);
-    static constexpr int WAVE_FLOATS = doff + 16 * PD;
+    static constexpr int WB_FLOATS = boff(NL);                           // == the global padded image (k_update writes it)
+    // transposed weight images W_l^T [in-unit][out-unit] for the delta chain (l >= 1), built in the prologue
+    static constexpr int LDT(int l) { return 16 * MT(l) + 4; }
+    static constexpr int toff(int l) { int o = WB_FLOATS; for (int m = 1; m < l; ++m) o += 16 * KG(m) * LDT(m); return o; }
+    static constexpr int STATIC_FLOATS = toff(NL);
+    static constexpr int SLOT_FLOATS = 16 * PA + 16 * PD;
+    static constexpr int WAVE_FLOATS = FAST_SLOTS * SLOT_FLOATS;
     static constexpr int P() { int p = 0; for (int l = 0; l < NL; ++l) p += in(l) * out(l) + out(l); return p; }
     static constexpr int offW(int l) { int p = 0; for (int m = 0; m < l; ++m) p += in(m) * out(m) + out(m); return p; }
-    static constexpr int REGION = (FAST_WAVES * WAVE_FLOATS > P()) ? FAST_WAVES * WAVE_FLOATS : P();
-    static constexpr int LDS_FLOATS = WB_FLOATS + REGION;
     static constexpr int dwoff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += MT(m) * NT(m); return o; }
     static constexpr int DW_TILES = dwoff(NL);
+    // epilogue staging: tiles per pass with all 4 waves' copies resident
+    static constexpr int MIN_LDS = STATIC_FLOATS + FAST_WAVES * WAVE_FLOATS;
+    static constexpr int EP_TILES_WANT = DW_TILES < 16 ? DW_TILES : 16;
+    static constexpr int LDS_FLOATS = MIN_LDS > EP_TILES_WANT * FAST_WAVES * 256 ? MIN_LDS : EP_TILES_WANT * FAST_WAVES * 256;
+    static constexpr int EP_TILES = LDS_FLOATS / (FAST_WAVES * 256) < DW_TILES ? LDS_FLOATS / (FAST_WAVES * 256) : DW_TILES;
     static constexpr int aroff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += MT(m); return o; }   // act register tiles
     static constexpr int ACT_TILES = aroff(NL);
+    static constexpr int KS0 = cdiv(in(0), 4);
+    static constexpr int MTL = MT(NL - 1);
 };
+
+// diagnostic build only (-DTBNN_TILE_STAMPS): shader-clock stamps at the phase boundaries of a tile step
+#ifdef TBNN_TILE_STAMPS
+__device__ unsigned long long g_tile_stamps[64];
+#define TSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0) g_tile_stamps[k] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// the NS (1..4) k-step operands of one k-group: 4, 8 or 16 bytes from LDS
+// (ns is a constant after unrolling: the branches fold)
+__device__ __forceinline__ f32x4 load_ks(const float* p, int ns) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ns >= 3) v = *reinterpret_cast<const f32x4*>(p);
+    else if (ns == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    else v[0] = p[0];
+    return v;
+}
 
-// Everything one wave keeps in registers across the row loop.
+// per-tile register state (outputs of every layer + the layer-0 operand)
 template <class S>
-struct FastRegs {
+struct TileRegs {
     using C = FastCfg<S>;
-    f32x4 dW[C::DW_TILES];      // dW_l tiles [mt][nt], D layout
-    f32x4 a[C::ACT_TILES];      // outputs of every layer for the current tile
+    f32x4 a[C::ACT_TILES];
+    float x0[C::KS0];
 };
 
-template <class S, int l>
+template <class S, int l, int NTL>
 struct FwdLayer {
     using C = FastCfg<S>;
-    // bprev: B operands of this layer = previous layer's output tiles (l >= 1)
-    static __device__ __forceinline__ void run(FastRegs<S>& R, const float* __restrict__ lds, float* wl, int i16, int g,
-                                                const NetDev& nd, const float (&x0)[C::cdiv(C::in(0), 4)]) {
+    static __device__ __forceinline__ void run(TileRegs<S> (&T)[NTL], const float* __restrict__ lds, int i16, int g) {
         constexpr int MT = C::MT(l);
-        f32x4 acc[MT];
+        f32x4 acc[NTL][MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * mt + 4 * g);   // bias in D layout
+        for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * mt + 4 * g);   // bias in D layout
+#pragma unroll
+            for (int tl = 0; tl < NTL; ++tl) acc[tl][mt] = b;
+        }
         if constexpr (l == 0) {
             // natural k mapping: step t covers units 4t+g, B operand straight from X
-            constexpr int KS = C::cdiv(C::in(0), 4);
 #pragma unroll
-            for (int t = 0; t < KS; ++t) {
+            for (int t = 0; t < C::KS0; ++t) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const float A = lds[C::woff(0) + (16 * mt + i16) * C::LDW(0) + 4 * t + g];
-                    acc[mt] = mfma16(A, x0[t], acc[mt]);
+#pragma unroll
+                    for (int tl = 0; tl < NTL; ++tl) acc[tl][mt] = mfma16(A, T[tl].x0[t], acc[tl][mt]);
                 }
             }
         } else {
+            // A operands (W_l rows, 4 k-steps per 16-B read) are fetched one k-group ahead of their MFMAs
             constexpr int KG = C::KG(l);
+            const float* wrow = lds + C::woff(l) + i16 * C::LDW(l) + 4 * g;
+            f32x4 An[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) An[mt] = load_ks(wrow + 16 * mt * C::LDW(l), C::ksteps(C::in(l), 0));
 #pragma unroll
             for (int kt = 0; kt < KG; ++kt) {
                 f32x4 A4[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    A4[mt] = *reinterpret_cast<const f32x4*>(lds + C::woff(l) + (16 * mt + i16) * C::LDW(l) + 16 * kt + 4 * g);
+                for (int mt = 0; mt < MT; ++mt) A4[mt] = An[mt];
+                if (kt + 1 < KG) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        An[mt] = load_ks(wrow + 16 * mt * C::LDW(l) + 16 * (kt + 1), C::ksteps(C::in(l), kt + 1));
+                }
 #pragma unroll
                 for (int s = 0; s < C::ksteps(C::in(l), kt); ++s) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = mfma16(A4[mt][s], R.a[C::aroff(l - 1) + kt][s], acc[mt]);
+#pragma unroll
+                        for (int tl = 0; tl < NTL; ++tl)
+                            acc[tl][mt] = mfma16(A4[mt][s], T[tl].a[C::aroff(l - 1) + kt][s], acc[tl][mt]);
                 }
             }
         }
-        const int act = nd.act[l];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act_fwd(acc[mt][r], act);
-            R.a[C::aroff(l) + mt] = v;
-        }
-        if constexpr (l + 1 < C::NL) {
-            // transposed image of a_{l+1} (= input of layer l+1) for dW_{l+1}; ones column at unit in(l+1)
-            constexpr int u1 = C::in(l + 1);
+        for (int tl = 0; tl < NTL; ++tl)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                f32x4 v = R.a[C::aroff(l) + mt];
-                if constexpr (u1 % 16 != 0) {
-                    if (mt == u1 / 16 && g == (u1 % 16) / 4) v[u1 % 4] = 1.f;
-                }
-                *reinterpret_cast<f32x4*>(wl + C::aoff(l + 1) + i16 * C::PA(l + 1) + 16 * mt + 4 * g) = v;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = actc_fwd<S::act(l)>(acc[tl][mt][r]);
+                T[tl].a[C::aroff(l) + mt] = v;
             }
-        }
+        TSTAMP(1 + l);
+        if constexpr (l + 1 < C::NL) FwdLayer<S, l + 1, NTL>::run(T, lds, i16, g);
     }
 };
 
-template <class S, int l>
+template <class S, int l, int NTL>
 struct BwdLayer {
     using C = FastCfg<S>;
-    // dz: delta tiles of layer l (D layout).  Accumulates dW_l, returns delta of layer l-1 in dzp.
-    static __device__ __forceinline__ void run(FastRegs<S>& R, const float* __restrict__ lds, float* wl, int i16, int g,
-                                                const NetDev& nd, const f32x4 (&dz)[C::MT(l)],
-                                                f32x4 (&dzp)[C::MT(l > 0 ? l - 1 : 0)]) {
+    // dz: delta tiles of layer l (D layout) for each tile slot
+    static __device__ __forceinline__ void run(f32x4 (&dW)[C::DW_TILES], TileRegs<S> (&T)[NTL], const float* __restrict__ lds,
+                                                float* wl, int i16, int g, const f32x4 (&dz)[NTL][C::MT(l)]) {
         constexpr int MT = C::MT(l), NT = C::NT(l);
-        // delta image [row][unit]
+        // transposed images [row][unit] of delta_l and of a_{l-1} (ones column at unit in(l) -> db)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            *reinterpret_cast<f32x4*>(wl + C::doff + i16 * C::PD + 16 * mt + 4 * g) = dz[mt];
-        // dW_l += dz . a_{l-1}^T : k = data row 4g+s
-        float Aop[MT][4], Bop[NT][4];
+        for (int tl = 0; tl < NTL; ++tl) {
+            float* aimg = wl + tl * C::SLOT_FLOATS;
+            float* dimg = aimg + 16 * C::PA;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+            for (int mt = 0; mt < MT; ++mt)
+                *reinterpret_cast<f32x4*>(dimg + i16 * C::PD + 16 * mt + 4 * g) = dz[tl][mt];
+            constexpr int u1 = C::in(l);
+            if constexpr (l == 0) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) Aop[mt][s] = wl[C::doff + (4 * g + s) * C::PD + 16 * mt + i16];
+                for (int t = 0; t < C::KS0; ++t) {
+                    const int u = 4 * t + g;
+                    if (u < u1) aimg[i16 * C::PA + u] = T[tl].x0[t];
+                }
+                if (g == (u1 & 3)) aimg[i16 * C::PA + u1] = 1.f;          // units u1+1.. of the tile: stale but finite, never stored
+            } else {
+                constexpr int MTP = C::MT(l - 1);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Bop[nt][s] = wl[C::aoff(l) + (4 * g + s) * C::PA(l) + 16 * nt + i16];
+                for (int m = 0; m < MTP; ++m) {
+                    f32x4 v = T[tl].a[C::aroff(l - 1) + m];
+                    if constexpr (u1 % 16 != 0) {
+                        if (m == u1 / 16 && g == (u1 % 16) / 4) v[u1 % 4] = 1.f;
+                    }
+                    *reinterpret_cast<f32x4*>(aimg + i16 * C::PA + 16 * m + 4 * g) = v;
+                }
+                if constexpr (u1 % 16 == 0) {
+                    if (g == 0) aimg[i16 * C::PA + u1] = 1.f;
+                }
+            }
         }
+        TSTAMP(10 + 3 * l);
+        // dW operands: k = data row 4g+s.  Issued now, consumed after the delta chain below.
+        float Aop[NTL][MT][4], Bop[NTL][NT][4];
+#pragma unroll
+        for (int tl = 0; tl < NTL; ++tl) {
+            const float* aimg = wl + tl * C::SLOT_FLOATS;
+            const float* dimg = aimg + 16 * C::PA;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) Aop[tl][mt][s] = dimg[(4 * g + s) * C::PD + 16 * mt + i16];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) Bop[tl][nt][s] = aimg[(4 * g + s) * C::PA + 16 * nt + i16];
+            }
+        }
+        // delta_{l-1} = (W_l^T dz) * act'(a_{l-1}) ; M = in(l) units, K = out(l) units;
+        // A operands from the transposed image, one k-group ahead
+        f32x4 dzp[NTL][C::MT(l > 0 ? l - 1 : 0)];
+        if constexpr (l > 0) {
+            constexpr int MTP = C::MT(l - 1);
+            constexpr int KG = C::cdiv(C::out(l), 16);
+            f32x4 acc[NTL][MTP];
+#pragma unroll
+            for (int tl = 0; tl < NTL; ++tl)
+#pragma unroll
+                for (int m = 0; m < MTP; ++m) acc[tl][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* trow = lds + C::toff(l) + i16 * C::LDT(l) + 4 * g;
+            f32x4 An[MTP];
+#pragma unroll
+            for (int m = 0; m < MTP; ++m) An[m] = load_ks(trow + 16 * m * C::LDT(l), C::ksteps(C::out(l), 0));
+#pragma unroll
+            for (int kt = 0; kt < KG; ++kt) {
+                f32x4 A4[MTP];
+#pragma unroll
+                for (int m = 0; m < MTP; ++m) A4[m] = An[m];
+                if (kt + 1 < KG) {
+#pragma unroll
+                    for (int m = 0; m < MTP; ++m)
+                        An[m] = load_ks(trow + 16 * m * C::LDT(l) + 16 * (kt + 1), C::ksteps(C::out(l), kt + 1));
+                }
+#pragma unroll
+                for (int s = 0; s < C::ksteps(C::out(l), kt); ++s) {
+#pragma unroll
+                    for (int m = 0; m < MTP; ++m)
+#pragma unroll
+                        for (int tl = 0; tl < NTL; ++tl) acc[tl][m] = mfma16(A4[m][s], dz[tl][kt][s], acc[tl][m]);
+                }
+            }
+#pragma unroll
+            for (int tl = 0; tl < NTL; ++tl)
+#pragma unroll
+                for (int m = 0; m < MTP; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dzp[tl][m][r] = acc[tl][m][r] * actc_bwd<S::act(l - 1)>(T[tl].a[C::aroff(l - 1) + m][r]);
+        }
+        TSTAMP(11 + 3 * l);
+        // dW_l += dz . a_{l-1}^T
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    R.dW[C::dwoff(l) + mt * NT + nt] = mfma16(Aop[mt][s], Bop[nt][s], R.dW[C::dwoff(l) + mt * NT + nt]);
-        if constexpr (l > 0) {
-            // delta_{l-1} = (W_l^T dz) * act'(a_{l-1}) ; M = in(l) units, K = out(l) units
-            constexpr int MTP = C::MT(l - 1);
-            constexpr int KG = C::cdiv(C::out(l), 16);
-            f32x4 acc[MTP];
 #pragma unroll
-            for (int m = 0; m < MTP; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int tl = 0; tl < NTL; ++tl)
+                        dW[C::dwoff(l) + mt * NT + nt] = mfma16(Aop[tl][mt][s], Bop[tl][nt][s], dW[C::dwoff(l) + mt * NT + nt]);
+        TSTAMP(12 + 3 * l);
+        if constexpr (l > 0) BwdLayer<S, l - 1, NTL>::run(dW, T, lds, wl, i16, g, dzp);
+    }
+};
+
+// one step of the row loop: NTL tiles through forward, likelihood, backward
+template <class S, int NTL>
+struct TileStep {
+    using C = FastCfg<S>;
+    static __device__ __forceinline__ void run(f32x4 (&dW)[C::DW_TILES], double& stat, const float* __restrict__ lds, float* wl,
+                                                int i16, int g, float inv_var, const float (&x)[NTL][C::KS0],
+                                                const float (&y)[NTL][C::MTL][4], const bool (&rvalid)[NTL]) {
+        constexpr int d_out = C::out(C::NL - 1);
+        TileRegs<S> T[NTL];
 #pragma unroll
-            for (int kt = 0; kt < KG; ++kt) {
+        for (int tl = 0; tl < NTL; ++tl)
 #pragma unroll
-                for (int s = 0; s < C::ksteps(C::out(l), kt); ++s) {
+            for (int t = 0; t < C::KS0; ++t) T[tl].x0[t] = x[tl][t];
+        TSTAMP(0);
+        FwdLayer<S, 0, NTL>::run(T, lds, i16, g);
+        // likelihood: f = a_L in D layout (unit 16mt+4g+r, row = lane&15)
+        f32x4 dz[NTL][C::MTL];
 #pragma unroll
-                    for (int m = 0; m < MTP; ++m) {
-                        const float A = lds[C::woff(l) + (16 * kt + 4 * g + s) * C::LDW(l) + 16 * m + i16];
-                        acc[m] = mfma16(A, dz[kt][s], acc[m]);
+        for (int tl = 0; tl < NTL; ++tl)
+#pragma unroll
+            for (int mt = 0; mt < C::MTL; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int u = 16 * mt + 4 * g + r;
+                    float d = 0.f;
+                    if (rvalid[tl] && u < d_out) {
+                        const float fi = T[tl].a[C::aroff(C::NL - 1) + mt][r];
+                        const float yy = y[tl][mt][r];
+                        float da;
+                        if constexpr (S::BERN) {
+                            const float p = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);
+                            const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
+                            const float t1 = (yy == 0.f) ? 0.f : yy * logf(p);
+                            const float t2 = (1.f - yy == 0.f) ? 0.f : (1.f - yy) * log1pf(-p);
+                            stat += (double)(t1 + t2);
+                            da = inside ? (yy / p - (1.f - yy) / (1.f - p)) : 0.f;
+                        } else {
+                            const float res = yy - fi;
+                            stat += (double)res * (double)res;
+                            da = res * inv_var;
+                        }
+                        d = da * actc_bwd<S::LACT>(fi);
                     }
+                    dz[tl][mt][r] = d;
                 }
-            }
-            const int act = nd.act[l - 1];
-#pragma unroll
-            for (int m = 0; m < MTP; ++m) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dzp[m][r] = acc[m][r] * act_bwd(R.a[C::aroff(l - 1) + m][r], act);
-            }
-        }
+        TSTAMP(9);
+        BwdLayer<S, C::NL - 1, NTL>::run(dW, T, lds, wl, i16, g, dz);
     }
 };
 
+// dense slab write-out for the staged tiles [t0, t0+cnt): thread (r = wave, lane) owns register r
+// of every tile; the 4 waves' copies are summed in fixed order; no division anywhere
 template <class S, int l>
-struct BwdChain {
+struct SlabOut {
     using C = FastCfg<S>;
-    static __device__ __forceinline__ void run(FastRegs<S>& R, const float* __restrict__ lds, float* wl, int i16, int g,
-                                                const NetDev& nd, const f32x4 (&dz)[C::MT(l)]) {
-        f32x4 dzp[C::MT(l > 0 ? l - 1 : 0)];
-        BwdLayer<S, l>::run(R, lds, wl, i16, g, nd, dz, dzp);
-        if constexpr (l > 0) BwdChain<S, l - 1>::run(R, lds, wl, i16, g, nd, dzp);
-    }
-};
-
-template <class S, int l>
-struct FwdChain {
-    using C = FastCfg<S>;
-    static __device__ __forceinline__ void run(FastRegs<S>& R, const float* __restrict__ lds, float* wl, int i16, int g,
-                                                const NetDev& nd, const float (&x0)[C::cdiv(C::in(0), 4)]) {
-        FwdLayer<S, l>::run(R, lds, wl, i16, g, nd, x0);
-        if constexpr (l + 1 < C::NL) FwdChain<S, l + 1>::run(R, lds, wl, i16, g, nd, x0);
-    }
-};
-
-// stage theta into the padded LDS images
-template <class S, int l>
-struct StageW {
-    using C = FastCfg<S>;
-    static __device__ __forceinline__ void run(float* lds, const float* __restrict__ q, int tid) {
-        constexpr int in = C::in(l), out = C::out(l);
-        for (int e = tid; e < in * out; e += FAST_THREADS) {
-            const int i = e / in, k = e - i * in;
-            lds[C::woff(l) + i * C::LDW(l) + k] = q[C::offW(l) + e];
-        }
-        for (int e = tid; e < out; e += FAST_THREADS) lds[C::boff(l) + e] = q[C::offW(l) + in * out + e];
-        if constexpr (l + 1 < C::NL) StageW<S, l + 1>::run(lds, q, tid);
-    }
-};
-
-// write one wave's dW tiles into the LDS gradient buffer (first = store, else add)
-template <class S, int l>
-struct FlushDW {
-    using C = FastCfg<S>;
-    static __device__ __forceinline__ void run(const FastRegs<S>& R, float* gbuf, int i16, int g, bool first) {
+    static __device__ __forceinline__ void run(const float* buf, float* __restrict__ slab, int r, int lane, int t0, int cnt) {
         constexpr int in = C::in(l), out = C::out(l), MT = C::MT(l), NT = C::NT(l);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int col = 16 * nt + i16;                 // in-unit (== in -> bias)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * mt + 4 * g + r;       // out-unit
+                const int t = C::dwoff(l) + mt * NT + nt - t0;
+                if (t >= 0 && t < cnt) {
+                    const int row = 16 * mt + 4 * (lane >> 4) + r, col = 16 * nt + (lane & 15);
                     if (row < out && col <= in) {
-                        const int idx = C::offW(l) + (col < in ? row * in + col : in * out + row);
-                        const float v = R.dW[C::dwoff(l) + mt * NT + nt][r];
-                        gbuf[idx] = first ? v : gbuf[idx] + v;
+                        const float* src = buf + (t * 4 + r) * 64 + lane;
+                        const float v = (src[0] + src[C::EP_TILES * 256]) + (src[2 * C::EP_TILES * 256] + src[3 * C::EP_TILES * 256]);
+                        slab[C::offW(l) + (col < in ? row * in + col : in * out + row)] = v;   // col == in: bias (ones column)
                     }
                 }
             }
-        if constexpr (l + 1 < C::NL) FlushDW<S, l + 1>::run(R, gbuf, i16, g, first);
+        if constexpr (l + 1 < C::NL) SlabOut<S, l + 1>::run(buf, slab, r, lane, t0, cnt);
+    }
+};
+
+// host: flat parameter index -> offsets in the padded weight image: map[j] (W / bias images) and
+// map[P+j] (transposed image, -1 if none)
+template <class S, int l>
+struct ImageMap {
+    using C = FastCfg<S>;
+    static void run(int* map) {
+        constexpr int in = C::in(l), out = C::out(l);
+        for (int i = 0; i < out; ++i) {
+            for (int k = 0; k < in; ++k) {
+                map[C::offW(l) + i * in + k] = C::woff(l) + i * C::LDW(l) + k;
+                map[C::P() + C::offW(l) + i * in + k] = l >= 1 ? C::toff(l) + k * C::LDT(l) + i : -1;   // W_l^T
+            }
+            map[C::offW(l) + in * out + i] = C::boff(l) + i;
+            map[C::P() + C::offW(l) + in * out + i] = -1;
+        }
+        if constexpr (l + 1 < C::NL) ImageMap<S, l + 1>::run(map);
     }
 };
 
 template <class S>
-__global__ __launch_bounds__(FAST_THREADS, 1) void k_fwd_bwd_fast(
-    NetDev nd, const float* __restrict__ q, const float* __restrict__ eta,
+__global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_fwd_bwd_fast(
+    NetDev nd, const float* __restrict__ qimg, const float* __restrict__ eta,
     const float* __restrict__ X, const float* __restrict__ Y, long n,
-    float* __restrict__ slabs, double* __restrict__ pstat)
+    float* __restrict__ slabs, int pitch, double* __restrict__ pstat, unsigned long long* __restrict__ stamps)
 {
     using C = FastCfg<S>;
+#define TB_STAMP(i) do { if (stamps && threadIdx.x == 0 && blockIdx.x == 0) { stamps[i] = wall_clock64(); stamps[8 + i] = clock64(); } } while (0)
+    TB_STAMP(0);
+    static_assert(C::WB_FLOATS % 4 == 0 && C::STATIC_FLOATS % 4 == 0 && C::SLOT_FLOATS % 4 == 0, "images must be float4-addressable");
+    static_assert(C::LDS_FLOATS * 4 + 64 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     __shared__ double red[FAST_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
 
-    for (int e = tid; e < C::LDS_FLOATS; e += FAST_THREADS) lds[e] = 0.f;
-    __syncthreads();
-    StageW<S, 0>::run(lds, q, tid);
-    float* wl = lds + C::WB_FLOATS + wave * C::WAVE_FLOATS;      // this wave's images
-    // ones column of the layer-0 input image (never overwritten)
-    if (g == 0) wl[C::aoff(0) + i16 * C::PA(0) + C::in(0)] = 1.f;
-    // ones column of later images when in(l) is a multiple of 16 (own tile column, never overwritten)
+    // ---- prologue: the padded weight image (built by k_update / k_make_image) -> LDS;
+    // every 16-B load is issued before the first store (one latency, not eleven)
+    {
+        constexpr int N4 = C::STATIC_FLOATS / 4, IT = (N4 + FAST_THREADS - 1) / FAST_THREADS;
+        const float4* src = reinterpret_cast<const float4*>(qimg);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        float4 v[IT];
 #pragma unroll
-    for (int l = 1; l < C::NL; ++l)
-        if (C::in(l) % 16 == 0 && g == 0) wl[C::aoff(l) + i16 * C::PA(l) + C::in(l)] = 1.f;
+        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; v[k] = e < N4 ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
+    }
+    float* wl = lds + C::STATIC_FLOATS + wave * C::WAVE_FLOATS;  // this wave's transposed activation/delta images
+    {
+        float4* z = reinterpret_cast<float4*>(wl);
+        for (int e = lane; e < C::WAVE_FLOATS / 4; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();
+    TB_STAMP(1);
 
-    FastRegs<S> R;
+    f32x4 dW[C::DW_TILES];
 #pragma unroll
-    for (int t = 0; t < C::DW_TILES; ++t) R.dW[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < C::DW_TILES; ++t) dW[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float sigma = lik_sigma(nd, eta);
     const float inv_var = 1.f / (sigma * sigma);
     double stat = 0.0;
     constexpr int d_in = C::in(0), d_out = C::out(C::NL - 1);
-    constexpr int KS0 = C::cdiv(d_in, 4);
     const long ntiles = (n + 15) / 16;
+    const long W = (long)gridDim.x * FAST_WAVES;                  // waves in the grid
+    const long wg = (long)blockIdx.x * FAST_WAVES + wave;
 
-    for (long tile = (long)blockIdx.x * FAST_WAVES + wave; tile < ntiles; tile += (long)gridDim.x * FAST_WAVES) {
+    // tile t of this wave = wg + t*W.  Pairs while two remain, then a single.
+    float xn[2][C::KS0], yn[2][C::MTL][4];
+    auto fetch = [&](int slot, long tile) {
         const long row = tile * 16 + i16;
-        const bool rvalid = row < n;
-        // layer-0 B operand (natural k mapping: unit 4t+g) + transposed image of x
-        float x0[KS0];
+        const bool ok = tile < ntiles && row < n;
 #pragma unroll
-        for (int t = 0; t < KS0; ++t) {
+        for (int t = 0; t < C::KS0; ++t) {
             const int u = 4 * t + g;
-            x0[t] = (rvalid && u < d_in) ? X[row * d_in + u] : 0.f;
-            if (u < d_in) wl[C::aoff(0) + i16 * C::PA(0) + u] = x0[t];
+            xn[slot][t] = (ok && u < d_in) ? X[row * d_in + u] : 0.f;
         }
-        FwdChain<S, 0>::run(R, lds, wl, i16, g, nd, x0);
-
-        // likelihood: f = a_L in D layout (unit 16mt+4g+r, row = lane&15)
-        constexpr int MTL = C::MT(C::NL - 1);
-        f32x4 dz[MTL];
-        const int actL = nd.act[C::NL - 1];
 #pragma unroll
-        for (int mt = 0; mt < MTL; ++mt) {
+        for (int mt = 0; mt < C::MTL; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int u = 16 * mt + 4 * g + r;
-                float d = 0.f;
-                if (rvalid && u < d_out) {
-                    const float fi = R.a[C::aroff(C::NL - 1) + mt][r];
-                    const float y = Y[row * d_out + u];
-                    float da;
-                    if (nd.lik == TBNN_LIK_BERNOULLI) {
-                        const float p = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);
-                        const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
-                        const float t1 = (y == 0.f) ? 0.f : y * logf(p);
-                        const float t2 = (1.f - y == 0.f) ? 0.f : (1.f - y) * log1pf(-p);
-                        stat += (double)(t1 + t2);
-                        da = inside ? (y / p - (1.f - y) / (1.f - p)) : 0.f;
-                    } else {
-                        const float res = y - fi;
-                        stat += (double)res * (double)res;
-                        da = res * inv_var;
-                    }
-                    d = da * act_bwd(fi, actL);
-                }
-                dz[mt][r] = d;
+                yn[slot][mt][r] = (ok && u < d_out) ? Y[row * d_out + u] : 0.f;
             }
+    };
+    long tile = wg;
+    fetch(0, tile);
+    fetch(1, tile + W);
+    bool first = true;
+    const bool pair_mode = (nd.reserved_flags & 1) == 0;
+    while (pair_mode && tile + W < ntiles) {                      // two tiles at a time
+        float x[2][C::KS0], y[2][C::MTL][4];
+        bool rv[2];
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            rv[sl] = (tile + sl * W) * 16 + i16 < n;
+#pragma unroll
+            for (int t = 0; t < C::KS0; ++t) x[sl][t] = xn[sl][t];
+#pragma unroll
+            for (int mt = 0; mt < C::MTL; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[sl][mt][r] = yn[sl][mt][r];
         }
-        BwdChain<S, C::NL - 1>::run(R, lds, wl, i16, g, nd, dz);
+        tile += 2 * W;
+        fetch(0, tile);
+        fetch(1, tile + W);
+        TileStep<S, 2>::run(dW, stat, lds, wl, i16, g, inv_var, x, y, rv);
+        if (first) { TB_STAMP(2); first = false; }
     }
+    for (; tile < ntiles; tile += W) {                            // remainder: one tile at a time
+        float x[1][C::KS0], y[1][C::MTL][4];
+        bool rv[1];
+        rv[0] = tile * 16 + i16 < n;
+#pragma unroll
+        for (int t = 0; t < C::KS0; ++t) x[0][t] = xn[0][t];
+#pragma unroll
+        for (int mt = 0; mt < C::MTL; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[0][mt][r] = yn[0][mt][r];
+        fetch(0, tile + W);
+        TileStep<S, 1>::run(dW, stat, lds, wl, i16, g, inv_var, x, y, rv);
+        if (first) { TB_STAMP(2); first = false; }
+    }
+    TB_STAMP(3);
 
-    // ---- combine the 4 waves' dW in LDS (fixed order), write the slab
+    // ---- epilogue: every wave stages its dW tiles [wave][tile][reg][lane] (conflict-free b32),
+    // all 256 threads sum the 4 copies in fixed order and write the dense slab; EP_TILES per pass
     const double wtot = wave_sum(stat);
-    __syncthreads();                       // all images dead from here on
     if (lane == 0) red[wave] = wtot;
-    float* gbuf = lds + C::WB_FLOATS;
-    for (int w = 0; w < FAST_WAVES; ++w) {
-        if (wave == w) FlushDW<S, 0>::run(R, gbuf, i16, g, w == 0);
+    float* slab = slabs + (size_t)blockIdx.x * pitch;
+#pragma unroll
+    for (int t0 = 0; t0 < C::DW_TILES; t0 += C::EP_TILES) {
+        __syncthreads();                   // images (or the previous pass) are dead
+        float* mine = lds + wave * (C::EP_TILES * 256);
+#pragma unroll
+        for (int t = t0; t < t0 + C::EP_TILES && t < C::DW_TILES; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[((t - t0) * 4 + r) * 64 + lane] = dW[t][r];
         __syncthreads();
+        const int cnt = (C::DW_TILES - t0) < C::EP_TILES ? (C::DW_TILES - t0) : C::EP_TILES;
+        SlabOut<S, 0>::run(lds, slab, wave, lane, t0, cnt);
     }
-    float* slab = slabs + (size_t)blockIdx.x * C::P();
-    for (int e = tid; e < C::P(); e += FAST_THREADS) slab[e] = gbuf[e];
     if (tid == 0) {
         double t = 0.0;
         for (int w = 0; w < FAST_WAVES; ++w) t += red[w];
         pstat[blockIdx.x] = t;
     }
+    TB_STAMP(4);
+#undef TB_STAMP
 }
 
 // ---------------------------------------------------------------------------
 // registry of ahead-of-time instantiations (shapes of BASELINE.json's configs)
 // ---------------------------------------------------------------------------
-using ShapeC2 = Shape<5, 50, 50, 50, 1>;      // configs[1], configs[2]
-using ShapeC1 = Shape<1, 10, 10, 1>;          // configs[0]
-using ShapeTR = Shape<1, 10, 10, 10, 1>;      // Examples/trainRegression.py
+using ShapeC2 = Shape<TBNN_ACT_RELU, TBNN_ACT_NONE, false, 5, 50, 50, 50, 1>;      // configs[1], configs[2]
+using ShapeC1 = Shape<TBNN_ACT_RELU, TBNN_ACT_NONE, false, 1, 10, 10, 1>;          // configs[0]
+using ShapeTR = Shape<TBNN_ACT_TANH, TBNN_ACT_NONE, false, 1, 10, 10, 10, 1>;      // Examples/trainRegression.py
 
 template <class S>
 static bool shape_matches(const NetDev& nd) {
     if (nd.nl != S::NL) return false;
+    if ((nd.lik == TBNN_LIK_BERNOULLI) != S::BERN) return false;
     for (int l = 0; l < S::NL; ++l)
-        if (nd.in[l] != S::D[l] || nd.out[l] != S::D[l + 1]) return false;
+        if (nd.in[l] != S::D[l] || nd.out[l] != S::D[l + 1] || nd.act[l] != S::act(l)) return false;
     return true;
 }
 
@@ -379,9 +551,9 @@ static inline int fast_lookup(const NetDev& nd) {
 }
 static inline const char* fast_name(int id) {
     switch (id) {
-        case 0: return "fast<5,50,50,50,1>";
-        case 1: return "fast<1,10,10,1>";
-        case 2: return "fast<1,10,10,10,1>";
+        case 0: return "fast<relu;5,50,50,50,1>";
+        case 1: return "fast<relu;1,10,10,1>";
+        case 2: return "fast<tanh;1,10,10,10,1>";
         default: return "fast<none>";
     }
 }
@@ -391,13 +563,32 @@ static inline int fast_grid(int, long n) {
     const long wgs = (ntiles + FAST_WAVES - 1) / FAST_WAVES;
     return (int)(wgs < 256 ? wgs : 256);
 }
-static inline int fast_launch(int id, int grid, hipStream_t st, const NetDev& nd, const float* q, const float* eta,
-                              const float* X, const float* Y, long n, float* slabs, double* pstat) {
+// qimg: the padded weight image of the position to evaluate
+static inline int fast_launch(int id, int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
+                              const float* X, const float* Y, long n, float* slabs, int pitch, double* pstat,
+                              unsigned long long* stamps = nullptr) {
     switch (id) {
-        case 0: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC2>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, q, eta, X, Y, n, slabs, pstat); break;
-        case 1: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC1>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, q, eta, X, Y, n, slabs, pstat); break;
-        case 2: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeTR>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, q, eta, X, Y, n, slabs, pstat); break;
+        case 0: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC2>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        case 1: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC1>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        case 2: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeTR>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
         default: return -1;
     }
     return 0;
+}
+// floats in the padded weight image and the parameter -> image-offset map
+static inline int fast_image_floats(int id) {
+    switch (id) {
+        case 0: return FastCfg<ShapeC2>::STATIC_FLOATS;
+        case 1: return FastCfg<ShapeC1>::STATIC_FLOATS;
+        case 2: return FastCfg<ShapeTR>::STATIC_FLOATS;
+        default: return 0;
+    }
+}
+static inline void fast_image_map(int id, int* map) {
+    switch (id) {
+        case 0: ImageMap<ShapeC2, 0>::run(map); break;
+        case 1: ImageMap<ShapeC1, 0>::run(map); break;
+        case 2: ImageMap<ShapeTR, 0>::run(map); break;
+        default: break;
+    }
 }

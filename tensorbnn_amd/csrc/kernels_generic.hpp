@@ -29,7 +29,7 @@ __global__ __launch_bounds__(GEN_RB) void k_fwd_bwd_generic(
     NetDev nd, const float* __restrict__ q, const float* __restrict__ eta,
     const float* __restrict__ X, const float* __restrict__ Y, long n,
     float* __restrict__ scratch, size_t scratchPerWG,
-    float* __restrict__ partial_grad, double* __restrict__ partial_stat)
+    float* __restrict__ partial_grad, int pitch, double* __restrict__ partial_stat)
 {
     __shared__ double red[GEN_RB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(GEN_RB) void k_fwd_bwd_generic(
     float* DZ = ACT + (size_t)nd.sumOut * GEN_RB;                // dL/dz_l        [maxW][RB]
     float* DA0 = DZ + (size_t)nd.maxW * GEN_RB;                  // dL/da ping
     float* DA1 = DA0 + (size_t)nd.maxW * GEN_RB;                 // dL/da pong
-    float* slab = partial_grad + (size_t)blockIdx.x * nd.P;
+    float* slab = partial_grad + (size_t)blockIdx.x * pitch;
 
     // zero this workgroup's gradient slab (same ownership pattern as the adds)
     for (int l = 0; l < nd.nl; ++l) {

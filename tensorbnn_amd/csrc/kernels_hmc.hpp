@@ -36,48 +36,97 @@ __device__ __forceinline__ float prior_grad(int prior, float loc, float scale, f
 }
 
 // Reduce the per-workgroup gradient slabs, add the prior gradient, then kick /
-// drift.  block = (64, 4): x = parameter, y = slab quarter.
-__global__ __launch_bounds__(256) void k_update(
+// drift.  One thread column = 4 consecutive parameters (float4 slab reads; the
+// slab pitch is a multiple of 4), 16 slab groups per block, every thread keeps
+// 4 independent 16-B loads in flight; fixed-order LDS tree => deterministic.
+// When imgmap != null the new position is also scattered into the padded
+// weight image (W_l and, for l >= 1, W_l^T: imgmap[j] / imgmap[P+j]) the
+// shape-specialised kernel stages into LDS.
+#define UPD_COLS 16    // float4 columns per block (64 parameters)
+#define UPD_GROUPS 16  // slab groups per block
+__global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     NetDev nd, int mode, float eps, const float* __restrict__ eta,
-    const float* __restrict__ slabs, int nslab,
+    const float* __restrict__ slabs, int nslab, int pitch,
     const float* __restrict__ q_cur, const float* __restrict__ g_cur,
-    float* __restrict__ q, float* __restrict__ p, float* __restrict__ g)
+    float* __restrict__ q, float* __restrict__ p, float* __restrict__ g,
+    const int* __restrict__ imgmap, float* __restrict__ qimg)
 {
-    __shared__ float part[4][64];
+    __shared__ float4 part[UPD_GROUPS][UPD_COLS];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int j = blockIdx.x * 64 + tx;
-    float gj = 0.f;
+    const int c4 = blockIdx.x * UPD_COLS + tx;          // float4 column
+    const int j0 = c4 * 4;
+    float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mode != UPD_FIRST) {
-        float s = 0.f;
-        if (j < nd.P)
-            for (int w = ty; w < nslab; w += 4) s += slabs[(size_t)w * nd.P + j];
+        float4 s0 = gs, s1 = gs, s2 = gs, s3 = gs;
+        if (j0 < pitch) {
+            const float4* base = reinterpret_cast<const float4*>(slabs) + c4;
+            const int p4 = pitch >> 2;
+            int w = ty;
+            for (; w + 3 * UPD_GROUPS < nslab; w += 4 * UPD_GROUPS) {
+                const float4 a = base[(size_t)w * p4];
+                const float4 b = base[(size_t)(w + UPD_GROUPS) * p4];
+                const float4 c = base[(size_t)(w + 2 * UPD_GROUPS) * p4];
+                const float4 d = base[(size_t)(w + 3 * UPD_GROUPS) * p4];
+                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+                s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+                s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+                s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+            }
+            for (; w < nslab; w += UPD_GROUPS) {
+                const float4 a = base[(size_t)w * p4];
+                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            }
+        }
+        float4 s;
+        s.x = (s0.x + s1.x) + (s2.x + s3.x); s.y = (s0.y + s1.y) + (s2.y + s3.y);
+        s.z = (s0.z + s1.z) + (s2.z + s3.z); s.w = (s0.w + s1.w) + (s2.w + s3.w);
         part[ty][tx] = s;
         __syncthreads();
-        if (ty == 0 && j < nd.P) {
-            // fixed order ((0+1)+(2+3)): deterministic
-            gj = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
-            int prior; float loc, scale;
-            prior_params(nd, eta, j, prior, loc, scale);
-            gj += prior_grad(prior, loc, scale, q[j]);
+#pragma unroll
+        for (int h = UPD_GROUPS / 2; h > 0; h >>= 1) {
+            if (ty < h) {
+                const float4 a = part[ty][tx], b = part[ty + h][tx];
+                part[ty][tx] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            }
+            __syncthreads();
         }
+        gs = part[0][tx];
     }
-    if (ty != 0 || j >= nd.P) return;
+    // ty selects which of the 4 parameters of the column this thread finishes
+    if (ty >= 4) return;
+    const int j = j0 + ty;
+    if (j >= nd.P) return;
+    float gj = ty == 0 ? gs.x : ty == 1 ? gs.y : ty == 2 ? gs.z : gs.w;
+    if (mode != UPD_FIRST) {
+        int prior; float loc, scale;
+        prior_params(nd, eta, j, prior, loc, scale);
+        gj += prior_grad(prior, loc, scale, q[j]);
+    }
     if (mode == UPD_GRAD_ONLY) { g[j] = gj; return; }
     if (mode == UPD_FIRST) {
         const float pj = p[j] + 0.5f * eps * g_cur[j];       // half kick
-        p[j] = pj;
-        q[j] = q_cur[j] + eps * pj;                           // drift
+        const float qj = q_cur[j] + eps * pj;                 // drift
+        p[j] = pj; q[j] = qj;
+        if (imgmap) { qimg[imgmap[j]] = qj; const int m1 = imgmap[nd.P + j]; if (m1 >= 0) qimg[m1] = qj; }
         return;
     }
     float pj = p[j] + eps * gj;                               // full kick
     g[j] = gj;
     if (mode == UPD_MID) {
-        p[j] = pj;
-        q[j] = q[j] + eps * pj;                               // drift
+        const float qj = q[j] + eps * pj;                     // drift
+        p[j] = pj; q[j] = qj;
+        if (imgmap) { qimg[imgmap[j]] = qj; const int m1 = imgmap[nd.P + j]; if (m1 >= 0) qimg[m1] = qj; }
     } else {
         pj = pj - 0.5f * eps * gj;                            // undo half kick
         p[j] = pj;
     }
+}
+
+// scatter a flat theta into the padded weight image (bootstrap / tbnn_logp_grad)
+__global__ __launch_bounds__(256) void k_make_image(int P, const float* __restrict__ q,
+                                                    const int* __restrict__ imgmap, float* __restrict__ qimg) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < P) { const float v = q[j]; qimg[imgmap[j]] = v; const int m1 = imgmap[P + j]; if (m1 >= 0) qimg[m1] = v; }
 }
 
 // data-term log-likelihood from the reduced statistic

@@ -42,13 +42,15 @@ struct tbnn_ctx {
     float *q_cur = nullptr, *g_cur = nullptr, *q = nullptr, *p = nullptr, *g = nullptr, *eta = nullptr;
     float *p0_inj = nullptr, *logu_inj = nullptr, *tmp = nullptr;
     bool cur_valid = false;               // (logp, grad, stat) cached at q_cur for the current eta/data
+    bool q_img_valid = false;             // h->qimg mirrors h->q (maintained by k_update)
     // fused-pass workspace
-    int grid = 0; float* slabs = nullptr; double* pstat = nullptr; float* scratch = nullptr;
+    int grid = 0, pitch = 0; float* slabs = nullptr; double* pstat = nullptr; float* scratch = nullptr;
+    int* imgmap = nullptr; float* qimg = nullptr; float* qimg_cur = nullptr; int img_floats = 0;   // fast kernel: padded weight images
     size_t scratchPerWG = 0;
     Scal* sc = nullptr; Scal* sc_host = nullptr; Scal* sc_out = nullptr;   // sc_out: device copy for host
     double* trace = nullptr; int trace_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool profile = false; std::vector<hipEvent_t> pev;
+    int profile = 0; long launch_no = 0; std::vector<hipEvent_t> pev;   // profile: event pair around every profile-th fwd+bwd launch
     // hyper workspace
     float* hyp_ws = nullptr;
 };
@@ -112,6 +114,9 @@ extern "C" int tbnn_destroy(tbnn_handle h) {
                      h->slabs, h->scratch, h->hyp_ws};
     for (float* b : bufs) if (b) hipFree(b);
     if (h->pstat) hipFree(h->pstat);
+    if (h->imgmap) hipFree(h->imgmap);
+    if (h->qimg) hipFree(h->qimg);
+    if (h->qimg_cur) hipFree(h->qimg_cur);
     if (h->sc) hipFree(h->sc);
     if (h->sc_out) hipFree(h->sc_out);
     if (h->trace) hipFree(h->trace);
@@ -171,9 +176,19 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
     if (want == TBNN_KERNEL_FAST && fid < 0) return bail(-1, "TBNN_KERNEL_FAST requested but no specialised kernel covers this shape");
     if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && fid >= 0) {
         h->kernel = TBNN_KERNEL_FAST; h->fast_id = fid; h->kernel_name = fast_name(fid);
+        h->img_floats = fast_image_floats(fid);
+        std::vector<int> map(2 * (size_t)nd.P);
+        fast_image_map(fid, map.data());
+        HIPB(hipMalloc(&h->imgmap, map.size() * sizeof(int)));
+        HIPB(hipMemcpy(h->imgmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPB(hipMalloc(&h->qimg, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg_cur, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg, 0, (size_t)h->img_floats * sizeof(float)));       // padding stays zero for ever
+        HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
     }
+    { const char* e1 = getenv("TBNN_FAST_SINGLE"); if (e1 && atoi(e1)) h->nd.reserved_flags |= 1; }
     const char* env = getenv("TBNN_PROFILE_FWDBWD");
-    h->profile = env && atoi(env) != 0;
+    h->profile = env ? atoi(env) : 0;
 #undef HIPB
     *out = h;
     return 0;
@@ -182,7 +197,7 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
 extern "C" int tbnn_param_count(tbnn_handle h) { NEED(h); return h->nd.P; }
 extern "C" int tbnn_hyper_count(tbnn_handle h) { NEED(h); return h->nd.H; }
 extern "C" const char* tbnn_kernel_name(tbnn_handle h) { return h ? h->kernel_name.c_str() : ""; }
-extern "C" int tbnn_set_profiling(tbnn_handle h, int on) { NEED(h); h->profile = on != 0; return 0; }
+extern "C" int tbnn_set_profiling(tbnn_handle h, int stride) { NEED(h); h->profile = stride > 0 ? stride : 0; return 0; }
 extern "C" int tbnn_set_epoch(tbnn_handle h, uint32_t epoch) { NEED(h); h->epoch = epoch; return 0; }
 
 // (re)allocate the fused-pass workspace for n rows
@@ -203,7 +218,8 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
     }
     // tbnn_forward always uses the generic forward kernel: keep a scratch for it
     h->grid = grid;
-    HIPCHK(hipMalloc(&h->slabs, (size_t)grid * nd.P * sizeof(float)));
+    h->pitch = (nd.P + 3) & ~3;                  // float4-readable slabs
+    HIPCHK(hipMalloc(&h->slabs, (size_t)grid * h->pitch * sizeof(float)));
     HIPCHK(hipMalloc(&h->pstat, (size_t)grid * sizeof(double)));
     return 0;
 }
@@ -267,27 +283,40 @@ extern "C" int tbnn_get_hypers(tbnn_handle h, float* eta) {
 }
 
 // ---- launch helpers (all on h->stream, no sync) ----
+// q == h->q: the leapfrog position, whose padded image h->qimg is maintained by k_update;
+// any other q gets its image built here (h->qimg_cur).
 static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
+    const float* img = nullptr;
+    if (h->kernel == TBNN_KERNEL_FAST) {
+        if (q == h->q && h->q_img_valid) img = h->qimg;
+        else {
+            hipLaunchKernelGGL(k_make_image, dim3((h->nd.P + 255) / 256), dim3(256), 0, h->stream, h->nd.P, q, h->imgmap, h->qimg_cur);
+            img = h->qimg_cur;
+        }
+    }
     hipEvent_t a = nullptr, b = nullptr;
-    if (h->profile) {
+    const bool prof = h->profile > 0 && (h->launch_no++ % h->profile) == 0;
+    if (prof) {
         hipEventCreate(&a); hipEventCreate(&b); h->pev.push_back(a); h->pev.push_back(b);
         hipEventRecord(a, h->stream);
     }
     if (h->kernel == TBNN_KERNEL_FAST) {
-        int rc = fast_launch(h->fast_id, h->grid, h->stream, h->nd, q, eta, h->dX, h->dY, h->n, h->slabs, h->pstat);
+        int rc = fast_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat);
         if (rc) return fail(-2, "fast kernel launch failed");
     } else {
         hipLaunchKernelGGL(k_fwd_bwd_generic, dim3(h->grid), dim3(GEN_RB), 0, h->stream, h->nd, q, eta, h->dX,
-                           h->dY, h->n, h->scratch, h->scratchPerWG, h->slabs, h->pstat);
+                           h->dY, h->n, h->scratch, h->scratchPerWG, h->slabs, h->pitch, h->pstat);
     }
-    if (h->profile) hipEventRecord(b, h->stream);
+    if (prof) hipEventRecord(b, h->stream);
     HIPCHK(hipGetLastError());
     return 0;
 }
 static void launch_update(tbnn_ctx* h, int mode, float eps, const float* eta, float* q, float* g) {
-    const int gx = (h->nd.P + 63) / 64;
-    hipLaunchKernelGGL(k_update, dim3(gx), dim3(64, 4), 0, h->stream, h->nd, mode, eps, eta, h->slabs, h->grid,
-                       h->q_cur, h->g_cur, q, h->p, g);
+    const int gx = (h->pitch / 4 + UPD_COLS - 1) / UPD_COLS;
+    const bool img = h->kernel == TBNN_KERNEL_FAST && q == h->q;
+    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, h->nd, mode, eps, eta, h->slabs, h->grid,
+                       h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg);
+    if (img && (mode == UPD_FIRST || mode == UPD_MID)) h->q_img_valid = true;
 }
 static void launch_energy(tbnn_ctx* h, int which, const float* eta, const float* q, double* slot) {
     hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, h->nd, which, eta, q, h->p, h->q_cur, h->pstat,
@@ -303,15 +332,16 @@ static int ensure_current(tbnn_ctx* h, double* slot) {
     h->cur_valid = true;
     return 0;
 }
+// mean duration (us) of the profiled fwd+bwd launches since the last drain
 static float drain_profile(tbnn_ctx* h) {
-    float tot = 0.f;
+    double tot = 0.0; int cnt = 0;
     for (size_t i = 0; i + 1 < h->pev.size(); i += 2) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->pev[i], h->pev[i + 1]) == hipSuccess) tot += ms * 1000.f;
+        if (hipEventElapsedTime(&ms, h->pev[i], h->pev[i + 1]) == hipSuccess) { tot += ms * 1000.0; ++cnt; }
     }
     for (auto e : h->pev) hipEventDestroy(e);
     h->pev.clear();
-    return tot;
+    return cnt ? (float)(tot / cnt) : 0.f;
 }
 
 extern "C" int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* eta, double* logp, float* grad,
@@ -323,13 +353,13 @@ extern "C" int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* et
     // evaluation happens on scratch copies (q, tmp-eta): the chain state is untouched
     const float* dq = h->q_cur;
     const float* de = h->eta;
-    if (theta) { HIPCHK(hipMemcpyAsync(h->q, theta, (size_t)nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream)); dq = h->q; }
+    if (theta) { HIPCHK(hipMemcpyAsync(h->q, theta, (size_t)nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream)); dq = h->q; h->q_img_valid = false; }
     if (eta) { HIPCHK(hipMemcpyAsync(h->tmp + nd.P, eta, (size_t)nd.H * sizeof(float), hipMemcpyHostToDevice, h->stream)); de = h->tmp + nd.P; }
     int rc = launch_fwd_bwd(h, dq, de);
     if (rc) return rc;
-    const int gx = (nd.P + 63) / 64;
-    hipLaunchKernelGGL(k_update, dim3(gx), dim3(64, 4), 0, h->stream, nd, (int)UPD_GRAD_ONLY, 0.f, de, h->slabs, h->grid,
-                       h->q_cur, h->g_cur, const_cast<float*>(dq), h->p, h->tmp);
+    const int gx = (h->pitch / 4 + UPD_COLS - 1) / UPD_COLS;
+    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, nd, (int)UPD_GRAD_ONLY, 0.f, de, h->slabs, h->grid,
+                       h->pitch, h->q_cur, h->g_cur, const_cast<float*>(dq), h->p, h->tmp, (const int*)nullptr, (float*)nullptr);
     // EN_TRACE leaves the chain's scalar record alone; stat comes from the slabs
     if (!h->trace || h->trace_cap < 2) {
         if (h->trace) hipFree(h->trace);
@@ -356,7 +386,7 @@ extern "C" int tbnn_forward(tbnn_handle h, const float* theta, const float* X, i
     HIPCHK(hipSetDevice(h->device));
     const NetDev& nd = h->nd;
     const float* dq = h->q_cur;
-    if (theta) { HIPCHK(hipMemcpyAsync(h->q, theta, (size_t)nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream)); dq = h->q; }
+    if (theta) { HIPCHK(hipMemcpyAsync(h->q, theta, (size_t)nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream)); dq = h->q; h->q_img_valid = false; }
     float *dXf = nullptr, *dOut = nullptr, *scr = nullptr;
     const long nblk = (n + GEN_RB - 1) / GEN_RB;
     const int grid = (int)std::min<long>(nblk, 512);
@@ -462,7 +492,7 @@ extern "C" int tbnn_hmc_run(tbnn_handle h, float eps, int32_t L, int32_t n_epoch
     float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1);
     const float fb = h->profile ? drain_profile(h) : 0.f;
     if (outs)
-        for (int e = 0; e < n_epochs; ++e) fill_out(recs[e], L, ms * 1000.f / n_epochs, fb / n_epochs, outs + e);
+        for (int e = 0; e < n_epochs; ++e) fill_out(recs[e], L, ms * 1000.f / n_epochs, fb, outs + e);
     hipFree(d_recs);
     return 0;
 }
@@ -543,3 +573,31 @@ extern "C" int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, 
     if (out_log_u) *out_log_u = host[n];
     return 0;
 }
+
+// diagnostic: 100 MHz wall-clock stamps of workgroup 0 inside one fused launch
+// [0] start, [1] prologue done, [2] first tile done, [3] tile loop done, [4] end
+extern "C" int tbnn_debug_stamps(tbnn_handle h, uint64_t* out5) {
+    NEED(h);
+    if (h->kernel != TBNN_KERNEL_FAST || !h->dX) return fail(-1, "debug_stamps: fast kernel + data required");
+    HIPCHK(hipSetDevice(h->device));
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc(&d, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(d, 0, 16 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_make_image, dim3((h->nd.P + 255) / 256), dim3(256), 0, h->stream, h->nd.P, h->q_cur, h->imgmap, h->qimg_cur);
+    for (int rep = 0; rep < 3; ++rep)
+        fast_launch(h->fast_id, h->grid, h->stream, h->nd, h->qimg_cur, h->eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, d);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out5, d, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    hipFree(d);
+    return 0;
+}
+
+#ifdef TBNN_TILE_STAMPS
+extern "C" int tbnn_debug_tile_stamps(tbnn_handle h, uint64_t* out64) {
+    NEED(h);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_tile_stamps), 64 * sizeof(uint64_t)));
+    return 0;
+}
+#endif
