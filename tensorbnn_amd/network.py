@@ -1,0 +1,228 @@
+"""The driver object: same ``network(...)``, ``add``, ``setupMCMC``, ``train``,
+``predict`` API as the reference (tensorBNN/network.py:13-670).
+
+What changes is the engine underneath: every epoch is one call to
+``tbnn_hmc_step`` (the whole weight transition -- fused forward + likelihood +
+gradient, leapfrog, Metropolis -- runs on the MI355X) plus, when
+``adjustHypers`` is set, one ``tbnn_hyper_step``; the (eps, L) adapter is host
+C++ (``tbnn_adapter_update``).  There is no CPU fallback.
+"""
+import os
+import time
+
+import numpy as np
+
+from . import _native as nat
+from .paramAdapter import paramAdapter
+
+
+class network(object):
+    def __init__(self, dtype, inputDims, trainX, trainY, validateX, validateY, device=0, chain_id=0, seed=50,
+                 kernel=nat.KERNEL_AUTO):
+        """network.py:19-58.  ``dtype`` must be float32 (the only type the reference's
+        examples use and the type the kernels compute in).  Extra keyword arguments
+        (device, chain_id, seed, kernel) select the GPU / the chain's Philox stream."""
+        if np.dtype(dtype if not hasattr(dtype, "as_numpy_dtype") else dtype.as_numpy_dtype) != np.float32:
+            raise TypeError("tensorbnn_amd computes in float32 only")
+        self.dtype = np.float32
+        self.inputDims = inputDims
+        self.trainX = np.asarray(trainX, dtype=np.float32).reshape(len(trainX), inputDims)       # :41-44
+        self.trainY = np.asarray(trainY, dtype=np.float32)                                        # :45
+        self.validateX = np.asarray(validateX, dtype=np.float32).reshape(len(validateX), inputDims)
+        self.validateY = np.asarray(validateY, dtype=np.float32)
+        self.states = []          # :53  [W1, b1, W2, b2, ...] as [out,in] / [out,1] arrays
+        self.hyperStates = []     # :54  list of shape-[1] arrays
+        self.layers = []          # :56
+        self.device, self.chain_id, self.seed, self.kernel = device, chain_id, seed, kernel
+        self._chain = None
+        self._dense = []          # descriptors (in, out, act, prior)
+
+    # ------------------------------------------------------------------ model
+    def add(self, layer, parameters=None):
+        """network.py:173-191"""
+        if layer.numTensors > 0:
+            if getattr(layer, "prior_kind", None) is None:
+                raise NotImplementedError(f"layer {layer.name!r} is not a dense layer the HIP path knows")
+            self._dense.append([int(layer.inputDims), int(layer.outputDims), nat.ACT_NONE, int(layer.prior_kind)])
+            for st in (layer.parameters if parameters is None else parameters):
+                self.states.append(np.asarray(st, dtype=np.float32))
+        else:
+            if getattr(layer, "act_kind", None) is None:
+                raise NotImplementedError(f"activation {layer.name!r} is not supported by the HIP path")
+            if not self._dense or self._dense[-1][2] != nat.ACT_NONE or (self.layers and self.layers[-1].numTensors == 0):
+                raise NotImplementedError("an activation must directly follow a dense layer (it is fused as its epilogue)")
+            self._dense[-1][2] = int(layer.act_kind)
+        self.layers.append(layer)
+        if layer.numHyperTensors > 0:
+            for row in np.asarray(layer.hypers, dtype=np.float32):          # :189-191: one [1]-tensor per row
+                self.hyperStates.append(np.asarray(row, dtype=np.float32).reshape(1))
+        self._chain = None
+
+    def _theta(self):
+        return np.concatenate([np.asarray(s, dtype=np.float32).reshape(-1) for s in self.states])
+
+    def _set_states_from(self, theta):
+        o = 0
+        for i, s in enumerate(self.states):
+            self.states[i] = theta[o:o + s.size].reshape(s.shape).copy()
+            o += s.size
+
+    def _ensure_chain(self, likelihood=None):
+        lik = likelihood if likelihood is not None else getattr(self, "likelihood", None)
+        kind = lik.kind if lik is not None else nat.LIK_FIXED_GAUSSIAN
+        sd = float(getattr(lik, "fixed_sd", 0.1)) if lik is not None else 0.1
+        key = (tuple(map(tuple, self._dense)), kind, sd)
+        if self._chain is None or self._chain_key != key:
+            if self._chain is not None:
+                self._chain.close()
+            self._chain = nat.Chain(self._dense, likelihood=kind, fixed_sd=sd, device=self.device, seed=self.seed,
+                                    chain_id=self.chain_id, kernel=self.kernel)
+            self._chain_key = key
+            y = self.trainY.reshape(len(self.trainX), -1)
+            self._chain.set_data(self.trainX, y)
+        return self._chain
+
+    def predict(self, train, *argv):
+        """network.py:141-171: [d_out, n] prediction (native forward kernel)."""
+        tensors = self.states if len(argv) == 0 else argv[0]
+        theta = np.concatenate([np.asarray(s, dtype=np.float32).reshape(-1) for s in tensors])
+        x = self.trainX if train else self.validateX
+        return self._ensure_chain().forward(x, theta)
+
+    def metrics(self, trainPredict, trainReal, validatePredict, validateReal):
+        """network.py:60-82"""
+        for metric in self.metricList:
+            metric.calculate(trainPredict, validatePredict, trainReal, validateReal)
+            metric.display()
+
+    # ------------------------------------------------------------------ MCMC
+    def setupMCMC(self, stepSizeStart=1e-3, stepSizeMin=1e-4, stepSizeMax=1e-2, stepSizeOptions=40,
+                  leapfrogStart=1000, leapfogMin=100, leapFrogMax=10000, leapfrogIncrement=1, hyperStepSize=1e-2,
+                  hyperLeapfrog=100, burnin=1000, cores=4, averagingSteps=10, a=4, delta=0.1, strikes=5,
+                  randomSteps=10, dualAveraging=False, adapt=True):
+        """network.py:193-278 (argument names, including the misspelt ones, are the API).
+        ``adapt=False`` (new) bypasses the (eps, L) adapter: fixed stepSizeStart / leapfrogStart."""
+        self.adapt = paramAdapter(stepSizeStart, leapfrogStart, stepSizeMin, stepSizeMax, stepSizeOptions, leapfogMin,
+                                  leapFrogMax, leapfrogIncrement, averagingSteps, burnin / averagingSteps, a=a,
+                                  delta=delta, cores=cores, strikes=strikes, randomSteps=randomSteps,
+                                  seed=self.seed + 7919 * self.chain_id)
+        self.adapt_enabled = adapt
+        self.step_size = np.float32(stepSizeStart)
+        self.leapfrog = np.int32(leapfrogStart)
+        self.cores = cores
+        self.burnin = burnin
+        self.target = np.float32(0.95)                    # :241
+        self.gamma = np.float32(0.4)                      # :243
+        self.t0 = np.float32(10)
+        self.kappa = np.float32(0.75)
+        self.h = np.float32(0)
+        self.logEpsilonBar = np.float32(0)
+        self.mu = np.float32(np.log(np.float32(100 * hyperStepSize)))      # :248
+        self.dualAveraging = dualAveraging
+        self.hyper_step_size = np.float32(hyperStepSize)
+        self.hyperLeapfrog = hyperLeapfrog
+
+    def _dual_averaging(self, epoch, log_accept_ratio):
+        """network.py:457-469 (epoch = iter_ before the increment)."""
+        f = np.float32
+        m = f(epoch) + f(1)
+        accept = f(np.exp(f(log_accept_ratio))) if log_accept_ratio < 0 else f(1)
+        self.h = (f(1) - f(1) / (m + self.t0)) * self.h + (f(1) / (m + self.t0)) * (self.target - accept)
+        logEpsilon = self.mu - self.h * (m ** f(0.5)) / self.gamma
+        self.logEpsilonBar = (f(1) - m ** (-self.kappa)) * self.logEpsilonBar + m ** (-self.kappa) * logEpsilon
+        if m < f(self.burnin * 0.8):
+            self.hyper_step_size = f(np.exp(self.logEpsilonBar))
+        return accept
+
+    def train(self, epochs, samplingStep, likelihood, metricList=[], adjustHypers=True, scaleExp=False,
+              folderName=None, networksPerFile=1000, displaySkip=1, verbose=True, gather=None):
+        """network.py:509-670.  Returns a list of per-epoch records (new; the reference
+        only prints).  ``gather``: optional callable(theta_eta_device_ptr) used by
+        tensorbnn_amd.parallel for the RCCL sample gather at checkpoint time."""
+        startSampling = self.burnin
+        self.likelihood = likelihood
+        self.makeResponseLikelihood = likelihood.makeResponseLikelihood
+        self.metricList = metricList
+        self.adjustHypers = adjustHypers
+        for val in likelihood.hypers:                                        # :542-543
+            self.hyperStates.append(np.asarray(val, dtype=np.float32).reshape(1))
+        ch = self._ensure_chain(likelihood)
+        ch.set_state(self._theta())
+        ch.set_hypers(np.concatenate(self.hyperStates) if self.hyperStates else np.zeros(0, np.float32))
+
+        filePath, files = None, []
+        if folderName is not None:                                           # :546-559
+            filePath = os.path.join(os.getcwd(), folderName)
+            os.makedirs(filePath, exist_ok=True)
+            for n in range(len(self.states)):
+                files.append(open(filePath + "/" + str(n) + ".0" + ".txt", "wb"))
+            files.append(open(filePath + "/hypers" + "0" + ".txt", "wb"))
+            with open(filePath + "/architecture.txt", "wb") as f:
+                for layer in self.layers:
+                    f.write((layer.name + "\n").encode("utf-8"))
+
+        iter_ = 0
+        self.mainAccept = np.float32(0)
+        self.hyperAccept = np.float32(0)
+        records = []
+        startTime = time.time()
+        while iter_ < epochs:                                                # :567
+            out = ch.hmc_step(float(self.step_size), int(self.leapfrog))     # InnerStepMain :368-412
+            self.mainAccept = np.float32(out["accept_prob"])
+            rec = {"iter": iter_, "eps": float(self.step_size), "L": int(self.leapfrog), "main": out}
+            if self.adjustHypers and ch.H > 0:                               # InnerStepHyper :414-471
+                hout = ch.hyper_step(float(self.hyper_step_size), int(self.hyperLeapfrog))
+                self.hyperAccept = self._dual_averaging(iter_, hout["log_accept_ratio"])
+                rec["hyper"] = hout
+                rec["hyper_step_size"] = float(self.hyper_step_size)
+            theta = ch.get_state()
+            self._set_states_from(theta)
+            eta = ch.get_hypers()
+            self.hyperStates = [eta[i:i + 1].copy() for i in range(eta.size)]
+            iter_ += 1
+            if verbose and iter_ % displaySkip == 0:                         # :593-602
+                print()
+                print("iter:{:>2}".format(iter_))
+                print("step size", self.step_size)
+                print("hyper step size", self.hyper_step_size)
+                print("leapfrog", self.leapfrog)
+                print("Main acceptance", self.mainAccept)
+                print("Hyper acceptance", self.hyperAccept)
+                self.metrics(self.predict(True), self.trainY, self.predict(False), self.validateY)
+            if self.adapt_enabled:                                           # :603-607
+                step, leap = self.adapt.update(self.states)
+                self.step_size, self.leapfrog = np.float32(step), np.int32(leap)
+                rec["sjd"] = self.adapt.lastSJD
+
+            indexShift = iter_ - startSampling - 1                           # :609-646
+            indexInterval = networksPerFile * samplingStep
+            if filePath is not None and iter_ > startSampling and indexShift % indexInterval == 0:
+                for file in files:
+                    file.close()
+                idx = int((iter_ - startSampling) // (networksPerFile * samplingStep))
+                files = [open(filePath + "/" + str(n) + "." + str(idx) + ".txt", "wb") for n in range(len(self.states))]
+                files.append(open(filePath + "/hypers" + str(idx) + ".txt", "wb"))
+                with open(filePath + "/summary.txt", "wb") as file:
+                    for n in range(len(self.states)):
+                        file.write((" ".join(str(s) for s in self.states[n].shape).strip() + "\n").encode("utf-8"))
+                    numNetworks = indexShift // samplingStep
+                    numFiles = numNetworks // networksPerFile
+                    if numNetworks % networksPerFile != 0:
+                        numFiles += 1
+                    file.write((str(numNetworks) + " " + str(numFiles) + " " + str(len(self.states)) + "\n").encode("utf-8"))
+                    file.write(str(int(sum(h.size for h in self.hyperStates))).encode("utf-8"))
+            if iter_ > startSampling and iter_ % samplingStep == 0:          # :648-663
+                if filePath is not None:
+                    for n in range(len(files) - 1):
+                        np.savetxt(files[n], self.states[n])
+                    np.savetxt(files[-1], [np.reshape(h, (1,)) for h in self.hyperStates])
+                if gather is not None:
+                    gather(ch, iter_)
+            if verbose and iter_ % displaySkip == 0:                         # :664-667
+                likelihood.display(self.hyperStates)
+                print("Time elapsed:", time.time() - startTime)
+                startTime = time.time()
+            records.append(rec)
+        for file in files:
+            file.close()
+        return records

@@ -1,0 +1,93 @@
+"""The drop-in Python API end to end on the GPU: the reference's
+trainRegression.py flow (Examples/trainRegression.py:31-111), the sample files,
+the predictor, accept-ratio parity against the oracle chain."""
+import os
+
+import numpy as np
+import pytest
+
+import tbnn_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_regression_script_flow(tmp_path, monkeypatch, native):
+    """the literal example problem: 11 rows, 1->10->10->10->1 Tanh, GaussianDenseLayer, FixedGaussianLikelihood"""
+    import math
+    from tensorbnn_amd.activationFunctions import Tanh
+    from tensorbnn_amd.layer import GaussianDenseLayer
+    from tensorbnn_amd.likelihood import FixedGaussianLikelihood
+    from tensorbnn_amd.metrics import PercentError, SquaredError
+    from tensorbnn_amd.network import network
+    from tensorbnn_amd.predictor import predictor
+    monkeypatch.chdir(tmp_path)
+    trainIn = np.linspace(-2, 2, num=11)
+    valIn = np.linspace(-2 + 2 / 30, 2.0 - 2 / 30, num=30)
+    trainOut = np.sin(trainIn * math.pi * 2) * trainIn - np.cos(trainIn * math.pi)
+    valOut = np.sin(valIn * math.pi * 2) * valIn - np.cos(valIn * math.pi)
+    net = network(np.float32, 1, trainIn, trainOut.T, valIn, valOut.T)
+    seed = 1000
+    net.add(GaussianDenseLayer(1, 10, seed=seed)); net.add(Tanh()); seed += 1000
+    for _ in range(2):
+        net.add(GaussianDenseLayer(10, 10, seed=seed)); net.add(Tanh()); seed += 1000
+    net.add(GaussianDenseLayer(10, 1, seed=seed))
+    net.setupMCMC(stepSizeStart=1e-3, stepSizeMin=1e-4, stepSizeMax=1e-2, stepSizeOptions=20, leapfrogStart=50,
+                  leapfogMin=10, leapFrogMax=100, leapfrogIncrement=10, hyperStepSize=0.001, hyperLeapfrog=20,
+                  burnin=20, averagingSteps=5)
+    rec = net.train(61, 10, FixedGaussianLikelihood(sd=0.1), metricList=[SquaredError(), PercentError()],
+                    adjustHypers=True, folderName="TrigRegression", networksPerFile=2, displaySkip=30)
+    assert len(rec) == 61 and "fast<tanh" in net._chain.kernel_name
+    assert all(np.isfinite(r["main"]["log_accept_ratio"]) or r["main"]["log_accept_ratio"] == -np.inf for r in rec)
+    assert np.mean([r["main"]["accept_prob"] for r in rec]) > 0.2
+    assert any(r["L"] != 50 or abs(r["eps"] - 1e-3) > 1e-9 for r in rec[10:])       # the adapter moved (eps, L)
+    p = predictor(str(tmp_path / "TrigRegression") + "/")
+    assert p.numNetworks == 4 and len(p.hypers) == 4 and p.hypers[0].shape == (16,)      # iters 30,40,50,60
+    preds = p.predict(valIn.reshape(-1, 1))
+    assert len(preds) == 4 and preds[0].shape == (1, 30)
+    # the predictor's forward equals the oracle's forward of the saved weights
+    spec = o.make_spec([1, 10, 10, 10, 1], o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_FIXED_GAUSSIAN)
+    ref = o.forward(spec, p.vectors[0], valIn.reshape(-1, 1).astype(np.float32), np.float64)
+    np.testing.assert_allclose(preds[0], ref, rtol=2e-5, atol=2e-5)
+
+
+def test_accept_ratio_parity_with_oracle_chain(native):
+    """accept-ratio parity +-0.02: the GPU chain and the fp32 oracle chain driven by the
+    same injected momenta / uniforms over 40 epochs of a down-scaled configs[1]."""
+    spec, X, Y, theta, eta = o.synth_problem([5, 50, 50, 50, 1], 512)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    ch = native.Chain(layers, likelihood=spec.likelihood)
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    rng = np.random.default_rng(3)
+    th = theta.copy()
+    eps, L = 1.2e-4, 10
+    acc_g, acc_o, dec_same = [], [], 0
+    for ep in range(40):
+        p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+        lu = float(np.log(rng.random()))
+        ch.set_state(th)                              # same start each epoch: compares the transition itself
+        out = ch.hmc_step(eps, L, p0=p0, log_u=lu)
+        ref = o.weight_step(spec, th, eta, X, Y, eps, L, p0, lu, np.float32)
+        acc_g.append(out["accept_prob"]); acc_o.append(ref.accept_prob)
+        dec_same += int(bool(out["accepted"]) == ref.accepted)
+        th = ref.theta
+    assert abs(np.mean(acc_g) - np.mean(acc_o)) <= 0.02, (np.mean(acc_g), np.mean(acc_o))
+    assert 0.3 < np.mean(acc_o) < 0.999          # a non-trivial regime
+    assert dec_same >= 38
+    ch.close()
+
+
+def test_hyper_transition_changes_weight_target(native):
+    """after an accepted hyper transition the cached (logp, grad) is refreshed"""
+    spec, X, Y, theta, eta = o.synth_problem([1, 10, 10, 1], 200)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    ch = native.Chain(layers, likelihood=spec.likelihood)
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    ch.hmc_step(1e-4, 3)
+    h = ch.hyper_step(1e-5, 5, log_u=-1e30)
+    assert h["accepted"] == 1
+    eta2, th2 = ch.get_hypers(), ch.get_state()
+    assert np.abs(eta2 - eta).max() > 0
+    out = ch.hmc_step(1e-4, 3, p0=np.zeros(ch.P, np.float32), log_u=1e30)
+    lp, _ = o.target_log_prob_and_grad(spec, th2, eta2, X, Y, np.float64)
+    assert abs(out["logp_old"] - lp) <= 4e-6 * abs(lp) + 1e-3
+    ch.close()

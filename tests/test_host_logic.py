@@ -1,0 +1,178 @@
+"""Host-side logic of the drop-in API, on CPU: network.train's order of
+operations / file format against the oracle's restatement (with a test double
+in place of the native chain), dual averaging, and the multi-process sample
+gather over gloo (world_size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import tbnn_oracle as o
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeChain:
+    """test double for _native.Chain: deterministic 'transitions' (state += 1)"""
+
+    def __init__(self, P, H):
+        self.P, self.H, self.n = P, H, 0
+        self.theta = np.zeros(P, np.float32)
+        self.eta = np.zeros(H, np.float32)
+        self.calls = []
+
+    def set_data(self, X, Y): pass
+    def set_state(self, t): self.theta = self.base = np.array(t, np.float32); self.k = 0
+    def set_hypers(self, e): self.eta = self.ebase = np.array(e, np.float32); self.ke = 0
+    def get_state(self): return self.theta.copy()
+    def get_hypers(self): return self.eta.copy()
+
+    def hmc_step(self, eps, L, **kw):
+        self.calls.append(("w", eps, L))
+        self.k += 1
+        self.theta = (self.base + self.k).astype(np.float32)
+        return dict(accepted=1, log_accept_ratio=-0.1, accept_prob=float(np.exp(-0.1)), sjd=float(self.P))
+
+    def hyper_step(self, eps, L, **kw):
+        self.calls.append(("h", eps, L))
+        self.ke += 1
+        self.eta = (self.ebase + self.ke).astype(np.float32)
+        return dict(accepted=1, log_accept_ratio=-0.3, accept_prob=float(np.exp(-0.3)))
+
+    def forward(self, X, theta=None):
+        return np.zeros((1, len(X)), np.float32)
+
+    def close(self): pass
+
+
+def build_net():
+    from tensorbnn_amd.network import network
+    from tensorbnn_amd.layer import DenseLayer
+    from tensorbnn_amd.activationFunctions import Relu
+    X = np.linspace(-1, 1, 8).reshape(8, 1)
+    net = network(np.float32, 1, X, np.sin(X), X, np.sin(X))
+    net.add(DenseLayer(1, 10, seed=1000))
+    net.add(Relu())
+    net.add(DenseLayer(10, 10, seed=2000))
+    net.add(Relu())
+    net.add(DenseLayer(10, 1, seed=3000))
+    return net
+
+
+def test_add_builds_reference_state_layout():
+    net = build_net()
+    assert [s.shape for s in net.states] == [(10, 1), (10, 1), (10, 10), (10, 1), (1, 10), (1, 1)]
+    assert len(net.hyperStates) == 12 and all(h.shape == (1,) for h in net.hyperStates)
+    assert net._dense == [[1, 10, 1, 0], [10, 10, 1, 0], [10, 1, 0, 0]]
+    assert [l.name for l in net.layers] == ["dense", "relu", "dense", "relu", "dense"]
+
+
+def test_unsupported_plugins_fail_loudly():
+    from tensorbnn_amd.activationFunctions import Elu, Relu
+    from tensorbnn_amd.network import network
+    with pytest.raises(NotImplementedError):
+        Elu()
+    X = np.zeros((2, 1))
+    net = network(np.float32, 1, X, X, X, X)
+    with pytest.raises(NotImplementedError):
+        net.add(Relu())          # activation with no dense layer to fuse into
+    with pytest.raises(TypeError):
+        network(np.float64, 1, X, X, X, X)
+
+
+def test_train_loop_order_and_file_format(tmp_path, monkeypatch):
+    from tensorbnn_amd.likelihood import GaussianLikelihood
+    net = build_net()
+    fake = FakeChain(141, 13)
+    monkeypatch.setattr(type(net), "_ensure_chain", lambda self, likelihood=None: fake)
+    net.setupMCMC(stepSizeStart=1e-3, stepSizeMin=1e-4, stepSizeMax=1e-2, stepSizeOptions=10, leapfrogStart=20,
+                  leapfogMin=10, leapFrogMax=30, leapfrogIncrement=1, hyperStepSize=0.01, hyperLeapfrog=7, burnin=2,
+                  averagingSteps=2)
+    monkeypatch.chdir(tmp_path)
+    theta0 = net._theta().copy()
+    rec = net.train(11, 2, GaussianLikelihood(sd=0.1), folderName="run", networksPerFile=2, displaySkip=100, verbose=False)
+    assert len(rec) == 11
+    # order per epoch: weight transition then hyper transition (network.py:570-582)
+    assert [c[0] for c in fake.calls[:4]] == ["w", "h", "w", "h"]
+    assert fake.calls[1][2] == 7 and fake.calls[0][2] == 20
+    # reference-format folder, read back with the predictor.py:43-113 algorithm
+    mats, hyp = o.load_networks(str(tmp_path / "run"))
+    assert open(tmp_path / "run" / "architecture.txt").read().split() == ["dense", "relu", "dense", "relu", "dense"]
+    assert mats[0].shape[0] == 4 and len(hyp) == 4          # iters 4,6,8,10 (12 would be in the invisible last file)
+    for k, it in enumerate((4, 6, 8, 10)):
+        got = np.concatenate([m[k].reshape(-1) for m in mats])
+        np.testing.assert_allclose(got, theta0 + it, rtol=1e-6)
+        assert hyp[k].shape == (13,)
+    # byte-identical to the oracle's restatement of the writer
+    w = o.SampleWriter(str(tmp_path / "ora"), [s.shape for s in net.states], [l.name for l in net.layers], 13, 2, 2, 2)
+    eta0 = np.concatenate([np.full(1, v, np.float32) for v in ([0, 0.5 ** 0.5, 0, 0.5 ** 0.5] * 3 + [0.1 ** 0.5])])
+    for it in range(1, 12):
+        th = theta0 + it
+        sts, off = [], 0
+        for s in net.states:
+            sts.append(th[off:off + s.size].reshape(s.shape)); off += s.size
+        w.after_epoch(it, sts, [eta0[i:i + 1] + it for i in range(13)])
+    w.close()
+    for f in sorted(os.listdir(tmp_path / "ora")):
+        assert open(tmp_path / "ora" / f, "rb").read() == open(tmp_path / "run" / f, "rb").read(), f
+
+
+def test_dual_averaging_matches_oracle():
+    net = build_net()
+    net.setupMCMC(hyperStepSize=0.01, burnin=100)
+    st = o.DualAveragingState(hyper_step_size=0.01, burnin=100)
+    rng = np.random.default_rng(0)
+    for ep in range(30):
+        lar = float(rng.normal(-0.5, 1.0))
+        a1 = net._dual_averaging(ep, lar)
+        a2 = o.dual_averaging_update(st, ep, lar)
+        assert abs(a1 - a2) < 1e-6
+        assert abs(float(net.hyper_step_size) - st.eps_h) <= 1e-5 * st.eps_h
+        assert abs(float(net.h) - st.h) < 1e-6
+
+
+GLOO_WORKER = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from tensorbnn_amd import parallel
+rank, world, _ = parallel.init_distributed("gloo")
+class Fake:
+    def __init__(s, r): s.r = r; s.k = 0
+    def get_state(s): return np.full(6, 10 * s.r + s.k, np.float32)
+    def get_hypers(s): return np.full(2, 100 * s.r + s.k, np.float32)
+g = parallel.SampleGatherer(6, 2, device="cpu")
+ch = Fake(rank)
+for k in range(3):
+    ch.k = k
+    g(ch, k)
+st = g.stacked()
+assert st.shape == (3, world, 8), st.shape
+for k in range(3):
+    for c in range(world):
+        assert np.all(st[k, c, :6] == 10 * c + k) and np.all(st[k, c, 6:] == 100 * c + k)
+if rank == 0:
+    parallel.write_chain_folders(sys.argv[2], st, [(2, 2), (2, 1)], ["dense"], 2)
+torch.distributed.barrier()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_process_gloo_gather(tmp_path):
+    """N>1 path on CPU: world_size-2 gloo all-gather of the sampled states, chain-major, and the
+    per-chain reference-format folders rank 0 writes."""
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_WORKER)
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), ROOT, str(tmp_path / "out")]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    for c in range(2):
+        mats, hyp = o.load_networks(str(tmp_path / "out" / f"chain{c}"))
+        assert mats[0].shape == (3, 2, 2) and mats[1].shape == (3, 2, 1) and len(hyp) == 3
+        for k in range(3):
+            assert np.all(mats[0][k] == 10 * c + k) and np.all(hyp[k] == 100 * c + k)
