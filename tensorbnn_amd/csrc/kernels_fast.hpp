@@ -28,7 +28,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FAST_WAVES 4
 #define FAST_THREADS (FAST_WAVES * 64)
-#define FAST_SLOTS 2     // tiles a wave works on at a time
 
 // HACT: activation after every hidden layer, LACT: after the last layer,
 // BERN: Bernoulli likelihood (else the Gaussian family) -- all compile-time so
@@ -68,29 +67,33 @@ struct FastCfg {
     static constexpr int KG(int l) { return cdiv(in(l), 16); }           // 16-unit k groups of layer l's input
     static constexpr int LDW(int l) { return 16 * KG(l) + 4; }           // pitch of the W_l image (== 4 mod 8)
     static constexpr int maxMT() { int m = 0; for (int l = 0; l < NL; ++l) m = MT(l) > m ? MT(l) : m; return m; }
-    static constexpr int maxNT() { int m = 0; for (int l = 0; l < NL; ++l) m = NT(l) > m ? NT(l) : m; return m; }
-    static constexpr int PA = 16 * maxNT() + 4;                          // pitch of the A_{l-1} image (== 4 mod 8)
+    static constexpr int PA(int l) { return 16 * NT(l) + 4; }            // pitch of the image of a_l = input of layer l (== 4 mod 8)
     static constexpr int PD = 16 * maxMT() + 4;                          // pitch of the delta image
     // number of valid k-steps s in group kt of a K dimension of size K (unit = 16kt+4g+s)
     static constexpr int ksteps(int K, int kt) { int rem = K - 16 * kt; return rem >= 4 ? 4 : (rem < 0 ? 0 : rem); }
-    // LDS layout (floats): [W images][bias images][per wave: FAST_SLOTS x (A image, D image)]
+    // LDS layout (floats): [W images][bias images][W^T images][per wave: images of a_0..a_{NL-1}, delta image]
     static constexpr int woff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += 16 * MT(m) * LDW(m); return o; }
     static constexpr int W_FLOATS = woff(NL);
     static constexpr int boff(int l) { int o = W_FLOATS; for (int m = 0; m < l; ++m) o += 16 * MT(m); return o; }
     static constexpr int WB_FLOATS = boff(NL);                           // == the global padded image (k_update writes it)
     // transposed weight images W_l^T [in-unit][out-unit] for the delta chain (l >= 1), built in the prologue
     static constexpr int LDT(int l) { return 16 * MT(l) + 4; }
-    static constexpr int toff(int l) { int o = WB_FLOATS; for (int m = 1; m < l; ++m) o += 16 * KG(m) * LDT(m); return o; }
+    // last layer with <= 2 outputs runs on the VALU (16 FMAs per output instead of padded MFMA tiles)
+    static constexpr bool VL = NL >= 2 && out(NL - 1) <= 2;
+    static constexpr int NLM = VL ? NL - 1 : NL;                          // layers on the MFMA path
+    static constexpr int toff(int l) { int o = WB_FLOATS; for (int m = 1; m < l && m < NLM; ++m) o += 16 * KG(m) * LDT(m); return o; }
     static constexpr int STATIC_FLOATS = toff(NL);
-    static constexpr int SLOT_FLOATS = 16 * PA + 16 * PD;
-    static constexpr int WAVE_FLOATS = FAST_SLOTS * SLOT_FLOATS;
+    static constexpr int aoff(int l) { int o = 0; for (int m = 0; m < l && m < NLM; ++m) o += 16 * PA(m); return o; }   // per wave
+    static constexpr int doff = aoff(NL);
+    static constexpr int WAVE_FLOATS = doff + 16 * PD;
     static constexpr int P() { int p = 0; for (int l = 0; l < NL; ++l) p += in(l) * out(l) + out(l); return p; }
     static constexpr int offW(int l) { int p = 0; for (int m = 0; m < l; ++m) p += in(m) * out(m) + out(m); return p; }
-    static constexpr int dwoff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += MT(m) * NT(m); return o; }
+    static constexpr int dwoff(int l) { int o = 0; for (int m = 0; m < l && m < NLM; ++m) o += MT(m) * NT(m); return o; }
     static constexpr int DW_TILES = dwoff(NL);
     // epilogue staging: tiles per pass with all 4 waves' copies resident
     static constexpr int MIN_LDS = STATIC_FLOATS + FAST_WAVES * WAVE_FLOATS;
-    static constexpr int EP_TILES_WANT = DW_TILES < 16 ? DW_TILES : 16;
+    // one staging pass when all dW tiles of the 4 waves fit in 156 KB of LDS, else as many tiles per pass as fit
+    static constexpr int EP_TILES_WANT = DW_TILES * FAST_WAVES * 256 <= 39936 ? DW_TILES : (DW_TILES < 16 ? DW_TILES : 16);
     static constexpr int LDS_FLOATS = MIN_LDS > EP_TILES_WANT * FAST_WAVES * 256 ? MIN_LDS : EP_TILES_WANT * FAST_WAVES * 256;
     static constexpr int EP_TILES = LDS_FLOATS / (FAST_WAVES * 256) < DW_TILES ? LDS_FLOATS / (FAST_WAVES * 256) : DW_TILES;
     static constexpr int aroff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += MT(m); return o; }   // act register tiles
@@ -128,36 +131,58 @@ struct TileRegs {
     float x0[C::KS0];
 };
 
-template <class S, int l, int NTL>
+#ifdef TBNN_NOFENCE
+#define SCHED_FENCE() do {} while (0)
+#else
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// ---- forward: layer l.  Its first k-group of A operands and its bias tiles arrive preloaded
+// (An, Bn); before its last MFMAs it preloads those of layer l+1.  The transposed image of its
+// output (input of layer l+1, ones column at unit in(l+1)) is written right after the activation,
+// i.e. under the next layer's MFMAs and far from the backward pass that reads it.
+template <class S, int l>
 struct FwdLayer {
     using C = FastCfg<S>;
-    static __device__ __forceinline__ void run(TileRegs<S> (&T)[NTL], const float* __restrict__ lds, int i16, int g) {
+    static __device__ __forceinline__ void preload(f32x4 (&An)[C::MT(l)], f32x4 (&Bn)[C::MT(l)], const float* __restrict__ lds,
+                                                    int i16, int g) {
         constexpr int MT = C::MT(l);
-        f32x4 acc[NTL][MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * mt + 4 * g);   // bias in D layout
-#pragma unroll
-            for (int tl = 0; tl < NTL; ++tl) acc[tl][mt] = b;
-        }
+        for (int mt = 0; mt < MT; ++mt) Bn[mt] = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * mt + 4 * g);
         if constexpr (l == 0) {
-            // natural k mapping: step t covers units 4t+g, B operand straight from X
+            // natural k mapping (unit 4t+g): one b32 per (mt, t); KS0 <= 4 steps packed into An[mt]
+            static_assert(C::KS0 <= 4, "layer-0 fan-in above 16 needs the grouped path");
 #pragma unroll
-            for (int t = 0; t < C::KS0; ++t) {
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const float A = lds[C::woff(0) + (16 * mt + i16) * C::LDW(0) + 4 * t + g];
-#pragma unroll
-                    for (int tl = 0; tl < NTL; ++tl) acc[tl][mt] = mfma16(A, T[tl].x0[t], acc[tl][mt]);
-                }
-            }
+                for (int t = 0; t < C::KS0; ++t) An[mt][t] = lds[C::woff(0) + (16 * mt + i16) * C::LDW(0) + 4 * t + g];
         } else {
-            // A operands (W_l rows, 4 k-steps per 16-B read) are fetched one k-group ahead of their MFMAs
+            const float* wrow = lds + C::woff(l) + i16 * C::LDW(l) + 4 * g;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) An[mt] = load_ks(wrow + 16 * mt * C::LDW(l), C::ksteps(C::in(l), 0));
+        }
+    }
+
+    static __device__ __forceinline__ void run(TileRegs<S>& T, const float* __restrict__ lds, float* wl, int i16, int g,
+                                                const f32x4 (&A0)[C::MT(l)], const f32x4 (&B0)[C::MT(l)]) {
+        constexpr int MT = C::MT(l);
+        constexpr int MTN = C::MT(l + 1 < C::NLM ? l + 1 : l);
+        f32x4 acc[MT];
+        f32x4 Anext[MTN], Bnext[MTN];          // next layer's preloads
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = B0[mt];
+        if constexpr (l == 0) {
+            if constexpr (l + 1 < C::NLM) FwdLayer<S, l + 1>::preload(Anext, Bnext, lds, i16, g);
+#pragma unroll
+            for (int t = 0; t < C::KS0; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(A0[mt][t], T.x0[t], acc[mt]);
+        } else {
             constexpr int KG = C::KG(l);
             const float* wrow = lds + C::woff(l) + i16 * C::LDW(l) + 4 * g;
             f32x4 An[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) An[mt] = load_ks(wrow + 16 * mt * C::LDW(l), C::ksteps(C::in(l), 0));
+            for (int mt = 0; mt < MT; ++mt) An[mt] = A0[mt];
 #pragma unroll
             for (int kt = 0; kt < KG; ++kt) {
                 f32x4 A4[MT];
@@ -167,95 +192,81 @@ struct FwdLayer {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         An[mt] = load_ks(wrow + 16 * mt * C::LDW(l) + 16 * (kt + 1), C::ksteps(C::in(l), kt + 1));
+                } else {
+                    if constexpr (l + 1 < C::NLM) FwdLayer<S, l + 1>::preload(Anext, Bnext, lds, i16, g);
                 }
 #pragma unroll
-                for (int s = 0; s < C::ksteps(C::in(l), kt); ++s) {
+                for (int s = 0; s < C::ksteps(C::in(l), kt); ++s)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int tl = 0; tl < NTL; ++tl)
-                            acc[tl][mt] = mfma16(A4[mt][s], T[tl].a[C::aroff(l - 1) + kt][s], acc[tl][mt]);
-                }
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(A4[mt][s], T.a[C::aroff(l - 1) + kt][s], acc[mt]);
             }
         }
 #pragma unroll
-        for (int tl = 0; tl < NTL; ++tl)
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = actc_fwd<S::act(l)>(acc[mt][r]);
+            T.a[C::aroff(l) + mt] = v;
+        }
+        if constexpr (l + 1 < C::NLM) {
+            constexpr int u1 = C::in(l + 1);
+            float* aimg = wl + C::aoff(l + 1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = actc_fwd<S::act(l)>(acc[tl][mt][r]);
-                T[tl].a[C::aroff(l) + mt] = v;
+                f32x4 v = T.a[C::aroff(l) + mt];
+                if constexpr (u1 % 16 != 0) {
+                    if (mt == u1 / 16 && g == (u1 % 16) / 4) v[u1 % 4] = 1.f;
+                }
+                *reinterpret_cast<f32x4*>(aimg + i16 * C::PA(l + 1) + 16 * mt + 4 * g) = v;
             }
-        TSTAMP(1 + l);
-        if constexpr (l + 1 < C::NL) FwdLayer<S, l + 1, NTL>::run(T, lds, i16, g);
+            TSTAMP(1 + l);
+            FwdLayer<S, l + 1>::run(T, lds, wl, i16, g, Anext, Bnext);
+        } else { TSTAMP(1 + l); }
     }
 };
 
-template <class S, int l, int NTL>
-struct BwdLayer {
+// ---- backward, as an explicit software pipeline (scheduling fences keep the order):
+//   W(D_l) R(op_l) | dW_{l+1} MFMAs | dA_l MFMAs -> delta_{l-1} | recurse(l-1)
+// so every LDS write->read round trip of layer l sits under the 64 dW MFMAs of layer l+1.
+template <class S, int l>
+struct BwdOps {
     using C = FastCfg<S>;
-    // dz: delta tiles of layer l (D layout) for each tile slot
-    static __device__ __forceinline__ void run(f32x4 (&dW)[C::DW_TILES], TileRegs<S> (&T)[NTL], const float* __restrict__ lds,
-                                                float* wl, int i16, int g, const f32x4 (&dz)[NTL][C::MT(l)]) {
+    // delta_l image [row][unit] -> A operands of dW_l; B operands from the image of a_{l-1} (k = data row 4g+s)
+    static __device__ __forceinline__ void issue(const f32x4 (&dz)[C::MT(l)], float* wl, int i16, int g,
+                                                  float (&Aop)[C::MT(l)][4], float (&Bop)[C::NT(l)][4]) {
         constexpr int MT = C::MT(l), NT = C::NT(l);
-        // transposed images [row][unit] of delta_l and of a_{l-1} (ones column at unit in(l) -> db)
+        float* dimg = wl + C::doff;
+        const float* aimg = wl + C::aoff(l);
 #pragma unroll
-        for (int tl = 0; tl < NTL; ++tl) {
-            float* aimg = wl + tl * C::SLOT_FLOATS;
-            float* dimg = aimg + 16 * C::PA;
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(dimg + i16 * C::PD + 16 * mt + 4 * g) = dz[mt];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Bop[nt][s] = aimg[(4 * g + s) * C::PA(l) + 16 * nt + i16];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) Aop[mt][s] = dimg[(4 * g + s) * C::PD + 16 * mt + i16];
+        }
+    }
+    static __device__ __forceinline__ void dw(f32x4 (&dW)[C::DW_TILES], const float (&Aop)[C::MT(l)][4],
+                                               const float (&Bop)[C::NT(l)][4]) {
+        constexpr int MT = C::MT(l), NT = C::NT(l);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                *reinterpret_cast<f32x4*>(dimg + i16 * C::PD + 16 * mt + 4 * g) = dz[tl][mt];
-            constexpr int u1 = C::in(l);
-            if constexpr (l == 0) {
 #pragma unroll
-                for (int t = 0; t < C::KS0; ++t) {
-                    const int u = 4 * t + g;
-                    if (u < u1) aimg[i16 * C::PA + u] = T[tl].x0[t];
-                }
-                if (g == (u1 & 3)) aimg[i16 * C::PA + u1] = 1.f;          // units u1+1.. of the tile: stale but finite, never stored
-            } else {
-                constexpr int MTP = C::MT(l - 1);
-#pragma unroll
-                for (int m = 0; m < MTP; ++m) {
-                    f32x4 v = T[tl].a[C::aroff(l - 1) + m];
-                    if constexpr (u1 % 16 != 0) {
-                        if (m == u1 / 16 && g == (u1 % 16) / 4) v[u1 % 4] = 1.f;
-                    }
-                    *reinterpret_cast<f32x4*>(aimg + i16 * C::PA + 16 * m + 4 * g) = v;
-                }
-                if constexpr (u1 % 16 == 0) {
-                    if (g == 0) aimg[i16 * C::PA + u1] = 1.f;
-                }
-            }
-        }
-        TSTAMP(10 + 3 * l);
-        // dW operands: k = data row 4g+s.  Issued now, consumed after the delta chain below.
-        float Aop[NTL][MT][4], Bop[NTL][NT][4];
-#pragma unroll
-        for (int tl = 0; tl < NTL; ++tl) {
-            const float* aimg = wl + tl * C::SLOT_FLOATS;
-            const float* dimg = aimg + 16 * C::PA;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) Aop[tl][mt][s] = dimg[(4 * g + s) * C::PD + 16 * mt + i16];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) Bop[tl][nt][s] = aimg[(4 * g + s) * C::PA + 16 * nt + i16];
-            }
-        }
-        // delta_{l-1} = (W_l^T dz) * act'(a_{l-1}) ; M = in(l) units, K = out(l) units;
-        // A operands from the transposed image, one k-group ahead
-        f32x4 dzp[NTL][C::MT(l > 0 ? l - 1 : 0)];
+                for (int nt = 0; nt < NT; ++nt)
+                    dW[C::dwoff(l) + mt * NT + nt] = mfma16(Aop[mt][s], Bop[nt][s], dW[C::dwoff(l) + mt * NT + nt]);
+    }
+    // delta_{l-1} = (W_l^T dz) * act'(a_{l-1}); A operands from the transposed image, one k-group ahead
+    static __device__ __forceinline__ void da(const TileRegs<S>& T, const float* __restrict__ lds, int i16, int g,
+                                               const f32x4 (&dz)[C::MT(l)], f32x4 (&dzp)[C::MT(l > 0 ? l - 1 : 0)]) {
         if constexpr (l > 0) {
             constexpr int MTP = C::MT(l - 1);
             constexpr int KG = C::cdiv(C::out(l), 16);
-            f32x4 acc[NTL][MTP];
+            f32x4 acc[MTP];
 #pragma unroll
-            for (int tl = 0; tl < NTL; ++tl)
-#pragma unroll
-                for (int m = 0; m < MTP; ++m) acc[tl][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < MTP; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* trow = lds + C::toff(l) + i16 * C::LDT(l) + 4 * g;
             f32x4 An[MTP];
 #pragma unroll
@@ -271,109 +282,186 @@ struct BwdLayer {
                         An[m] = load_ks(trow + 16 * m * C::LDT(l) + 16 * (kt + 1), C::ksteps(C::out(l), kt + 1));
                 }
 #pragma unroll
-                for (int s = 0; s < C::ksteps(C::out(l), kt); ++s) {
+                for (int s = 0; s < C::ksteps(C::out(l), kt); ++s)
 #pragma unroll
-                    for (int m = 0; m < MTP; ++m)
-#pragma unroll
-                        for (int tl = 0; tl < NTL; ++tl) acc[tl][m] = mfma16(A4[m][s], dz[tl][kt][s], acc[tl][m]);
-                }
+                    for (int m = 0; m < MTP; ++m) acc[m] = mfma16(A4[m][s], dz[kt][s], acc[m]);
             }
 #pragma unroll
-            for (int tl = 0; tl < NTL; ++tl)
+            for (int m = 0; m < MTP; ++m)
 #pragma unroll
-                for (int m = 0; m < MTP; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        dzp[tl][m][r] = acc[tl][m][r] * actc_bwd<S::act(l - 1)>(T[tl].a[C::aroff(l - 1) + m][r]);
+                for (int r = 0; r < 4; ++r) dzp[m][r] = acc[m][r] * actc_bwd<S::act(l - 1)>(T.a[C::aroff(l - 1) + m][r]);
         }
-        TSTAMP(11 + 3 * l);
-        // dW_l += dz . a_{l-1}^T
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int tl = 0; tl < NTL; ++tl)
-                        dW[C::dwoff(l) + mt * NT + nt] = mfma16(Aop[tl][mt][s], Bop[tl][nt][s], dW[C::dwoff(l) + mt * NT + nt]);
-        TSTAMP(12 + 3 * l);
-        if constexpr (l > 0) BwdLayer<S, l - 1, NTL>::run(dW, T, lds, wl, i16, g, dzp);
     }
 };
 
-// one step of the row loop: NTL tiles through forward, likelihood, backward
-template <class S, int NTL>
+template <class S, int l>
+struct BwdPipe {
+    using C = FastCfg<S>;
+    // (Aup, Bup): operands of dW_{l+1}, already in flight; consumed here under layer l's LDS traffic
+    static __device__ __forceinline__ void run(f32x4 (&dW)[C::DW_TILES], const TileRegs<S>& T, const float* __restrict__ lds,
+                                                float* wl, int i16, int g, const f32x4 (&dz)[C::MT(l)],
+                                                const float (&Aup)[C::MT(l + 1)][4], const float (&Bup)[C::NT(l + 1)][4]) {
+        float Aop[C::MT(l)][4], Bop[C::NT(l)][4];
+        BwdOps<S, l>::issue(dz, wl, i16, g, Aop, Bop);
+        SCHED_FENCE();
+        TSTAMP(10 + 3 * l);
+        BwdOps<S, l + 1>::dw(dW, Aup, Bup);
+        SCHED_FENCE();
+        TSTAMP(11 + 3 * l);
+        if constexpr (l > 0) {
+            f32x4 dzp[C::MT(l - 1)];
+            BwdOps<S, l>::da(T, lds, i16, g, dz, dzp);
+            SCHED_FENCE();
+            TSTAMP(12 + 3 * l);
+            BwdPipe<S, l - 1>::run(dW, T, lds, wl, i16, g, dzp, Aop, Bop);
+        } else {
+            BwdOps<S, 0>::dw(dW, Aop, Bop);
+            TSTAMP(12);
+        }
+    }
+};
+
+// state of the VALU last layer (C::VL): weights/bias (loaded once) and per-lane dW/db partial sums
+template <class S>
+struct LastRegs {
+    using C = FastCfg<S>;
+    static constexpr int O = C::VL ? C::out(C::NL - 1) : 1, MTP = C::MT(C::NL >= 2 ? C::NL - 2 : 0);
+    f32x4 w[O][MTP];       // W_L[o][16mt+4g+r]
+    float b[O];
+    f32x4 acc[O][MTP];     // sum over this lane's rows of dz_o * a_{L-1}[unit][row]
+    float accb[O];
+};
+
+// likelihood for one output value: statistic (counted when `count`), returns dL/df * act'
+template <class S>
+__device__ __forceinline__ float lik_delta(float fi, float yy, float inv_var, bool count, double& stat) {
+    float da;
+    if constexpr (S::BERN) {
+        const float p = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);
+        const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
+        const float t1 = (yy == 0.f) ? 0.f : yy * logf(p);
+        const float t2 = (1.f - yy == 0.f) ? 0.f : (1.f - yy) * log1pf(-p);
+        if (count) stat += (double)(t1 + t2);
+        da = inside ? (yy / p - (1.f - yy) / (1.f - p)) : 0.f;
+    } else {
+        const float res = yy - fi;
+        if (count) stat += (double)res * (double)res;
+        da = res * inv_var;
+    }
+    return da * actc_bwd<S::LACT>(fi);
+}
+
+// one step of the row loop: one 16-row tile through forward, likelihood, backward.
+// y: C::VL ? y[o] of row i16 (all lane groups) : D layout [MTL][4]
+template <class S>
 struct TileStep {
     using C = FastCfg<S>;
-    static __device__ __forceinline__ void run(f32x4 (&dW)[C::DW_TILES], double& stat, const float* __restrict__ lds, float* wl,
-                                                int i16, int g, float inv_var, const float (&x)[NTL][C::KS0],
-                                                const float (&y)[NTL][C::MTL][4], const bool (&rvalid)[NTL]) {
-        constexpr int d_out = C::out(C::NL - 1);
-        TileRegs<S> T[NTL];
+    static constexpr int YN = C::VL ? C::out(C::NL - 1) : 4 * C::MTL;
+    static __device__ __forceinline__ void run(f32x4 (&dW)[C::DW_TILES], LastRegs<S>& LR, double& stat, const float* __restrict__ lds,
+                                                float* wl, int i16, int g, float inv_var, const float (&x)[C::KS0],
+                                                const float (&y)[YN], bool rvalid,
+                                                const f32x4 (&A0)[C::MT(0)], const f32x4 (&B0)[C::MT(0)]) {
+        constexpr int d_out = C::out(C::NL - 1), d_in = C::in(0), L = C::NL - 1, LM = C::NLM - 1;
+        TileRegs<S> T;
 #pragma unroll
-        for (int tl = 0; tl < NTL; ++tl)
-#pragma unroll
-            for (int t = 0; t < C::KS0; ++t) T[tl].x0[t] = x[tl][t];
+        for (int t = 0; t < C::KS0; ++t) {
+            T.x0[t] = x[t];
+            const int u = 4 * t + g;
+            if (u < d_in) wl[C::aoff(0) + i16 * C::PA(0) + u] = x[t];       // transposed image of x (ones column preset)
+        }
+#ifdef TBNN_IGLP
+        __builtin_amdgcn_iglp_opt(TBNN_IGLP);
+#endif
         TSTAMP(0);
-        FwdLayer<S, 0, NTL>::run(T, lds, i16, g);
-        // likelihood: f = a_L in D layout (unit 16mt+4g+r, row = lane&15)
-        f32x4 dz[NTL][C::MTL];
+        FwdLayer<S, 0>::run(T, lds, wl, i16, g, A0, B0);
+        f32x4 dz[C::MT(LM)];
+        if constexpr (C::VL) {
+            // ---- last layer on the VALU: f_o = b_o + sum_u W[o][u] a[u]; lane (row i16, group g) holds units 16mt+4g+r
+            constexpr int MTP = C::MT(L - 1);
+            float dzl[d_out];
 #pragma unroll
-        for (int tl = 0; tl < NTL; ++tl)
+            for (int o = 0; o < d_out; ++o) {
+                float p = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MTP; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p = fmaf(LR.w[o][mt][r], T.a[C::aroff(L - 1) + mt][r], p);
+                p += __shfl_xor(p, 16, 64);
+                p += __shfl_xor(p, 32, 64);
+                const float fi = actc_fwd<S::LACT>(p + LR.b[o]);
+                dzl[o] = rvalid ? lik_delta<S>(fi, y[o], inv_var, g == 0, stat) : 0.f;
+            }
+            TSTAMP(9);
+            // dW_L / db_L partial sums, delta_{L-1}
+#pragma unroll
+            for (int mt = 0; mt < MTP; ++mt) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < d_out; ++o)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        LR.acc[o][mt][r] = fmaf(dzl[o], T.a[C::aroff(L - 1) + mt][r], LR.acc[o][mt][r]);
+                        d[r] = fmaf(LR.w[o][mt][r], dzl[o], d[r]);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz[mt][r] = d[r] * actc_bwd<S::act(L - 1)>(T.a[C::aroff(L - 1) + mt][r]);
+            }
+#pragma unroll
+            for (int o = 0; o < d_out; ++o) LR.accb[o] += dzl[o];
+        } else {
+            // likelihood: f = a_L in D layout (unit 16mt+4g+r, row = lane&15)
 #pragma unroll
             for (int mt = 0; mt < C::MTL; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int u = 16 * mt + 4 * g + r;
-                    float d = 0.f;
-                    if (rvalid[tl] && u < d_out) {
-                        const float fi = T[tl].a[C::aroff(C::NL - 1) + mt][r];
-                        const float yy = y[tl][mt][r];
-                        float da;
-                        if constexpr (S::BERN) {
-                            const float p = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);
-                            const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
-                            const float t1 = (yy == 0.f) ? 0.f : yy * logf(p);
-                            const float t2 = (1.f - yy == 0.f) ? 0.f : (1.f - yy) * log1pf(-p);
-                            stat += (double)(t1 + t2);
-                            da = inside ? (yy / p - (1.f - yy) / (1.f - p)) : 0.f;
-                        } else {
-                            const float res = yy - fi;
-                            stat += (double)res * (double)res;
-                            da = res * inv_var;
-                        }
-                        d = da * actc_bwd<S::LACT>(fi);
-                    }
-                    dz[tl][mt][r] = d;
+                    dz[mt][r] = (rvalid && u < d_out) ? lik_delta<S>(T.a[C::aroff(L) + mt][r], y[4 * mt + r], inv_var, true, stat) : 0.f;
                 }
-        TSTAMP(9);
-        BwdLayer<S, C::NL - 1, NTL>::run(dW, T, lds, wl, i16, g, dz);
+            TSTAMP(9);
+        }
+        // top of the backward pipeline (layer LM)
+        float Aop[C::MT(LM)][4], Bop[C::NT(LM)][4];
+        BwdOps<S, LM>::issue(dz, wl, i16, g, Aop, Bop);
+        TSTAMP(10 + 3 * LM);
+        if constexpr (LM > 0) {
+            f32x4 dzp[C::MT(LM - 1)];
+            BwdOps<S, LM>::da(T, lds, i16, g, dz, dzp);
+            SCHED_FENCE();
+            TSTAMP(12 + 3 * LM);
+            BwdPipe<S, LM - 1>::run(dW, T, lds, wl, i16, g, dzp, Aop, Bop);
+        } else {
+            BwdOps<S, 0>::dw(dW, Aop, Bop);
+        }
     }
 };
 
-// dense slab write-out for the staged tiles [t0, t0+cnt): thread (r = wave, lane) owns register r
-// of every tile; the 4 waves' copies are summed in fixed order; no division anywhere
+// dense slab write-out for the staged tiles [t0, t0+cnt) ([wave][tile][lane] x 16 B): tile t is handled
+// by wave t % 4, every lane sums the 4 waves' copies of its 4 registers (fixed order) and stores them;
+// no division anywhere
 template <class S, int l>
 struct SlabOut {
     using C = FastCfg<S>;
-    static __device__ __forceinline__ void run(const float* buf, float* __restrict__ slab, int r, int lane, int t0, int cnt) {
+    static __device__ __forceinline__ void run(const float* buf, float* __restrict__ slab, int wave, int lane, int t0, int cnt) {
         constexpr int in = C::in(l), out = C::out(l), MT = C::MT(l), NT = C::NT(l);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int t = C::dwoff(l) + mt * NT + nt - t0;
-                if (t >= 0 && t < cnt) {
-                    const int row = 16 * mt + 4 * (lane >> 4) + r, col = 16 * nt + (lane & 15);
-                    if (row < out && col <= in) {
-                        const float* src = buf + (t * 4 + r) * 64 + lane;
-                        const float v = (src[0] + src[C::EP_TILES * 256]) + (src[2 * C::EP_TILES * 256] + src[3 * C::EP_TILES * 256]);
-                        slab[C::offW(l) + (col < in ? row * in + col : in * out + row)] = v;   // col == in: bias (ones column)
+                if (t >= 0 && t < cnt && (t & (FAST_WAVES - 1)) == wave) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(buf) + t * 64 + lane;
+                    const f32x4 c0 = src[0], c1 = src[C::EP_TILES * 64], c2 = src[2 * C::EP_TILES * 64], c3 = src[3 * C::EP_TILES * 64];
+                    const int col = 16 * nt + (lane & 15), row0 = 16 * mt + 4 * (lane >> 4);
+                    if (col <= in) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (row0 + r < out)
+                                slab[C::offW(l) + (col < in ? (row0 + r) * in + col : in * out + row0 + r)] =
+                                    (c0[r] + c1[r]) + (c2[r] + c3[r]);                   // col == in: bias (ones column)
                     }
                 }
             }
-        if constexpr (l + 1 < C::NL) SlabOut<S, l + 1>::run(buf, slab, r, lane, t0, cnt);
+        if constexpr (l + 1 < C::NLM) SlabOut<S, l + 1>::run(buf, slab, wave, lane, t0, cnt);
     }
 };
 
@@ -387,7 +475,7 @@ struct ImageMap {
         for (int i = 0; i < out; ++i) {
             for (int k = 0; k < in; ++k) {
                 map[C::offW(l) + i * in + k] = C::woff(l) + i * C::LDW(l) + k;
-                map[C::P() + C::offW(l) + i * in + k] = l >= 1 ? C::toff(l) + k * C::LDT(l) + i : -1;   // W_l^T
+                map[C::P() + C::offW(l) + i * in + k] = (l >= 1 && l < C::NLM) ? C::toff(l) + k * C::LDT(l) + i : -1;   // W_l^T
             }
             map[C::offW(l) + in * out + i] = C::boff(l) + i;
             map[C::P() + C::offW(l) + in * out + i] = -1;
@@ -405,7 +493,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     using C = FastCfg<S>;
 #define TB_STAMP(i) do { if (stamps && threadIdx.x == 0 && blockIdx.x == 0) { stamps[i] = wall_clock64(); stamps[8 + i] = clock64(); } } while (0)
     TB_STAMP(0);
-    static_assert(C::WB_FLOATS % 4 == 0 && C::STATIC_FLOATS % 4 == 0 && C::SLOT_FLOATS % 4 == 0, "images must be float4-addressable");
+    static_assert(C::WB_FLOATS % 4 == 0 && C::STATIC_FLOATS % 4 == 0 && C::WAVE_FLOATS % 4 == 0, "images must be float4-addressable");
     static_assert(C::LDS_FLOATS * 4 + 64 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     __shared__ double red[FAST_WAVES];
@@ -443,80 +531,119 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     const long W = (long)gridDim.x * FAST_WAVES;                  // waves in the grid
     const long wg = (long)blockIdx.x * FAST_WAVES + wave;
 
-    // tile t of this wave = wg + t*W.  Pairs while two remain, then a single.
-    float xn[2][C::KS0], yn[2][C::MTL][4];
-    auto fetch = [&](int slot, long tile) {
+    // ones columns of the activation images (never overwritten: x image; own tile column when in(l) % 16 == 0)
+    if (g == 0) wl[C::aoff(0) + i16 * C::PA(0) + d_in] = 1.f;
+#pragma unroll
+    for (int l = 1; l < C::NLM; ++l)
+        if (C::in(l) % 16 == 0 && g == 0) wl[C::aoff(l) + i16 * C::PA(l) + C::in(l)] = 1.f;
+    // layer-0 operands and bias tiles are the same for every tile: loaded once
+    f32x4 A0[C::MT(0)], B0[C::MT(0)];
+    FwdLayer<S, 0>::preload(A0, B0, lds, i16, g);
+
+    // tile t of this wave = wg + t*W; x / y of the next tile are fetched under the current one
+    constexpr int YN = TileStep<S>::YN;
+    float xn[C::KS0], yn[YN];
+    LastRegs<S> LR;
+    if constexpr (C::VL) {
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) {
+            LR.b[o] = lds[C::boff(C::NL - 1) + o];
+            LR.accb[o] = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < LastRegs<S>::MTP; ++mt) {
+                LR.w[o][mt] = *reinterpret_cast<const f32x4*>(lds + C::woff(C::NL - 1) + o * C::LDW(C::NL - 1) + 16 * mt + 4 * g);
+                LR.acc[o][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    auto fetch = [&](long tile) {
         const long row = tile * 16 + i16;
         const bool ok = tile < ntiles && row < n;
 #pragma unroll
         for (int t = 0; t < C::KS0; ++t) {
             const int u = 4 * t + g;
-            xn[slot][t] = (ok && u < d_in) ? X[row * d_in + u] : 0.f;
+            xn[t] = (ok && u < d_in) ? X[row * d_in + u] : 0.f;
         }
+        if constexpr (C::VL) {
 #pragma unroll
-        for (int mt = 0; mt < C::MTL; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int u = 16 * mt + 4 * g + r;
-                yn[slot][mt][r] = (ok && u < d_out) ? Y[row * d_out + u] : 0.f;
-            }
-    };
-    long tile = wg;
-    fetch(0, tile);
-    fetch(1, tile + W);
-    bool first = true;
-    const bool pair_mode = (nd.reserved_flags & 1) == 0;
-    while (pair_mode && tile + W < ntiles) {                      // two tiles at a time
-        float x[2][C::KS0], y[2][C::MTL][4];
-        bool rv[2];
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            rv[sl] = (tile + sl * W) * 16 + i16 < n;
-#pragma unroll
-            for (int t = 0; t < C::KS0; ++t) x[sl][t] = xn[sl][t];
+            for (int o = 0; o < d_out; ++o) yn[o] = ok ? Y[row * d_out + o] : 0.f;
+        } else {
 #pragma unroll
             for (int mt = 0; mt < C::MTL; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[sl][mt][r] = yn[sl][mt][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int u = 16 * mt + 4 * g + r;
+                    yn[4 * mt + r] = (ok && u < d_out) ? Y[row * d_out + u] : 0.f;
+                }
         }
-        tile += 2 * W;
-        fetch(0, tile);
-        fetch(1, tile + W);
-        TileStep<S, 2>::run(dW, stat, lds, wl, i16, g, inv_var, x, y, rv);
-        if (first) { TB_STAMP(2); first = false; }
-    }
-    for (; tile < ntiles; tile += W) {                            // remainder: one tile at a time
-        float x[1][C::KS0], y[1][C::MTL][4];
-        bool rv[1];
-        rv[0] = tile * 16 + i16 < n;
+    };
+    long tile = wg;
+    fetch(tile);
+    bool first = true;
+    for (; tile < ntiles; tile += W) {
+        float x[C::KS0], y[YN];
+        const bool rv = tile * 16 + i16 < n;
 #pragma unroll
-        for (int t = 0; t < C::KS0; ++t) x[0][t] = xn[0][t];
+        for (int t = 0; t < C::KS0; ++t) x[t] = xn[t];
 #pragma unroll
-        for (int mt = 0; mt < C::MTL; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) y[0][mt][r] = yn[0][mt][r];
-        fetch(0, tile + W);
-        TileStep<S, 1>::run(dW, stat, lds, wl, i16, g, inv_var, x, y, rv);
+        for (int k = 0; k < YN; ++k) y[k] = yn[k];
+        fetch(tile + W);
+        TileStep<S>::run(dW, LR, stat, lds, wl, i16, g, inv_var, x, y, rv, A0, B0);
         if (first) { TB_STAMP(2); first = false; }
     }
     TB_STAMP(3);
 
-    // ---- epilogue: every wave stages its dW tiles [wave][tile][reg][lane] (conflict-free b32),
-    // all 256 threads sum the 4 copies in fixed order and write the dense slab; EP_TILES per pass
+    // ---- epilogue: every wave stages its dW tiles [wave][tile][lane] (16 B per lane), wave t%4 sums the
+    // 4 copies of tile t in fixed order and writes the dense slab; EP_TILES per pass
     const double wtot = wave_sum(stat);
     if (lane == 0) red[wave] = wtot;
     float* slab = slabs + (size_t)blockIdx.x * pitch;
 #pragma unroll
     for (int t0 = 0; t0 < C::DW_TILES; t0 += C::EP_TILES) {
         __syncthreads();                   // images (or the previous pass) are dead
-        float* mine = lds + wave * (C::EP_TILES * 256);
+        f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::EP_TILES * 64);
 #pragma unroll
-        for (int t = t0; t < t0 + C::EP_TILES && t < C::DW_TILES; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mine[((t - t0) * 4 + r) * 64 + lane] = dW[t][r];
+        for (int t = t0; t < t0 + C::EP_TILES && t < C::DW_TILES; ++t) mine[(t - t0) * 64 + lane] = dW[t];
         __syncthreads();
         const int cnt = (C::DW_TILES - t0) < C::EP_TILES ? (C::DW_TILES - t0) : C::EP_TILES;
+        TB_STAMP(5);
         SlabOut<S, 0>::run(lds, slab, wave, lane, t0, cnt);
+        TB_STAMP(6);
+    }
+    if constexpr (C::VL) {
+        // dW_L / db_L: every lane stages its per-row-group partials [wave][o][unit][i16]; thread (entry, wave)
+        // sums the 16 lanes with 16-B reads, the 4 waves are combined with two lane shuffles (fixed order)
+        constexpr int Lr = C::NL - 1, inL = C::in(Lr), MTP = LastRegs<S>::MTP, UP = 16 * MTP;
+        static_assert(FAST_WAVES * 2 * (UP + 1) * 16 <= C::LDS_FLOATS, "last-layer staging does not fit");
+        __syncthreads();
+        float* lb = lds;
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) {
+#pragma unroll
+            for (int mt = 0; mt < MTP; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    lb[((wave * d_out + o) * (UP + 1) + 16 * mt + 4 * g + r) * 16 + i16] = LR.acc[o][mt][r];
+            if (g == 0) lb[((wave * d_out + o) * (UP + 1) + UP) * 16 + i16] = LR.accb[o];
+        }
+        __syncthreads();
+        constexpr int NE = d_out * (inL + 1);
+        for (int base = 0; base < NE * FAST_WAVES; base += FAST_THREADS) {
+            const int t = base + tid;
+            const int e = t >> 2, w = t & 3;
+            float v = 0.f;
+            int o = 0, u = 0;
+            if (e < NE) {
+                o = e / (inL + 1); u = e - o * (inL + 1);
+                const f32x4* src = reinterpret_cast<const f32x4*>(lb + ((w * d_out + o) * (UP + 1) + (u < inL ? u : UP)) * 16);
+                const f32x4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+                v = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3])) +
+                    (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));
+            }
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            if (e < NE && w == 0) slab[C::offW(Lr) + (u < inL ? o * inL + u : inL * d_out + o)] = v;
+        }
     }
     if (tid == 0) {
         double t = 0.0;
@@ -533,6 +660,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 using ShapeC2 = Shape<TBNN_ACT_RELU, TBNN_ACT_NONE, false, 5, 50, 50, 50, 1>;      // configs[1], configs[2]
 using ShapeC1 = Shape<TBNN_ACT_RELU, TBNN_ACT_NONE, false, 1, 10, 10, 1>;          // configs[0]
 using ShapeTR = Shape<TBNN_ACT_TANH, TBNN_ACT_NONE, false, 1, 10, 10, 10, 1>;      // Examples/trainRegression.py
+using ShapeT3 = Shape<TBNN_ACT_SIGMOID, TBNN_ACT_NONE, false, 4, 7, 3>;            // test shape: last layer on the MFMA path
 
 template <class S>
 static bool shape_matches(const NetDev& nd) {
@@ -547,6 +675,7 @@ static inline int fast_lookup(const NetDev& nd) {
     if (shape_matches<ShapeC2>(nd)) return 0;
     if (shape_matches<ShapeC1>(nd)) return 1;
     if (shape_matches<ShapeTR>(nd)) return 2;
+    if (shape_matches<ShapeT3>(nd)) return 3;
     return -1;
 }
 static inline const char* fast_name(int id) {
@@ -554,6 +683,7 @@ static inline const char* fast_name(int id) {
         case 0: return "fast<relu;5,50,50,50,1>";
         case 1: return "fast<relu;1,10,10,1>";
         case 2: return "fast<tanh;1,10,10,10,1>";
+        case 3: return "fast<sigmoid;4,7,3>";
         default: return "fast<none>";
     }
 }
@@ -571,6 +701,7 @@ static inline int fast_launch(int id, int grid, hipStream_t st, const NetDev& nd
         case 0: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC2>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
         case 1: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC1>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
         case 2: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeTR>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        case 3: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeT3>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
         default: return -1;
     }
     return 0;
@@ -581,6 +712,7 @@ static inline int fast_image_floats(int id) {
         case 0: return FastCfg<ShapeC2>::STATIC_FLOATS;
         case 1: return FastCfg<ShapeC1>::STATIC_FLOATS;
         case 2: return FastCfg<ShapeTR>::STATIC_FLOATS;
+        case 3: return FastCfg<ShapeT3>::STATIC_FLOATS;
         default: return 0;
     }
 }
@@ -589,6 +721,7 @@ static inline void fast_image_map(int id, int* map) {
         case 0: ImageMap<ShapeC2, 0>::run(map); break;
         case 1: ImageMap<ShapeC1, 0>::run(map); break;
         case 2: ImageMap<ShapeTR, 0>::run(map); break;
+        case 3: ImageMap<ShapeT3, 0>::run(map); break;
         default: break;
     }
 }

@@ -1,0 +1,413 @@
+// k_fwd_bwd_fast2: the shape-specialised fused kernel with TWO waves per SIMD.
+//
+// kernels_fast.hpp keeps all dW accumulators plus the whole layer chain in one
+// wave (~400 registers => one wave per SIMD, every LDS/VALU stall idles the
+// matrix pipe).  Here a workgroup has 8 waves in 4 producer/consumer pairs:
+//   chain wave (wave p)    : forward + likelihood + delta chain of its 16-row
+//                            tiles (MFMA, layers chained in registers); for
+//                            every layer it publishes the transposed images of
+//                            delta_l and a_{l-1} into a 2-slot LDS ring;
+//   dW wave   (wave p + 4) : owns ALL dW accumulators of the pair; consumes the
+//                            ring (32 operand reads + 64 MFMAs per layer).
+// Both roles fit in 256 registers, so two waves share each SIMD's MFMA pipe and
+// one role's LDS/VALU latency is covered by the other's MFMAs.  The ring is a
+// plain bounded buffer on two monotonic LDS counters (LDS services a CU's
+// requests in order; waves of one workgroup are always co-resident); every
+// spin is bounded and poisons the statistic (NaN => the transition is
+// rejected) instead of hanging.
+#pragma once
+#include "kernels_fast.hpp"
+
+#define FAST2_WAVES 8
+#define FAST2_THREADS (FAST2_WAVES * 64)
+#define FAST2_PAIRS 4
+#define FAST2_RING 2
+
+template <class S>
+struct Fast2Cfg : FastCfg<S> {
+    using B = FastCfg<S>;
+    static constexpr int maxPA() { int m = 0; for (int l = 0; l < B::NLM; ++l) m = B::PA(l) > m ? B::PA(l) : m; return m; }
+    static constexpr int PAM = maxPA();
+    static constexpr int SLOT = 16 * B::PD + 16 * PAM;                   // delta image + a_{l-1} image
+    static constexpr int RING_OFF = B::STATIC_FLOATS;
+    static constexpr int MIN2 = RING_OFF + FAST2_PAIRS * FAST2_RING * SLOT;
+    static constexpr int EP2_WANT = B::DW_TILES * FAST2_PAIRS * 256 <= 39936 ? B::DW_TILES : (B::DW_TILES < 16 ? B::DW_TILES : 16);
+    static constexpr int LDS2_FLOATS = MIN2 > EP2_WANT * FAST2_PAIRS * 256 ? MIN2 : EP2_WANT * FAST2_PAIRS * 256;
+    static constexpr int EP2_TILES = LDS2_FLOATS / (FAST2_PAIRS * 256) < B::DW_TILES ? LDS2_FLOATS / (FAST2_PAIRS * 256) : B::DW_TILES;
+};
+
+// SlabOut for the 4 dW waves' staged copies (stride EP2_TILES)
+template <class S, int l>
+struct SlabOut2 {
+    using C = Fast2Cfg<S>;
+    static __device__ __forceinline__ void run(const float* buf, float* __restrict__ slab, int wave, int lane, int t0, int cnt) {
+        constexpr int in = C::in(l), out = C::out(l), MT = C::MT(l), NT = C::NT(l);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int t = C::dwoff(l) + mt * NT + nt - t0;
+                if (t >= 0 && t < cnt && (t & (FAST2_PAIRS - 1)) == wave) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(buf) + t * 64 + lane;
+                    const f32x4 c0 = src[0], c1 = src[C::EP2_TILES * 64], c2 = src[2 * C::EP2_TILES * 64], c3 = src[3 * C::EP2_TILES * 64];
+                    const int col = 16 * nt + (lane & 15), row0 = 16 * mt + 4 * (lane >> 4);
+                    if (col <= in) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (row0 + r < out)
+                                slab[C::offW(l) + (col < in ? (row0 + r) * in + col : in * out + row0 + r)] =
+                                    (c0[r] + c1[r]) + (c2[r] + c3[r]);
+                    }
+                }
+            }
+        if constexpr (l + 1 < C::NLM) SlabOut2<S, l + 1>::run(buf, slab, wave, lane, t0, cnt);
+    }
+};
+
+// bounded spin on a monotonic LDS counter; returns false on time-out
+__device__ unsigned long long g_ring_wait_cycles[2];   // diagnostic: cycles workgroup 0 / pair 0 spent waiting (chain, dW)
+__device__ __forceinline__ bool ring_wait(unsigned* ctr, unsigned need) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 22)) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ void ring_post(unsigned* ctr, unsigned val, int lane) {
+    if (lane == 0) __hip_atomic_store(ctr, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// forward layer l for the chain wave: as FwdLayer, without the image writes
+template <class S, int l>
+struct Fwd2 {
+    using C = FastCfg<S>;
+    static __device__ __forceinline__ void run(TileRegs<S>& T, const float* __restrict__ lds, int i16, int g,
+                                                const f32x4 (&A0)[C::MT(l)], const f32x4 (&B0)[C::MT(l)]) {
+        constexpr int MT = C::MT(l);
+        constexpr int MTN = C::MT(l + 1 < C::NLM ? l + 1 : l);
+        f32x4 acc[MT];
+        f32x4 Anext[MTN], Bnext[MTN];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = B0[mt];
+        if constexpr (l == 0) {
+            if constexpr (l + 1 < C::NLM) FwdLayer<S, l + 1>::preload(Anext, Bnext, lds, i16, g);
+#pragma unroll
+            for (int t = 0; t < C::KS0; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(A0[mt][t], T.x0[t], acc[mt]);
+        } else {
+            constexpr int KG = C::KG(l);
+            const float* wrow = lds + C::woff(l) + i16 * C::LDW(l) + 4 * g;
+            f32x4 An[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) An[mt] = A0[mt];
+#pragma unroll
+            for (int kt = 0; kt < KG; ++kt) {
+                f32x4 A4[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) A4[mt] = An[mt];
+                if (kt + 1 < KG) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        An[mt] = load_ks(wrow + 16 * mt * C::LDW(l) + 16 * (kt + 1), C::ksteps(C::in(l), kt + 1));
+                } else {
+                    if constexpr (l + 1 < C::NLM) FwdLayer<S, l + 1>::preload(Anext, Bnext, lds, i16, g);
+                }
+#pragma unroll
+                for (int s = 0; s < C::ksteps(C::in(l), kt); ++s)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(A4[mt][s], T.a[C::aroff(l - 1) + kt][s], acc[mt]);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = actc_fwd<S::act(l)>(acc[mt][r]);
+            T.a[C::aroff(l) + mt] = v;
+        }
+        if constexpr (l + 1 < C::NLM) Fwd2<S, l + 1>::run(T, lds, i16, g, Anext, Bnext);
+    }
+};
+
+// chain wave, backward: publish (delta_l, a_{l-1}) images for layer l, then the delta chain
+template <class S, int l>
+struct Chain2 {
+    using C = Fast2Cfg<S>;
+    static __device__ __forceinline__ bool run(const TileRegs<S>& T, const float* __restrict__ lds, float* ring, unsigned* prod,
+                                                unsigned* cons, unsigned& j, int lane, int i16, int g, const f32x4 (&dz)[C::MT(l)]) {
+        constexpr int MT = C::MT(l), u1 = C::in(l);
+        // slot j & 1 is free once entries 0..j-2 are consumed
+        const long long w0 = clock64();
+        if (j >= FAST2_RING && !ring_wait(cons, j - (FAST2_RING - 1))) return false;
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_ring_wait_cycles[0] += clock64() - w0;
+        float* dimg = ring + (j % FAST2_RING) * C::SLOT;
+        float* aimg = dimg + 16 * C::PD;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(dimg + i16 * C::PD + 16 * mt + 4 * g) = dz[mt];
+        if constexpr (l == 0) {
+#pragma unroll
+            for (int t = 0; t < C::KS0; ++t) {
+                const int u = 4 * t + g;
+                if (u < u1) aimg[i16 * C::PA(0) + u] = T.x0[t];
+            }
+            if (g == (u1 & 3)) aimg[i16 * C::PA(0) + u1] = 1.f;           // ones column -> db; other pad columns: finite, never stored
+        } else {
+            constexpr int MTP = C::MT(l - 1);
+#pragma unroll
+            for (int m = 0; m < MTP; ++m) {
+                f32x4 v = T.a[C::aroff(l - 1) + m];
+                if constexpr (u1 % 16 != 0) {
+                    if (m == u1 / 16 && g == (u1 % 16) / 4) v[u1 % 4] = 1.f;
+                }
+                *reinterpret_cast<f32x4*>(aimg + i16 * C::PA(l) + 16 * m + 4 * g) = v;
+            }
+            if constexpr (u1 % 16 == 0) {
+                if (g == 0) aimg[i16 * C::PA(l) + u1] = 1.f;
+            }
+        }
+        ++j;
+        ring_post(prod, j, lane);
+        if constexpr (l > 0) {
+            f32x4 dzp[C::MT(l - 1)];
+            BwdOps<S, l>::da(T, lds, i16, g, dz, dzp);
+            return Chain2<S, l - 1>::run(T, lds, ring, prod, cons, j, lane, i16, g, dzp);
+        }
+        return true;
+    }
+};
+
+// dW wave: consume the ring entry of layer l
+template <class S, int l>
+struct Dw2 {
+    using C = Fast2Cfg<S>;
+    static __device__ __forceinline__ bool run(f32x4 (&dW)[C::DW_TILES], const float* ring, unsigned* prod, unsigned* cons,
+                                                unsigned& j, int lane, int i16, int g) {
+        constexpr int MT = C::MT(l), NT = C::NT(l);
+        const long long w0 = clock64();
+        if (!ring_wait(prod, j + 1)) return false;
+        if (blockIdx.x == 0 && threadIdx.x == 256) g_ring_wait_cycles[1] += clock64() - w0;
+        const float* dimg = ring + (j % FAST2_RING) * C::SLOT;
+        const float* aimg = dimg + 16 * C::PD;
+        float Aop[MT][4], Bop[NT][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Bop[nt][s] = aimg[(4 * g + s) * C::PA(l) + 16 * nt + i16];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) Aop[mt][s] = dimg[(4 * g + s) * C::PD + 16 * mt + i16];
+        }
+        ++j;
+        ring_post(cons, j, lane);          // release: the operand reads above have completed
+        BwdOps<S, l>::dw(dW, Aop, Bop);
+        if constexpr (l > 0) return Dw2<S, l - 1>::run(dW, ring, prod, cons, j, lane, i16, g);
+        return true;
+    }
+};
+
+template <class S>
+__global__ __launch_bounds__(FAST2_THREADS, 2) void k_fwd_bwd_fast2(
+    NetDev nd, const float* __restrict__ qimg, const float* __restrict__ eta,
+    const float* __restrict__ X, const float* __restrict__ Y, long n,
+    float* __restrict__ slabs, int pitch, double* __restrict__ pstat, unsigned long long* __restrict__ stamps)
+{
+    using C = Fast2Cfg<S>;
+    static_assert(C::VL, "fast2 is instantiated for shapes whose last layer runs on the VALU");
+    static_assert(C::LDS2_FLOATS * 4 + 256 <= 160 * 1024, "LDS budget");
+#define TB_STAMP(i) do { if (stamps && threadIdx.x == 0 && blockIdx.x == 0) { stamps[i] = wall_clock64(); stamps[8 + i] = clock64(); } } while (0)
+    TB_STAMP(0);
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS2_FLOATS];
+    __shared__ double red[FAST2_PAIRS];
+    __shared__ unsigned ctr[FAST2_PAIRS][2];
+    __shared__ int bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int pair = wave & (FAST2_PAIRS - 1);
+    const bool chain = wave < FAST2_PAIRS;
+
+    {   // prologue: padded weight images -> LDS, every 16-B load in flight before the first store
+        constexpr int N4 = C::STATIC_FLOATS / 4, IT = (N4 + FAST2_THREADS - 1) / FAST2_THREADS;
+        const float4* src = reinterpret_cast<const float4*>(qimg);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        float4 v[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST2_THREADS; v[k] = e < N4 ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST2_THREADS; if (e < N4) dst[e] = v[k]; }
+        for (int e = tid; e < FAST2_PAIRS * FAST2_RING * C::SLOT; e += FAST2_THREADS) lds[C::RING_OFF + e] = 0.f;
+        if (tid < FAST2_PAIRS * 2) (&ctr[0][0])[tid] = 0u;
+        if (tid == 0) bad = 0;
+    }
+    __syncthreads();
+    TB_STAMP(1);
+
+    float* ring = lds + C::RING_OFF + pair * FAST2_RING * C::SLOT;
+    unsigned* prod = &ctr[pair][0];
+    unsigned* cons = &ctr[pair][1];
+    const long ntiles = (n + 15) / 16;
+    const long W = (long)gridDim.x * FAST2_PAIRS;                 // pairs in the grid
+    const long wg = (long)blockIdx.x * FAST2_PAIRS + pair;
+    constexpr int d_in = C::in(0), d_out = C::out(C::NL - 1), L = C::NL - 1, LM = C::NLM - 1;
+    unsigned j = 0;
+    bool ok = true;
+
+    f32x4 dW[C::DW_TILES];
+    LastRegs<S> LR;
+    double stat = 0.0;
+    if (chain) {
+        // ---------------------------------------------------------------- chain wave
+        const float sigma = lik_sigma(nd, eta);
+        const float inv_var = 1.f / (sigma * sigma);
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) {
+            LR.b[o] = lds[C::boff(L) + o];
+            LR.accb[o] = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < LastRegs<S>::MTP; ++mt) {
+                LR.w[o][mt] = *reinterpret_cast<const f32x4*>(lds + C::woff(L) + o * C::LDW(L) + 16 * mt + 4 * g);
+                LR.acc[o][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f32x4 A0[C::MT(0)], B0[C::MT(0)];
+        FwdLayer<S, 0>::preload(A0, B0, lds, i16, g);
+        float xn[C::KS0], yn[d_out];
+        auto fetch = [&](long tile) {
+            const long row = tile * 16 + i16;
+            const bool in_range = tile < ntiles && row < n;
+#pragma unroll
+            for (int t = 0; t < C::KS0; ++t) {
+                const int u = 4 * t + g;
+                xn[t] = (in_range && u < d_in) ? X[row * d_in + u] : 0.f;
+            }
+#pragma unroll
+            for (int o = 0; o < d_out; ++o) yn[o] = in_range ? Y[row * d_out + o] : 0.f;
+        };
+        long tile = wg;
+        fetch(tile);
+        for (; tile < ntiles && ok; tile += W) {
+            TileRegs<S> T;
+            float y[d_out];
+            const bool rvalid = tile * 16 + i16 < n;
+#pragma unroll
+            for (int t = 0; t < C::KS0; ++t) T.x0[t] = xn[t];
+#pragma unroll
+            for (int o = 0; o < d_out; ++o) y[o] = yn[o];
+            fetch(tile + W);
+            Fwd2<S, 0>::run(T, lds, i16, g, A0, B0);
+            // last layer on the VALU (as TileStep, C::VL branch)
+            constexpr int MTP = C::MT(L - 1);
+            float dzl[d_out];
+#pragma unroll
+            for (int o = 0; o < d_out; ++o) {
+                float p = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MTP; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p = fmaf(LR.w[o][mt][r], T.a[C::aroff(L - 1) + mt][r], p);
+                p += __shfl_xor(p, 16, 64);
+                p += __shfl_xor(p, 32, 64);
+                const float fi = actc_fwd<S::LACT>(p + LR.b[o]);
+                dzl[o] = rvalid ? lik_delta<S>(fi, y[o], inv_var, g == 0, stat) : 0.f;
+            }
+            f32x4 dz[C::MT(LM)];
+#pragma unroll
+            for (int mt = 0; mt < MTP; ++mt) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < d_out; ++o)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        LR.acc[o][mt][r] = fmaf(dzl[o], T.a[C::aroff(L - 1) + mt][r], LR.acc[o][mt][r]);
+                        d[r] = fmaf(LR.w[o][mt][r], dzl[o], d[r]);
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz[mt][r] = d[r] * actc_bwd<S::act(L - 1)>(T.a[C::aroff(L - 1) + mt][r]);
+            }
+#pragma unroll
+            for (int o = 0; o < d_out; ++o) LR.accb[o] += dzl[o];
+            ok = Chain2<S, LM>::run(T, lds, ring, prod, cons, j, lane, i16, g, dz);
+        }
+    } else {
+        // ---------------------------------------------------------------- dW wave
+#pragma unroll
+        for (int t = 0; t < C::DW_TILES; ++t) dW[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (long tile = wg; tile < ntiles && ok; tile += W)
+            ok = Dw2<S, LM>::run(dW, ring, prod, cons, j, lane, i16, g);
+    }
+    if (!ok && lane == 0) bad = 1;
+    TB_STAMP(3);
+
+    // ---- epilogue: dW waves stage their tiles [pair][tile][lane] x 16 B; dW wave t%4 sums tile t and writes the slab
+    const double wtot = wave_sum(stat);
+    if (chain && lane == 0) red[pair] = wtot;
+    float* slab = slabs + (size_t)blockIdx.x * pitch;
+#pragma unroll
+    for (int t0 = 0; t0 < C::DW_TILES; t0 += C::EP2_TILES) {
+        __syncthreads();
+        if (!chain) {
+            f32x4* mine = reinterpret_cast<f32x4*>(lds) + pair * (C::EP2_TILES * 64);
+#pragma unroll
+            for (int t = t0; t < t0 + C::EP2_TILES && t < C::DW_TILES; ++t) mine[(t - t0) * 64 + lane] = dW[t];
+        }
+        __syncthreads();
+        const int cnt = (C::DW_TILES - t0) < C::EP2_TILES ? (C::DW_TILES - t0) : C::EP2_TILES;
+        if (!chain) SlabOut2<S, 0>::run(lds, slab, pair, lane, t0, cnt);
+    }
+    {   // last-layer dW/db partials live in the chain waves
+        constexpr int inL = C::in(L), MTP = LastRegs<S>::MTP, UP = 16 * MTP;
+        static_assert(FAST2_PAIRS * 2 * (UP + 1) * 16 <= C::LDS2_FLOATS, "last-layer staging does not fit");
+        __syncthreads();
+        float* lb = lds;
+        if (chain) {
+#pragma unroll
+            for (int o = 0; o < d_out; ++o) {
+#pragma unroll
+                for (int mt = 0; mt < MTP; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        lb[((pair * d_out + o) * (UP + 1) + 16 * mt + 4 * g + r) * 16 + i16] = LR.acc[o][mt][r];
+                if (g == 0) lb[((pair * d_out + o) * (UP + 1) + UP) * 16 + i16] = LR.accb[o];
+            }
+        }
+        __syncthreads();
+        constexpr int NE = d_out * (inL + 1);
+        for (int base = 0; base < NE * FAST2_PAIRS; base += FAST2_THREADS) {
+            const int t = base + tid;
+            const int e = t >> 2, w = t & 3;
+            float v = 0.f;
+            int o = 0, u = 0;
+            if (e < NE) {
+                o = e / (inL + 1); u = e - o * (inL + 1);
+                const f32x4* src = reinterpret_cast<const f32x4*>(lb + ((w * d_out + o) * (UP + 1) + (u < inL ? u : UP)) * 16);
+                const f32x4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+                v = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3])) +
+                    (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));
+            }
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            if (e < NE && w == 0) slab[C::offW(L) + (u < inL ? o * inL + u : inL * d_out + o)] = v;
+        }
+    }
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < FAST2_PAIRS; ++w) t += red[w];
+        pstat[blockIdx.x] = bad ? (double)NAN : t;               // a ring time-out poisons the energy => rejected
+    }
+    TB_STAMP(4);
+#undef TB_STAMP
+}
+
+// v2 launcher for the registry ids of kernels_fast.hpp (VALU-last-layer shapes only)
+static inline bool fast2_available(int id) { return id == 0 || id == 1 || id == 2; }
+static inline int fast2_launch(int id, int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
+                               const float* X, const float* Y, long n, float* slabs, int pitch, double* pstat,
+                               unsigned long long* stamps = nullptr) {
+    switch (id) {
+        case 0: hipLaunchKernelGGL(k_fwd_bwd_fast2<ShapeC2>, dim3(grid), dim3(FAST2_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        case 1: hipLaunchKernelGGL(k_fwd_bwd_fast2<ShapeC1>, dim3(grid), dim3(FAST2_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        case 2: hipLaunchKernelGGL(k_fwd_bwd_fast2<ShapeTR>, dim3(grid), dim3(FAST2_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        default: return -1;
+    }
+    return 0;
+}

@@ -42,8 +42,8 @@ __device__ __forceinline__ float prior_grad(int prior, float loc, float scale, f
 // When imgmap != null the new position is also scattered into the padded
 // weight image (W_l and, for l >= 1, W_l^T: imgmap[j] / imgmap[P+j]) the
 // shape-specialised kernel stages into LDS.
-#define UPD_COLS 16    // float4 columns per block (64 parameters)
-#define UPD_GROUPS 16  // slab groups per block
+#define UPD_COLS 8     // float4 columns per block (32 parameters)
+#define UPD_GROUPS 32  // slab groups per block
 __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     NetDev nd, int mode, float eps, const float* __restrict__ eta,
     const float* __restrict__ slabs, int nslab, int pitch,
@@ -62,15 +62,17 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
             const float4* base = reinterpret_cast<const float4*>(slabs) + c4;
             const int p4 = pitch >> 2;
             int w = ty;
-            for (; w + 3 * UPD_GROUPS < nslab; w += 4 * UPD_GROUPS) {
-                const float4 a = base[(size_t)w * p4];
-                const float4 b = base[(size_t)(w + UPD_GROUPS) * p4];
-                const float4 c = base[(size_t)(w + 2 * UPD_GROUPS) * p4];
-                const float4 d = base[(size_t)(w + 3 * UPD_GROUPS) * p4];
-                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-                s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
-                s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
-                s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+            for (; w + 7 * UPD_GROUPS < nslab; w += 8 * UPD_GROUPS) {          // 8 independent 16-B loads in flight
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(w + k * UPD_GROUPS) * p4];
+#pragma unroll
+                for (int k = 0; k < 8; k += 4) {
+                    s0.x += v[k].x; s0.y += v[k].y; s0.z += v[k].z; s0.w += v[k].w;
+                    s1.x += v[k + 1].x; s1.y += v[k + 1].y; s1.z += v[k + 1].z; s1.w += v[k + 1].w;
+                    s2.x += v[k + 2].x; s2.y += v[k + 2].y; s2.z += v[k + 2].z; s2.w += v[k + 2].w;
+                    s3.x += v[k + 3].x; s3.y += v[k + 3].y; s3.z += v[k + 3].z; s3.w += v[k + 3].w;
+                }
             }
             for (; w < nslab; w += UPD_GROUPS) {
                 const float4 a = base[(size_t)w * p4];

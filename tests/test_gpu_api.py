@@ -36,7 +36,7 @@ def test_train_regression_script_flow(tmp_path, monkeypatch, native):
                   burnin=20, averagingSteps=5)
     rec = net.train(61, 10, FixedGaussianLikelihood(sd=0.1), metricList=[SquaredError(), PercentError()],
                     adjustHypers=True, folderName="TrigRegression", networksPerFile=2, displaySkip=30)
-    assert len(rec) == 61 and "fast<tanh" in net._chain.kernel_name
+    assert len(rec) == 61 and "<tanh" in net._chain.kernel_name
     assert all(np.isfinite(r["main"]["log_accept_ratio"]) or r["main"]["log_accept_ratio"] == -np.inf for r in rec)
     assert np.mean([r["main"]["accept_prob"] for r in rec]) > 0.2
     assert any(r["L"] != 50 or abs(r["eps"] - 1e-3) > 1e-9 for r in rec[10:])       # the adapter moved (eps, L)

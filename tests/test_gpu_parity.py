@@ -70,7 +70,7 @@ def test_logp_grad_generic(native, case):
     check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_GENERIC)
 
 
-FAST_CASES = ["c1", "trainreg", "c2_small", "c2_ragged"]
+FAST_CASES = ["c1", "trainreg", "c2_small", "c2_ragged", "sigmoid_hidden"]
 
 
 @pytest.mark.parametrize("case", FAST_CASES)

@@ -7,6 +7,6 @@ for n in (16, 16384, 114688):
     ch = nat.Chain(layers, likelihood=lik); ch.set_data(X[:n], Y[:n]); ch.set_state(th); ch.set_hypers(eta)
     out=(C.c_uint64*16)()
     nat.lib.tbnn_debug_stamps(ch._h, out)
-    t=np.array(list(out)[:5],dtype=np.float64); d=(t-t[0])*0.01; c=np.array(list(out)[8:13],dtype=np.float64); print("  clock MHz", (c[4]-c[0])/(d[4]+1e-9))
-    print('n',n,'us: prologue',d[1],'first tile end',d[2],'loop end',d[3],'end',d[4])
+    t=np.array(list(out)[:8],dtype=np.float64); d=(t-t[0])*0.01; c=np.array(list(out)[8:13],dtype=np.float64); print("  clock MHz", (c[4]-c[0])/(d[4]+1e-9))
+    print('n',n,'us: prologue',d[1],'first tile end',d[2],'loop end',d[3],'end',d[4], 'ring wait cycles per launch: chain', out[5]/3, 'dW', out[6]/3, 'clk', c[4]-c[0])
     ch.close()
