@@ -56,6 +56,30 @@ __device__ __forceinline__ float actc_bwd(float a) {
     else return 1.f;
 }
 
+// Unit <-> padded-slot map of a layer's unit dimension.  Full 16-unit groups are identity; the last,
+// partial group spreads its units over the lane groups first (unit 16T+e -> slot 16T + 4*(e%4) + e/4),
+// so that group needs only ceil(rem/4) MFMA k-steps (50 units: 13 steps instead of 14).  The dW bias
+// column ("ones" pseudo-unit U) takes the next free slot.
+__host__ __device__ constexpr int slot_of(int U, int u) {
+    const int T = U / 16;
+    if (u < 16 * T) return u;
+    const int e = u - 16 * T;
+    return 16 * T + 4 * (e % 4) + e / 4;
+}
+// -1: padding; U: the ones pseudo-unit (only when with_ones)
+__host__ __device__ constexpr int unit_of(int U, int slot, bool with_ones) {
+    const int T = U / 16, rem = U % 16;
+    if (slot < 16 * T) return slot;
+    const int sl = slot - 16 * T;
+    if (sl >= 16) return -1;
+    const int e = 4 * (sl % 4) + sl / 4;
+    if (e < rem) return 16 * T + e;
+    return (with_ones && e == rem) ? U : -1;
+}
+
+// slot of the ones pseudo-unit (bias column of dW) behind U real units
+__host__ __device__ constexpr int ones_slot(int U) { return 16 * (U / 16) + 4 * ((U % 16) % 4) + (U % 16) / 4; }
+
 template <class S>
 struct FastCfg {
     static constexpr int NL = S::NL;
@@ -70,7 +94,7 @@ struct FastCfg {
     static constexpr int PA(int l) { return 16 * NT(l) + 4; }            // pitch of the image of a_l = input of layer l (== 4 mod 8)
     static constexpr int PD = 16 * maxMT() + 4;                          // pitch of the delta image
     // number of valid k-steps s in group kt of a K dimension of size K (unit = 16kt+4g+s)
-    static constexpr int ksteps(int K, int kt) { int rem = K - 16 * kt; return rem >= 4 ? 4 : (rem < 0 ? 0 : rem); }
+    static constexpr int ksteps(int K, int kt) { int rem = K - 16 * kt; return rem >= 16 ? 4 : (rem <= 0 ? 0 : (rem + 3) / 4); }
     // LDS layout (floats): [W images][bias images][W^T images][per wave: images of a_0..a_{NL-1}, delta image]
     static constexpr int woff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += 16 * MT(m) * LDW(m); return o; }
     static constexpr int W_FLOATS = woff(NL);
@@ -215,7 +239,8 @@ struct FwdLayer {
             for (int mt = 0; mt < MT; ++mt) {
                 f32x4 v = T.a[C::aroff(l) + mt];
                 if constexpr (u1 % 16 != 0) {
-                    if (mt == u1 / 16 && g == (u1 % 16) / 4) v[u1 % 4] = 1.f;
+                    constexpr int osl = ones_slot(u1);
+                    if (mt == osl / 16 && g == (osl % 16) / 4) v[osl % 4] = 1.f;
                 }
                 *reinterpret_cast<f32x4*>(aimg + i16 * C::PA(l + 1) + 16 * mt + 4 * g) = v;
             }
@@ -414,8 +439,8 @@ struct TileStep {
             for (int mt = 0; mt < C::MTL; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int u = 16 * mt + 4 * g + r;
-                    dz[mt][r] = (rvalid && u < d_out) ? lik_delta<S>(T.a[C::aroff(L) + mt][r], y[4 * mt + r], inv_var, true, stat) : 0.f;
+                    const int u = unit_of(d_out, 16 * mt + 4 * g + r, false);
+                    dz[mt][r] = (rvalid && u >= 0) ? lik_delta<S>(T.a[C::aroff(L) + mt][r], y[4 * mt + r], inv_var, true, stat) : 0.f;
                 }
             TSTAMP(9);
         }
@@ -451,13 +476,17 @@ struct SlabOut {
                 if (t >= 0 && t < cnt && (t & (FAST_WAVES - 1)) == wave) {
                     const f32x4* src = reinterpret_cast<const f32x4*>(buf) + t * 64 + lane;
                     const f32x4 c0 = src[0], c1 = src[C::EP_TILES * 64], c2 = src[2 * C::EP_TILES * 64], c3 = src[3 * C::EP_TILES * 64];
-                    const int col = 16 * nt + (lane & 15), row0 = 16 * mt + 4 * (lane >> 4);
-                    if (col <= in) {
+                    const int cs = 16 * nt + (lane & 15), row0 = 16 * mt + 4 * (lane >> 4);
+                    // layer 0's input columns are natural (x), later layers' columns are slots
+                    const int col = l == 0 ? (cs <= in ? cs : -1) : unit_of(in, cs, true);
+                    if (col >= 0) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (row0 + r < out)
-                                slab[C::offW(l) + (col < in ? (row0 + r) * in + col : in * out + row0 + r)] =
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = unit_of(out, row0 + r, false);
+                            if (row >= 0)
+                                slab[C::offW(l) + (col < in ? row * in + col : in * out + row)] =
                                     (c0[r] + c1[r]) + (c2[r] + c3[r]);                   // col == in: bias (ones column)
+                        }
                     }
                 }
             }
@@ -474,10 +503,11 @@ struct ImageMap {
         constexpr int in = C::in(l), out = C::out(l);
         for (int i = 0; i < out; ++i) {
             for (int k = 0; k < in; ++k) {
-                map[C::offW(l) + i * in + k] = C::woff(l) + i * C::LDW(l) + k;
-                map[C::P() + C::offW(l) + i * in + k] = (l >= 1 && l < C::NLM) ? C::toff(l) + k * C::LDT(l) + i : -1;   // W_l^T
+                const int ri = slot_of(out, i), ck = l == 0 ? k : slot_of(in, k);      // layer 0 reads x in natural order
+                map[C::offW(l) + i * in + k] = C::woff(l) + ri * C::LDW(l) + ck;
+                map[C::P() + C::offW(l) + i * in + k] = (l >= 1 && l < C::NLM) ? C::toff(l) + ck * C::LDT(l) + ri : -1;   // W_l^T
             }
-            map[C::offW(l) + in * out + i] = C::boff(l) + i;
+            map[C::offW(l) + in * out + i] = C::boff(l) + slot_of(out, i);
             map[C::P() + C::offW(l) + in * out + i] = -1;
         }
         if constexpr (l + 1 < C::NL) ImageMap<S, l + 1>::run(map);
@@ -547,11 +577,11 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     if constexpr (C::VL) {
 #pragma unroll
         for (int o = 0; o < d_out; ++o) {
-            LR.b[o] = lds[C::boff(C::NL - 1) + o];
+            LR.b[o] = lds[C::boff(C::NL - 1) + slot_of(d_out, o)];
             LR.accb[o] = 0.f;
 #pragma unroll
             for (int mt = 0; mt < LastRegs<S>::MTP; ++mt) {
-                LR.w[o][mt] = *reinterpret_cast<const f32x4*>(lds + C::woff(C::NL - 1) + o * C::LDW(C::NL - 1) + 16 * mt + 4 * g);
+                LR.w[o][mt] = *reinterpret_cast<const f32x4*>(lds + C::woff(C::NL - 1) + slot_of(d_out, o) * C::LDW(C::NL - 1) + 16 * mt + 4 * g);
                 LR.acc[o][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -572,8 +602,8 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             for (int mt = 0; mt < C::MTL; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int u = 16 * mt + 4 * g + r;
-                    yn[4 * mt + r] = (ok && u < d_out) ? Y[row * d_out + u] : 0.f;
+                    const int u = unit_of(d_out, 16 * mt + 4 * g + r, false);
+                    yn[4 * mt + r] = (ok && u >= 0) ? Y[row * d_out + u] : 0.f;
                 }
         }
     };
@@ -635,7 +665,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             int o = 0, u = 0;
             if (e < NE) {
                 o = e / (inL + 1); u = e - o * (inL + 1);
-                const f32x4* src = reinterpret_cast<const f32x4*>(lb + ((w * d_out + o) * (UP + 1) + (u < inL ? u : UP)) * 16);
+                const f32x4* src = reinterpret_cast<const f32x4*>(lb + ((w * d_out + o) * (UP + 1) + (u < inL ? slot_of(inL, u) : UP)) * 16);
                 const f32x4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
                 v = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3])) +
                     (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));

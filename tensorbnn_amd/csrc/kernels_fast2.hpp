@@ -50,13 +50,15 @@ struct SlabOut2 {
                 if (t >= 0 && t < cnt && (t & (FAST2_PAIRS - 1)) == wave) {
                     const f32x4* src = reinterpret_cast<const f32x4*>(buf) + t * 64 + lane;
                     const f32x4 c0 = src[0], c1 = src[C::EP2_TILES * 64], c2 = src[2 * C::EP2_TILES * 64], c3 = src[3 * C::EP2_TILES * 64];
-                    const int col = 16 * nt + (lane & 15), row0 = 16 * mt + 4 * (lane >> 4);
-                    if (col <= in) {
+                    const int cs = 16 * nt + (lane & 15), row0 = 16 * mt + 4 * (lane >> 4);
+                    const int col = l == 0 ? (cs <= in ? cs : -1) : unit_of(in, cs, true);
+                    if (col >= 0) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (row0 + r < out)
-                                slab[C::offW(l) + (col < in ? (row0 + r) * in + col : in * out + row0 + r)] =
-                                    (c0[r] + c1[r]) + (c2[r] + c3[r]);
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = unit_of(out, row0 + r, false);
+                            if (row >= 0)
+                                slab[C::offW(l) + (col < in ? row * in + col : in * out + row)] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
+                        }
                     }
                 }
             }
@@ -159,7 +161,8 @@ struct Chain2 {
             for (int m = 0; m < MTP; ++m) {
                 f32x4 v = T.a[C::aroff(l - 1) + m];
                 if constexpr (u1 % 16 != 0) {
-                    if (m == u1 / 16 && g == (u1 % 16) / 4) v[u1 % 4] = 1.f;
+                    constexpr int osl = ones_slot(u1);
+                    if (m == osl / 16 && g == (osl % 16) / 4) v[osl % 4] = 1.f;
                 }
                 *reinterpret_cast<f32x4*>(aimg + i16 * C::PA(l) + 16 * m + 4 * g) = v;
             }
@@ -261,11 +264,11 @@ __global__ __launch_bounds__(FAST2_THREADS, 2) void k_fwd_bwd_fast2(
         const float inv_var = 1.f / (sigma * sigma);
 #pragma unroll
         for (int o = 0; o < d_out; ++o) {
-            LR.b[o] = lds[C::boff(L) + o];
+            LR.b[o] = lds[C::boff(L) + slot_of(d_out, o)];
             LR.accb[o] = 0.f;
 #pragma unroll
             for (int mt = 0; mt < LastRegs<S>::MTP; ++mt) {
-                LR.w[o][mt] = *reinterpret_cast<const f32x4*>(lds + C::woff(L) + o * C::LDW(L) + 16 * mt + 4 * g);
+                LR.w[o][mt] = *reinterpret_cast<const f32x4*>(lds + C::woff(L) + slot_of(d_out, o) * C::LDW(L) + 16 * mt + 4 * g);
                 LR.acc[o][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(FAST2_THREADS, 2) void k_fwd_bwd_fast2(
             int o = 0, u = 0;
             if (e < NE) {
                 o = e / (inL + 1); u = e - o * (inL + 1);
-                const f32x4* src = reinterpret_cast<const f32x4*>(lb + ((w * d_out + o) * (UP + 1) + (u < inL ? u : UP)) * 16);
+                const f32x4* src = reinterpret_cast<const f32x4*>(lb + ((w * d_out + o) * (UP + 1) + (u < inL ? slot_of(inL, u) : UP)) * 16);
                 const f32x4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
                 v = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3])) +
                     (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));
