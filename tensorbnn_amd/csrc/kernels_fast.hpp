@@ -43,7 +43,8 @@ struct Shape {
 
 template <int ACT>
 __device__ __forceinline__ float actc_fwd(float z) {
-    if constexpr (ACT == TBNN_ACT_RELU) return __builtin_amdgcn_fmed3f(z, 0.f, __builtin_inff());   // one v_med3_f32 (z finite)
+    // relu as ONE integer max on the bit pattern (negative floats are negative ints; no NaN canonicalisation op)
+    if constexpr (ACT == TBNN_ACT_RELU) return __int_as_float(max(__float_as_int(z), 0));
     else if constexpr (ACT == TBNN_ACT_TANH) return tanhf(z);
     else if constexpr (ACT == TBNN_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
     else return z;
@@ -79,6 +80,13 @@ __host__ __device__ constexpr int unit_of(int U, int slot, bool with_ones) {
 
 // slot of the ones pseudo-unit (bias column of dW) behind U real units
 __host__ __device__ constexpr int ones_slot(int U) { return 16 * (U / 16) + 4 * ((U % 16) % 4) + (U % 16) / 4; }
+
+// acc * act'(a) with act' expressed through the activation output a (relu: a select, no multiply)
+template <int ACT>
+__device__ __forceinline__ float actc_bwd_mul(float acc, float a) {
+    if constexpr (ACT == TBNN_ACT_RELU) return __float_as_int(a) > 0 ? acc : 0.f;
+    else return acc * actc_bwd<ACT>(a);
+}
 
 template <class S>
 struct FastCfg {
@@ -314,7 +322,7 @@ struct BwdOps {
 #pragma unroll
             for (int m = 0; m < MTP; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dzp[m][r] = acc[m][r] * actc_bwd<S::act(l - 1)>(T.a[C::aroff(l - 1) + m][r]);
+                for (int r = 0; r < 4; ++r) dzp[m][r] = actc_bwd_mul<S::act(l - 1)>(acc[m][r], T.a[C::aroff(l - 1) + m][r]);
         }
     }
 };
@@ -429,7 +437,7 @@ struct TileStep {
                         d[r] = fmaf(LR.w[o][mt][r], dzl[o], d[r]);
                     }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dz[mt][r] = d[r] * actc_bwd<S::act(L - 1)>(T.a[C::aroff(L - 1) + mt][r]);
+                for (int r = 0; r < 4; ++r) dz[mt][r] = actc_bwd_mul<S::act(L - 1)>(d[r], T.a[C::aroff(L - 1) + mt][r]);
             }
 #pragma unroll
             for (int o = 0; o < d_out; ++o) LR.accb[o] += dzl[o];
@@ -622,6 +630,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         if (first) { TB_STAMP(2); first = false; }
     }
     TB_STAMP(3);
+    if (stamps && blockIdx.x == 0 && lane == 0) stamps[12 + wave] = wall_clock64();
 
     // ---- epilogue: every wave stages its dW tiles [wave][tile][lane] (16 B per lane), wave t%4 sums the
     // 4 copies of tile t in fixed order and writes the dense slab; EP_TILES per pass

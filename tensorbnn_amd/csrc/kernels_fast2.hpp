@@ -325,7 +325,7 @@ __global__ __launch_bounds__(FAST2_THREADS, 2) void k_fwd_bwd_fast2(
                         d[r] = fmaf(LR.w[o][mt][r], dzl[o], d[r]);
                     }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dz[mt][r] = d[r] * actc_bwd<S::act(L - 1)>(T.a[C::aroff(L - 1) + mt][r]);
+                for (int r = 0; r < 4; ++r) dz[mt][r] = actc_bwd_mul<S::act(L - 1)>(d[r], T.a[C::aroff(L - 1) + mt][r]);
             }
 #pragma unroll
             for (int o = 0; o < d_out; ++o) LR.accb[o] += dzl[o];

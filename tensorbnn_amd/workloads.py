@@ -10,13 +10,14 @@ import numpy as np
 
 from . import _native as nat
 
-# fixed leapfrog step size per config (adapter bypassed for timing); chosen so
-# that the mean acceptance probability over the bench's timed epochs lies in
-# [0.6, 0.9] (tests/golden/bench_eps.json records the scan that picked them)
-_BENCH_EPS = {"c2": 2.0e-5, "c1": 2.0e-4, "c4": 5.0e-6, "c5": 1.0e-4}
+# fixed leapfrog step sizes per config (adapter bypassed for timing): (warm-up eps, timed eps).
+# The chain starts far from equilibrium (log-prob -2.7e7), where only eps <= 4e-5 is stable; the
+# warm-up epochs use the safe value, the timed epochs the value that puts the mean acceptance
+# probability in [0.6, 0.9] (scan recorded in tests/golden/bench_eps.json).
+_BENCH_EPS = {"c2": (2.0e-5, 8.0e-5)}
 
 
-def bench_eps(cfg: str) -> float:
+def bench_eps(cfg: str):
     return _BENCH_EPS[cfg]
 
 

@@ -8,5 +8,5 @@ for n in (16, 16384, 114688):
     out=(C.c_uint64*16)()
     nat.lib.tbnn_debug_stamps(ch._h, out)
     t=np.array(list(out)[:8],dtype=np.float64); d=(t-t[0])*0.01; c=np.array(list(out)[8:13],dtype=np.float64); print("  clock MHz", (c[4]-c[0])/(d[4]+1e-9))
-    print('n',n,'us: prologue',d[1],'first tile end',d[2],'loop end',d[3],'end',d[4], 'ring wait cycles per launch: chain', out[5]/3, 'dW', out[6]/3, 'clk', c[4]-c[0])
+    print('n',n,'us: prologue',d[1],'first tile end',d[2],'loop end',d[3],'end',d[4], 'per-wave loop end', [(out[12+w]-out[0])*0.01 for w in range(4)], 'staged', d[5], 'slabout', d[6])
     ch.close()
