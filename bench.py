@@ -64,6 +64,9 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if not os.path.exists(os.path.join(ROOT, "tensorbnn_amd", "libtbnn.so")) and rank == 0:
+        from tensorbnn_amd import build as _b
+        _b.build(verbose=False)
     from tensorbnn_amd import _native as nat
     from tensorbnn_amd.workloads import synth_problem, bench_eps
 

@@ -1,0 +1,577 @@
+// k_fwd_bwd_fast3: k_fwd_bwd_fast with the *fringe* units of every layer on the VALU.
+//
+// On gfx950 the f32 MFMA and the f32 VALU share one ALU (kernels_fast.hpp header), so
+// the cost of the tile body is its MFMA count.  A 50-unit layer fills 3 full 16-unit MFMA tiles
+// plus a 4th tile that carries 2 units: a quarter of the forward / delta-chain MFMAs and 7 of the
+// 16 dW tiles of a layer exist for 2 units.  Here a layer with out % 16 in {1, 2} keeps
+// MTF = out/16 full tiles on the MFMA path and computes its NF fringe units with plain FMAs:
+//   forward   z_u = b_u + sum_k W[u][k] a[k]        each lane sums its own 16 k-slots, the four
+//             lane groups are combined with two lane shuffles; the result (all lanes) is dropped
+//             into register 0 of the fringe tile (lane group f) so that it feeds the next layer's
+//             last k-step exactly like an MFMA result would;
+//   delta     d_u = act'(a_u) sum_i W[i][u] delta[i]   same shape, W^T image;
+//   dW rows   dW[u][k] += d_u a_{l-1}[k]               per-lane partial sums (2 x 16 registers per
+//             layer), reduced once per launch in the epilogue.
+// The last layer (<= 2 outputs) is simply the all-fringe case (MTF = 0).  C2: 270 MFMAs per
+// 16-row tile instead of 360, +~250 VALU ops.
+#pragma once
+#include "kernels_fast.hpp"
+
+template <class S>
+struct F3Cfg : FastCfg<S> {
+    using B = FastCfg<S>;
+    static constexpr int NF(int l) { return (B::out(l) % 16 == 1 || B::out(l) % 16 == 2) ? B::out(l) % 16 : 0; }
+    static constexpr int MTF(int l) { return NF(l) ? B::MT(l) - 1 : B::MT(l); }      // tiles on the MFMA path
+    static constexpr int fslot(int l, int f) { return 16 * MTF(l) + 4 * f; }          // slot of fringe unit f (lane group f, reg 0)
+    static constexpr int funit(int l, int f) { return 16 * MTF(l) + f; }
+    // number of layers whose dW has an MFMA part (a trailing all-fringe layer has none)
+    static constexpr int NLM3 = MTF(B::NL - 1) == 0 ? B::NL - 1 : B::NL;
+    static_assert(NLM3 == B::NLM, "fast3 expects the same MFMA/VALU split of the last layer as fast");
+    static constexpr int dwoff3(int l) { int o = 0; for (int m = 0; m < l && m < NLM3; ++m) o += MTF(m) * B::NT(m); return o; }
+    static constexpr int DW3_TILES = dwoff3(B::NL);
+    // per-lane k-slots of layer l's input: natural x for layer 0, else 4 registers of every tile of a_{l-1}
+    static constexpr int KIN(int l) { return l == 0 ? B::KS0 : 4 * B::MT(l - 1); }
+    static constexpr int fpoff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += NF(m) * (KIN(m) + 1); return o; }
+    static constexpr int FP_REGS = fpoff(B::NL);
+    static constexpr int maxNF() { int m = 0; for (int l = 0; l < B::NL; ++l) m = NF(l) > m ? NF(l) : m; return m; }
+    static constexpr int EP3_WANT = DW3_TILES * FAST_WAVES * 256 <= 39936 ? DW3_TILES : (DW3_TILES < 16 ? DW3_TILES : 16);
+    static constexpr int LDS3_A = B::MIN_LDS > EP3_WANT * FAST_WAVES * 256 ? B::MIN_LDS : EP3_WANT * FAST_WAVES * 256;
+    static constexpr int LDS3_FLOATS = LDS3_A > FAST_WAVES * (FP_REGS > 0 ? FP_REGS : 1) * 64 ? LDS3_A : FAST_WAVES * FP_REGS * 64;
+    static constexpr int EP3_TILES = LDS3_FLOATS / (FAST_WAVES * 256) < DW3_TILES ? LDS3_FLOATS / (FAST_WAVES * 256) : (DW3_TILES > 0 ? DW3_TILES : 1);
+};
+
+template <class S>
+struct Tile3 {
+    using C = F3Cfg<S>;
+    f32x4 a[C::ACT_TILES];                 // outputs of every layer, D layout (fringe tile: reg 0 of lane group f)
+    float af[C::NL][C::maxNF() > 0 ? C::maxNF() : 1];   // fringe activations (all lanes: value of row lane&15)
+    float x0[C::KS0];
+};
+
+__device__ __forceinline__ float gsum(float p) {           // sum over the 4 lane groups (same lane&15)
+    p += __shfl_xor(p, 16, 64);
+    p += __shfl_xor(p, 32, 64);
+    return p;
+}
+
+// sum_k w[k-slot] * v[k-slot] over this lane's k-slots of a K dimension living in D-layout tiles
+template <class S, int K>
+__device__ __forceinline__ float dot_slots(const float* __restrict__ row, const f32x4* tiles, int g) {
+    using C = F3Cfg<S>;
+    float p = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < C::cdiv(K, 16); ++kt) {
+        const f32x4 w = load_ks(row + 16 * kt + 4 * g, C::ksteps(K, kt));
+#pragma unroll
+        for (int s = 0; s < C::ksteps(K, kt); ++s) p = fmaf(w[s], tiles[kt][s], p);
+    }
+    return p;
+}
+
+template <class S, int l>
+struct Fwd3 {
+    using C = F3Cfg<S>;
+    static __device__ __forceinline__ void preload(f32x4 (&An)[C::MTF(l) > 0 ? C::MTF(l) : 1], f32x4 (&Bn)[C::MTF(l) > 0 ? C::MTF(l) : 1],
+                                                    const float* __restrict__ lds, int i16, int g) {
+        constexpr int MT = C::MTF(l);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) Bn[mt] = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * mt + 4 * g);
+        if constexpr (l == 0) {
+            static_assert(C::KS0 <= 4, "layer-0 fan-in above 16 needs the grouped path");
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < C::KS0; ++t) An[mt][t] = lds[C::woff(0) + (16 * mt + i16) * C::LDW(0) + 4 * t + g];
+        } else {
+            const float* wrow = lds + C::woff(l) + i16 * C::LDW(l) + 4 * g;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) An[mt] = load_ks(wrow + 16 * mt * C::LDW(l), C::ksteps(C::in(l), 0));
+        }
+    }
+
+    static __device__ __forceinline__ void run(Tile3<S>& T, const float* __restrict__ lds, float* wl, int i16, int g,
+                                                const f32x4 (&A0)[C::MTF(l) > 0 ? C::MTF(l) : 1],
+                                                const f32x4 (&B0)[C::MTF(l) > 0 ? C::MTF(l) : 1]) {
+        constexpr int MT = C::MTF(l), NF = C::NF(l);
+        constexpr bool more = l + 1 < C::NL;
+        constexpr int MTN = more ? (C::MTF(l + 1) > 0 ? C::MTF(l + 1) : 1) : 1;
+        f32x4 Anext[MTN], Bnext[MTN];
+        // ---- fringe units on the VALU (issued first: their two lane shuffles land under the MFMAs below)
+        float pf[NF > 0 ? NF : 1];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const float* row = lds + C::woff(l) + C::fslot(l, f) * C::LDW(l);
+            float p = 0.f;
+            if constexpr (l == 0) {
+#pragma unroll
+                for (int t = 0; t < C::KS0; ++t) p = fmaf(row[4 * t + g], T.x0[t], p);
+            } else {
+                p = dot_slots<S, C::in(l)>(row, &T.a[C::aroff(l - 1)], g);
+            }
+            pf[f] = p;
+        }
+        // ---- full tiles on the MFMA path
+        if constexpr (MT > 0) {
+            f32x4 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = B0[mt];
+            if constexpr (l == 0) {
+                if constexpr (more && C::MTF(l + 1) > 0) Fwd3<S, l + 1>::preload(Anext, Bnext, lds, i16, g);
+#pragma unroll
+                for (int t = 0; t < C::KS0; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(A0[mt][t], T.x0[t], acc[mt]);
+            } else {
+                constexpr int KG = C::KG(l);
+                const float* wrow = lds + C::woff(l) + i16 * C::LDW(l) + 4 * g;
+                f32x4 An[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) An[mt] = A0[mt];
+#pragma unroll
+                for (int kt = 0; kt < KG; ++kt) {
+                    f32x4 A4[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) A4[mt] = An[mt];
+                    if (kt + 1 < KG) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            An[mt] = load_ks(wrow + 16 * mt * C::LDW(l) + 16 * (kt + 1), C::ksteps(C::in(l), kt + 1));
+                    } else {
+                        if constexpr (more && C::MTF(l + 1) > 0) Fwd3<S, l + 1>::preload(Anext, Bnext, lds, i16, g);
+                    }
+#pragma unroll
+                    for (int s = 0; s < C::ksteps(C::in(l), kt); ++s)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(A4[mt][s], T.a[C::aroff(l - 1) + kt][s], acc[mt]);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = actc_fwd<S::act(l)>(acc[mt][r]);
+                T.a[C::aroff(l) + mt] = v;
+            }
+        }
+        // ---- finish the fringe units: combine the lane groups, bias, activation; drop into the fringe tile
+        if constexpr (NF > 0) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float z = gsum(pf[f]) + lds[C::boff(l) + C::fslot(l, f)];
+                T.af[l][f] = actc_fwd<S::act(l)>(z);
+                if (g == f) v[0] = T.af[l][f];
+            }
+            T.a[C::aroff(l) + MT] = v;
+        }
+        if constexpr (more) {
+            if constexpr (C::MTF(l + 1) > 0) {
+                // transposed image of a_{l+1}'s input (= this layer's output) for the MFMA part of dW_{l+1}
+                constexpr int u1 = C::in(l + 1);
+                float* aimg = wl + C::aoff(l + 1);
+#pragma unroll
+                for (int mt = 0; mt < C::MT(l); ++mt) {
+                    f32x4 v = T.a[C::aroff(l) + mt];
+                    if constexpr (u1 % 16 != 0) {
+                        constexpr int osl = ones_slot(u1);
+                        if (mt == osl / 16 && g == (osl % 16) / 4) v[osl % 4] = 1.f;
+                    }
+                    *reinterpret_cast<f32x4*>(aimg + i16 * C::PA(l + 1) + 16 * mt + 4 * g) = v;
+                }
+            }
+            Fwd3<S, l + 1>::run(T, lds, wl, i16, g, Anext, Bnext);
+        }
+    }
+};
+
+// per-lane partial sums of the fringe rows of dW (and db): FP[fpoff(l) + f*(KIN+1) + k], k == KIN: bias
+template <class S, int l>
+struct FringeDW {
+    using C = F3Cfg<S>;
+    static __device__ __forceinline__ void run(float (&FP)[C::FP_REGS > 0 ? C::FP_REGS : 1], const Tile3<S>& T,
+                                                const float (&dzf)[C::maxNF() > 0 ? C::maxNF() : 1], int g) {
+        constexpr int NF = C::NF(l), KIN = C::KIN(l);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            float* fp = FP + C::fpoff(l) + f * (KIN + 1);
+            if constexpr (l == 0) {
+#pragma unroll
+                for (int t = 0; t < C::KS0; ++t) fp[t] = fmaf(dzf[f], T.x0[t], fp[t]);
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < C::MT(l - 1); ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) fp[4 * kt + r] = fmaf(dzf[f], T.a[C::aroff(l - 1) + kt][r], fp[4 * kt + r]);
+            }
+            fp[KIN] += dzf[f];              // every lane group adds it; the epilogue takes lane group 0
+        }
+    }
+};
+
+// backward of layer l: dz (full tiles, D layout) + dzf (fringe deltas, all lanes) are known.
+template <class S, int l>
+struct Bwd3 {
+    using C = F3Cfg<S>;
+    static constexpr int MT = C::MTF(l), NT = C::NT(l), NF = C::NF(l);
+    static constexpr int MTd = MT > 0 ? MT : 1, NFd = C::maxNF() > 0 ? C::maxNF() : 1;
+
+    // W(D_l) R(op_l): only when the layer has an MFMA dW part
+    static __device__ __forceinline__ void issue(const f32x4 (&dz)[C::MT(l)], float* wl, int i16, int g,
+                                                  float (&Aop)[MTd][4], float (&Bop)[NT][4]) {
+        if constexpr (MT > 0) {
+            float* dimg = wl + C::doff;
+            const float* aimg = wl + C::aoff(l);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(dimg + i16 * C::PD + 16 * mt + 4 * g) = dz[mt];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) Bop[nt][s] = aimg[(4 * g + s) * C::PA(l) + 16 * nt + i16];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) Aop[mt][s] = dimg[(4 * g + s) * C::PD + 16 * mt + i16];
+            }
+        }
+    }
+    static __device__ __forceinline__ void dw(f32x4 (&dW)[C::DW3_TILES > 0 ? C::DW3_TILES : 1], const float (&Aop)[MTd][4],
+                                               const float (&Bop)[NT][4]) {
+        if constexpr (MT > 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        dW[C::dwoff3(l) + mt * NT + nt] = mfma16(Aop[mt][s], Bop[nt][s], dW[C::dwoff3(l) + mt * NT + nt]);
+        }
+    }
+    // delta_{l-1} (full tiles + fringe) from delta_l
+    static __device__ __forceinline__ void da(const Tile3<S>& T, const float* __restrict__ lds, int i16, int g,
+                                               const f32x4 (&dz)[C::MT(l)], const float (&dzf)[NFd],
+                                               f32x4 (&dzp)[C::MT(l > 0 ? l - 1 : 0)], float (&dzpf)[NFd]) {
+        if constexpr (l > 0) {
+            constexpr int MTP = C::MTF(l - 1), NFP = C::NF(l - 1), K = C::out(l);
+            // fringe units of layer l-1 first (their shuffles land under the MFMAs)
+            float pf[NFP > 0 ? NFP : 1];
+            if constexpr (MT > 0) {
+#pragma unroll
+                for (int f = 0; f < NFP; ++f)
+                    pf[f] = dot_slots<S, K>(lds + C::toff(l) + C::fslot(l - 1, f) * C::LDT(l), dz, g);
+            }
+            if constexpr (MT > 0) {
+                constexpr int KG = C::cdiv(K, 16);
+                f32x4 acc[MTP > 0 ? MTP : 1];
+#pragma unroll
+                for (int m = 0; m < MTP; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* trow = lds + C::toff(l) + i16 * C::LDT(l) + 4 * g;
+                f32x4 An[MTP > 0 ? MTP : 1];
+#pragma unroll
+                for (int m = 0; m < MTP; ++m) An[m] = load_ks(trow + 16 * m * C::LDT(l), C::ksteps(K, 0));
+#pragma unroll
+                for (int kt = 0; kt < KG; ++kt) {
+                    f32x4 A4[MTP > 0 ? MTP : 1];
+#pragma unroll
+                    for (int m = 0; m < MTP; ++m) A4[m] = An[m];
+                    if (kt + 1 < KG) {
+#pragma unroll
+                        for (int m = 0; m < MTP; ++m) An[m] = load_ks(trow + 16 * m * C::LDT(l) + 16 * (kt + 1), C::ksteps(K, kt + 1));
+                    }
+#pragma unroll
+                    for (int s = 0; s < C::ksteps(K, kt); ++s)
+#pragma unroll
+                        for (int m = 0; m < MTP; ++m) acc[m] = mfma16(A4[m][s], dz[kt][s], acc[m]);
+                }
+#pragma unroll
+                for (int m = 0; m < MTP; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dzp[m][r] = actc_bwd_mul<S::act(l - 1)>(acc[m][r], T.a[C::aroff(l - 1) + m][r]);
+#pragma unroll
+                for (int f = 0; f < NFP; ++f) dzpf[f] = actc_bwd_mul<S::act(l - 1)>(gsum(pf[f]), T.af[l - 1][f]);
+            } else {
+                // all-fringe layer (the VALU last layer): K = NF fringe deltas, weights W_l[o][slot] read per lane
+#pragma unroll
+                for (int m = 0; m < MTP; ++m) {
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int o = 0; o < NF; ++o) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(lds + C::woff(l) + C::fslot(l, o) * C::LDW(l) + 16 * m + 4 * g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d[r] = fmaf(w[r], dzf[o], d[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dzp[m][r] = actc_bwd_mul<S::act(l - 1)>(d[r], T.a[C::aroff(l - 1) + m][r]);
+                }
+#pragma unroll
+                for (int f = 0; f < NFP; ++f) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int o = 0; o < NF; ++o) d = fmaf(lds[C::woff(l) + C::fslot(l, o) * C::LDW(l) + C::fslot(l - 1, f)], dzf[o], d);
+                    dzpf[f] = actc_bwd_mul<S::act(l - 1)>(d, T.af[l - 1][f]);
+                }
+            }
+            // fringe tile of delta_{l-1} (K operand of the next delta step)
+            if constexpr (NFP > 0) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int f = 0; f < NFP; ++f)
+                    if (g == f) v[0] = dzpf[f];
+                dzp[MTP] = v;
+            }
+        }
+    }
+};
+
+// software pipeline as BwdPipe: W(D_l) R(op_l) | dW_{l+1} (MFMA) | dA_l | fringe dW_l | recurse
+template <class S, int l>
+struct Pipe3 {
+    using C = F3Cfg<S>;
+    static constexpr int NFd = C::maxNF() > 0 ? C::maxNF() : 1;
+    static __device__ __forceinline__ void run(f32x4 (&dW)[C::DW3_TILES > 0 ? C::DW3_TILES : 1], float (&FP)[C::FP_REGS > 0 ? C::FP_REGS : 1],
+                                                const Tile3<S>& T, const float* __restrict__ lds, float* wl, int i16, int g,
+                                                const f32x4 (&dz)[C::MT(l)], const float (&dzf)[NFd],
+                                                const float (&Aup)[Bwd3<S, l + 1>::MTd][4], const float (&Bup)[C::NT(l + 1)][4]) {
+        float Aop[Bwd3<S, l>::MTd][4], Bop[C::NT(l)][4];
+        Bwd3<S, l>::issue(dz, wl, i16, g, Aop, Bop);
+        SCHED_FENCE();
+        Bwd3<S, l + 1>::dw(dW, Aup, Bup);
+        SCHED_FENCE();
+        FringeDW<S, l>::run(FP, T, dzf, g);
+        if constexpr (l > 0) {
+            f32x4 dzp[C::MT(l - 1)];
+            float dzpf[NFd];
+            Bwd3<S, l>::da(T, lds, i16, g, dz, dzf, dzp, dzpf);
+            SCHED_FENCE();
+            Pipe3<S, l - 1>::run(dW, FP, T, lds, wl, i16, g, dzp, dzpf, Aop, Bop);
+        } else {
+            Bwd3<S, 0>::dw(dW, Aop, Bop);
+        }
+    }
+};
+
+// slab write-out of the MFMA dW tiles (rows = full tiles only)
+template <class S, int l>
+struct SlabOut3 {
+    using C = F3Cfg<S>;
+    static __device__ __forceinline__ void run(const float* buf, float* __restrict__ slab, int wave, int lane, int t0, int cnt) {
+        constexpr int in = C::in(l), out = C::out(l), MT = C::MTF(l), NT = C::NT(l);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int t = C::dwoff3(l) + mt * NT + nt - t0;
+                if (t >= 0 && t < cnt && (t & (FAST_WAVES - 1)) == wave) {
+                    const f32x4* src = reinterpret_cast<const f32x4*>(buf) + t * 64 + lane;
+                    const f32x4 c0 = src[0], c1 = src[C::EP3_TILES * 64], c2 = src[2 * C::EP3_TILES * 64], c3 = src[3 * C::EP3_TILES * 64];
+                    const int cs = 16 * nt + (lane & 15), row0 = 16 * mt + 4 * (lane >> 4);
+                    const int col = l == 0 ? (cs <= in ? cs : -1) : unit_of(in, cs, true);
+                    if (col >= 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = unit_of(out, row0 + r, false);
+                            if (row >= 0)
+                                slab[C::offW(l) + (col < in ? row * in + col : in * out + row)] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
+                        }
+                    }
+                }
+            }
+        if constexpr (l + 1 < C::NLM3) SlabOut3<S, l + 1>::run(buf, slab, wave, lane, t0, cnt);
+    }
+};
+
+// fringe partials -> slab: staged [wave][reg][i16] (lane group g selects which k-slots the register means)
+template <class S, int l>
+struct FringeOut {
+    using C = F3Cfg<S>;
+    // thread (item = (f, kslot, g), wave): item count per layer = NF * (KIN+1) * 4 lane groups
+    static __device__ __forceinline__ void run(const float* lb, float* __restrict__ slab, int tid) {
+        constexpr int NF = C::NF(l), KIN = C::KIN(l), in = C::in(l), out = C::out(l);
+        constexpr int NI = NF * (KIN + 1) * 4;
+        if constexpr (NF > 0) {
+            for (int base = 0; base < NI * FAST_WAVES; base += FAST_THREADS) {
+                const int t = base + tid;
+                const int it = t >> 2, w = t & 3;
+                float v = 0.f;
+                int dest = -1;
+                if (it < NI) {
+                    const int gg = it & 3, fk = it >> 2;
+                    const int f = fk / (KIN + 1), k = fk - f * (KIN + 1);
+                    const int reg = C::fpoff(l) + f * (KIN + 1) + k;
+                    const f32x4* src = reinterpret_cast<const f32x4*>(lb + ((size_t)(w * C::FP_REGS + reg) * 4 + gg) * 16);
+                    const f32x4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+                    v = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3])) +
+                        (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));
+                    const int u = C::funit(l, f);
+                    if (k == KIN) { if (gg == 0) dest = C::offW(l) + in * out + u; }
+                    else {
+                        // k-slot -> input unit: layer 0: x unit 4k+g; else slot 16*(k/4) + 4g + k%4
+                        const int col = l == 0 ? (4 * k + gg < in ? 4 * k + gg : -1) : unit_of(in, 16 * (k >> 2) + 4 * gg + (k & 3), false);
+                        if (col >= 0) dest = C::offW(l) + u * in + col;
+                    }
+                }
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                if (dest >= 0 && w == 0) slab[dest] = v;
+            }
+        }
+        if constexpr (l + 1 < C::NL) FringeOut<S, l + 1>::run(lb, slab, tid);
+    }
+};
+
+template <class S>
+__global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_fwd_bwd_fast3(
+    NetDev nd, const float* __restrict__ qimg, const float* __restrict__ eta,
+    const float* __restrict__ X, const float* __restrict__ Y, long n,
+    float* __restrict__ slabs, int pitch, double* __restrict__ pstat, unsigned long long* __restrict__ stamps)
+{
+    using C = F3Cfg<S>;
+    static_assert(C::VL && C::NF(C::NL - 1) == C::out(C::NL - 1) && C::MTF(C::NL - 1) == 0, "fast3: last layer must be all-fringe");
+    static_assert(C::LDS3_FLOATS * 4 + 64 <= 160 * 1024, "LDS budget");
+    static_assert((size_t)FAST_WAVES * C::FP_REGS * 64 <= (size_t)C::LDS3_FLOATS, "fringe staging does not fit");
+#define TB_STAMP(i) do { if (stamps && threadIdx.x == 0 && blockIdx.x == 0) { stamps[i] = wall_clock64(); stamps[8 + i] = clock64(); } } while (0)
+    TB_STAMP(0);
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS3_FLOATS];
+    __shared__ double red[FAST_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    {
+        constexpr int N4 = C::STATIC_FLOATS / 4, IT = (N4 + FAST_THREADS - 1) / FAST_THREADS;
+        const float4* src = reinterpret_cast<const float4*>(qimg);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        float4 v[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; v[k] = e < N4 ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
+    }
+    float* wl = lds + C::STATIC_FLOATS + wave * C::WAVE_FLOATS;
+    {
+        float4* z = reinterpret_cast<float4*>(wl);
+        for (int e = lane; e < C::WAVE_FLOATS / 4; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    TB_STAMP(1);
+
+    constexpr int d_in = C::in(0), d_out = C::out(C::NL - 1), L = C::NL - 1;
+    constexpr int NFd = C::maxNF() > 0 ? C::maxNF() : 1;
+    f32x4 dW[C::DW3_TILES > 0 ? C::DW3_TILES : 1];
+#pragma unroll
+    for (int t = 0; t < C::DW3_TILES; ++t) dW[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float FP[C::FP_REGS > 0 ? C::FP_REGS : 1];
+#pragma unroll
+    for (int t = 0; t < C::FP_REGS; ++t) FP[t] = 0.f;
+    const float sigma = lik_sigma(nd, eta);
+    const float inv_var = 1.f / (sigma * sigma);
+    double stat = 0.0;
+    const long ntiles = (n + 15) / 16;
+    const long W = (long)gridDim.x * FAST_WAVES;
+    const long wg = (long)blockIdx.x * FAST_WAVES + wave;
+
+    if (g == 0) wl[C::aoff(0) + i16 * C::PA(0) + d_in] = 1.f;
+#pragma unroll
+    for (int l = 1; l < C::NLM3; ++l)
+        if (C::in(l) % 16 == 0 && g == 0) wl[C::aoff(l) + i16 * C::PA(l) + C::in(l)] = 1.f;
+    f32x4 A0[C::MTF(0) > 0 ? C::MTF(0) : 1], B0[C::MTF(0) > 0 ? C::MTF(0) : 1];
+    Fwd3<S, 0>::preload(A0, B0, lds, i16, g);
+
+    float xn[C::KS0], yn[d_out];
+    auto fetch = [&](long tile) {
+        const long row = tile * 16 + i16;
+        const bool ok = tile < ntiles && row < n;
+#pragma unroll
+        for (int t = 0; t < C::KS0; ++t) {
+            const int u = 4 * t + g;
+            xn[t] = (ok && u < d_in) ? X[row * d_in + u] : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) yn[o] = ok ? Y[row * d_out + o] : 0.f;
+    };
+    long tile = wg;
+    fetch(tile);
+    bool first = true;
+    for (; tile < ntiles; tile += W) {
+        Tile3<S> T;
+        float y[d_out];
+        const bool rvalid = tile * 16 + i16 < n;
+#pragma unroll
+        for (int t = 0; t < C::KS0; ++t) {
+            T.x0[t] = xn[t];
+            const int u = 4 * t + g;
+            if (u < d_in) wl[C::aoff(0) + i16 * C::PA(0) + u] = xn[t];
+        }
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) y[o] = yn[o];
+        fetch(tile + W);
+        Fwd3<S, 0>::run(T, lds, wl, i16, g, A0, B0);
+        // likelihood on the all-fringe last layer
+        float dzf[NFd];
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) dzf[o] = rvalid ? lik_delta<S>(T.af[L][o], y[o], inv_var, g == 0, stat) : 0.f;
+        FringeDW<S, L>::run(FP, T, dzf, g);
+        // delta of layer L-1, then the pipeline
+        f32x4 dzL[C::MT(L)];
+        f32x4 dzp[C::MT(L - 1)];
+        float dzpf[NFd];
+        Bwd3<S, L>::da(T, lds, i16, g, dzL, dzf, dzp, dzpf);
+        {
+            constexpr int LM = L - 1;
+            float Aop[Bwd3<S, LM>::MTd][4], Bop[C::NT(LM)][4];
+            Bwd3<S, LM>::issue(dzp, wl, i16, g, Aop, Bop);
+            FringeDW<S, LM>::run(FP, T, dzpf, g);
+            if constexpr (LM > 0) {
+                f32x4 dzq[C::MT(LM - 1)];
+                float dzqf[NFd];
+                Bwd3<S, LM>::da(T, lds, i16, g, dzp, dzpf, dzq, dzqf);
+                SCHED_FENCE();
+                Pipe3<S, LM - 1>::run(dW, FP, T, lds, wl, i16, g, dzq, dzqf, Aop, Bop);
+            } else {
+                Bwd3<S, 0>::dw(dW, Aop, Bop);
+            }
+        }
+        if (first) { TB_STAMP(2); first = false; }
+    }
+    TB_STAMP(3);
+
+    // ---- epilogue
+    const double wtot = wave_sum(stat);
+    if (lane == 0) red[wave] = wtot;
+    float* slab = slabs + (size_t)blockIdx.x * pitch;
+    if constexpr (C::DW3_TILES > 0) {
+#pragma unroll
+        for (int t0 = 0; t0 < C::DW3_TILES; t0 += C::EP3_TILES) {
+            __syncthreads();
+            f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::EP3_TILES * 64);
+#pragma unroll
+            for (int t = t0; t < t0 + C::EP3_TILES && t < C::DW3_TILES; ++t) mine[(t - t0) * 64 + lane] = dW[t];
+            __syncthreads();
+            const int cnt = (C::DW3_TILES - t0) < C::EP3_TILES ? (C::DW3_TILES - t0) : C::EP3_TILES;
+            SlabOut3<S, 0>::run(lds, slab, wave, lane, t0, cnt);
+        }
+    }
+    {   // fringe partials: [wave][reg][g][i16]
+        __syncthreads();
+        float* lb = lds;
+#pragma unroll
+        for (int r = 0; r < C::FP_REGS; ++r) lb[((size_t)(wave * C::FP_REGS + r) * 4 + g) * 16 + i16] = FP[r];
+        __syncthreads();
+        FringeOut<S, 0>::run(lb, slab, tid);
+    }
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < FAST_WAVES; ++w) t += red[w];
+        pstat[blockIdx.x] = t;
+    }
+    TB_STAMP(4);
+#undef TB_STAMP
+}
+
+static inline bool fast3_available(int id) { return id == 0 || id == 1 || id == 2; }
+static inline int fast3_launch(int id, int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
+                               const float* X, const float* Y, long n, float* slabs, int pitch, double* pstat,
+                               unsigned long long* stamps = nullptr) {
+    switch (id) {
+        case 0: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeC2>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        case 1: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeC1>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        case 2: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeTR>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        default: return -1;
+    }
+    return 0;
+}

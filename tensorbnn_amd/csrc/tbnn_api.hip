@@ -16,6 +16,7 @@
 #include "kernels_hyper.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_fast2.hpp"
+#include "kernels_fast3.hpp"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -36,7 +37,7 @@ struct tbnn_ctx {
     uint32_t key0 = 0, key1 = 0, epoch = 0;
     int kernel = TBNN_KERNEL_GENERIC;     // resolved variant
     int fast_id = -1;
-    bool fast_v2 = false;                 // two-waves-per-SIMD variant (kernels_fast2.hpp)
+    int fast_ver = 1;                     // 1: kernels_fast.hpp, 2: two waves per SIMD (experimental), 3: fringe units on the VALU
     std::string kernel_name;
     // data
     float* dX = nullptr; float* dY = nullptr; bool own_data = false; long n = 0;
@@ -179,8 +180,14 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
     if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && fid >= 0) {
         h->kernel = TBNN_KERNEL_FAST; h->fast_id = fid; h->kernel_name = fast_name(fid);
         // experimental two-waves-per-SIMD variant (kernels_fast2.hpp): measured equal to v1, off by default
-        { const char* v2 = getenv("TBNN_FAST_V2"); h->fast_v2 = fast2_available(fid) && v2 && atoi(v2); }
-        if (h->fast_v2) h->kernel_name = std::string("fast2") + (h->kernel_name.c_str() + 4);
+        {   // TBNN_FAST_VER=1|2|3 selects the variant (default: 3 where available)
+            const char* ve = getenv("TBNN_FAST_VER");
+            int want = ve ? atoi(ve) : 3;
+            if (want == 3 && !fast3_available(fid)) want = 1;
+            if (want == 2 && !fast2_available(fid)) want = 1;
+            h->fast_ver = (want >= 1 && want <= 3) ? want : 1;
+        }
+        if (h->fast_ver != 1) h->kernel_name = std::string("fast") + char('0' + h->fast_ver) + (h->kernel_name.c_str() + 4);
         h->img_floats = fast_image_floats(fid);
         std::vector<int> map(2 * (size_t)nd.P);
         fast_image_map(fid, map.data());
@@ -306,8 +313,9 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
         hipEventRecord(a, h->stream);
     }
     if (h->kernel == TBNN_KERNEL_FAST) {
-        int rc = h->fast_v2 ? fast2_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat)
-                            : fast_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat);
+        int rc = h->fast_ver == 3 ? fast3_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat)
+               : h->fast_ver == 2 ? fast2_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat)
+                                  : fast_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat);
         if (rc) return fail(-2, "fast kernel launch failed");
     } else {
         hipLaunchKernelGGL(k_fwd_bwd_generic, dim3(h->grid), dim3(GEN_RB), 0, h->stream, h->nd, q, eta, h->dX,
@@ -592,12 +600,13 @@ extern "C" int tbnn_debug_stamps(tbnn_handle h, uint64_t* out5) {
     { unsigned long long z[2] = {0, 0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_ring_wait_cycles), z, sizeof(z))); }
     hipLaunchKernelGGL(k_make_image, dim3((h->nd.P + 255) / 256), dim3(256), 0, h->stream, h->nd.P, h->q_cur, h->imgmap, h->qimg_cur);
     for (int rep = 0; rep < 3; ++rep) {
-        if (h->fast_v2) fast2_launch(h->fast_id, h->grid, h->stream, h->nd, h->qimg_cur, h->eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, d);
+        if (h->fast_ver == 3) fast3_launch(h->fast_id, h->grid, h->stream, h->nd, h->qimg_cur, h->eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, d);
+        else if (h->fast_ver == 2) fast2_launch(h->fast_id, h->grid, h->stream, h->nd, h->qimg_cur, h->eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, d);
         else fast_launch(h->fast_id, h->grid, h->stream, h->nd, h->qimg_cur, h->eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, d);
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out5, d, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (h->fast_v2) HIPCHK(hipMemcpyFromSymbol(out5 + 5, HIP_SYMBOL(g_ring_wait_cycles), 2 * sizeof(uint64_t)));
+    if (h->fast_ver == 2) HIPCHK(hipMemcpyFromSymbol(out5 + 5, HIP_SYMBOL(g_ring_wait_cycles), 2 * sizeof(uint64_t)));
     hipFree(d);
     return 0;
 }

@@ -11,6 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the C-ABI library is built in-tree (hipcc cross-compiles gfx950 without a GPU); build it if absent/stale
+    try:
+        from tensorbnn_amd import build as _b
+        _b.build(force=False, verbose=False)
+    except Exception as e:          # the tests that need it will fail loudly
+        print("libtbnn build failed:", e)
 
 
 def _has_gpu():
