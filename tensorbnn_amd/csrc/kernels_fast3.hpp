@@ -48,10 +48,15 @@ struct Tile3 {
     float x0[C::KS0];
 };
 
-__device__ __forceinline__ float gsum(float p) {           // sum over the 4 lane groups (same lane&15)
-    p += __shfl_xor(p, 16, 64);
-    p += __shfl_xor(p, 32, 64);
-    return p;
+// sum over the 4 lane groups (same lane&15) with the gfx950 row-swap instructions: VALU only, no
+// LDS round trip (ds_bpermute would put ~2 x 100 cycles of latency on the layer chain)
+__device__ __forceinline__ float gsum(float p) {
+    const unsigned a = __float_as_uint(p);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);   // lanes l and l^32
+    const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const unsigned b = __float_as_uint(s);
+    const auto q = __builtin_amdgcn_permlane16_swap(b, b, false, false);   // rows r and r^1
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
 // sum_k w[k-slot] * v[k-slot] over this lane's k-slots of a K dimension living in D-layout tiles
