@@ -35,7 +35,15 @@ struct F3Cfg : FastCfg<S> {
     static constexpr int FP_REGS = fpoff(B::NL);
     static constexpr int maxNF() { int m = 0; for (int l = 0; l < B::NL; ++l) m = NF(l) > m ? NF(l) : m; return m; }
     static constexpr int EP3_WANT = DW3_TILES * FAST_WAVES * 256 <= 39936 ? DW3_TILES : (DW3_TILES < 16 ? DW3_TILES : 16);
-    static constexpr int LDS3_A = B::MIN_LDS > EP3_WANT * FAST_WAVES * 256 ? B::MIN_LDS : EP3_WANT * FAST_WAVES * 256;
+    // transposed images, column-major: [input slot][row], pitch PR floats.  A lane's 4 operand rows (4g..4g+3)
+    // are then one 16-B read (a single wave gets poor ds_read_b32 throughput); the D-layout writes become
+    // bank-conflict-free b32 pairs.
+    static constexpr int PR = 20;
+    static constexpr int aoff3(int l) { int o = 0; for (int m = 0; m < l && m < NLM3; ++m) o += 16 * B::NT(m) * PR; return o; }
+    static constexpr int doff3 = aoff3(NLM3);
+    static constexpr int WAVE3_FLOATS = doff3 + 16 * B::maxMT() * PR;
+    static constexpr int MIN3 = B::STATIC_FLOATS + FAST_WAVES * WAVE3_FLOATS;
+    static constexpr int LDS3_A = MIN3 > EP3_WANT * FAST_WAVES * 256 ? MIN3 : EP3_WANT * FAST_WAVES * 256;
     static constexpr int LDS3_FLOATS = LDS3_A > FAST_WAVES * (FP_REGS > 0 ? FP_REGS : 1) * 64 ? LDS3_A : FAST_WAVES * FP_REGS * 64;
     static constexpr int EP3_TILES = LDS3_FLOATS / (FAST_WAVES * 256) < DW3_TILES ? LDS3_FLOATS / (FAST_WAVES * 256) : (DW3_TILES > 0 ? DW3_TILES : 1);
 };
@@ -173,7 +181,7 @@ struct Fwd3 {
             if constexpr (C::MTF(l + 1) > 0) {
                 // transposed image of a_{l+1}'s input (= this layer's output) for the MFMA part of dW_{l+1}
                 constexpr int u1 = C::in(l + 1);
-                float* aimg = wl + C::aoff(l + 1);
+                float* aimg = wl + C::aoff3(l + 1);
 #pragma unroll
                 for (int mt = 0; mt < C::MT(l); ++mt) {
                     f32x4 v = T.a[C::aroff(l) + mt];
@@ -181,11 +189,13 @@ struct Fwd3 {
                         constexpr int osl = ones_slot(u1);
                         if (mt == osl / 16 && g == (osl % 16) / 4) v[osl % 4] = 1.f;
                     }
-                    *reinterpret_cast<f32x4*>(aimg + i16 * C::PA(l + 1) + 16 * mt + 4 * g) = v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) aimg[(16 * mt + 4 * g + r) * C::PR + i16] = v[r];
                 }
             }
+            TSTAMP(1 + l);
             Fwd3<S, l + 1>::run(T, lds, wl, i16, g, Anext, Bnext);
-        }
+        } else { TSTAMP(1 + l); }
     }
 };
 
@@ -224,16 +234,23 @@ struct Bwd3 {
     static __device__ __forceinline__ void issue(const f32x4 (&dz)[C::MT(l)], float* wl, int i16, int g,
                                                   float (&Aop)[MTd][4], float (&Bop)[NT][4]) {
         if constexpr (MT > 0) {
-            float* dimg = wl + C::doff;
-            const float* aimg = wl + C::aoff(l);
+            float* dimg = wl + C::doff3;
+            const float* aimg = wl + C::aoff3(l);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(dimg + i16 * C::PD + 16 * mt + 4 * g) = dz[mt];
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+                for (int r = 0; r < 4; ++r) dimg[(16 * mt + 4 * g + r) * C::PR + i16] = dz[mt][r];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) Bop[nt][s] = aimg[(4 * g + s) * C::PA(l) + 16 * nt + i16];
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(aimg + (16 * nt + i16) * C::PR + 4 * g);   // rows 4g..4g+3
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) Aop[mt][s] = dimg[(4 * g + s) * C::PD + 16 * mt + i16];
+                for (int s = 0; s < 4; ++s) Bop[nt][s] = b[s];
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(dimg + (16 * mt + i16) * C::PR + 4 * g);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Aop[mt][s] = a[s];
             }
         }
     }
@@ -337,17 +354,22 @@ struct Pipe3 {
         float Aop[Bwd3<S, l>::MTd][4], Bop[C::NT(l)][4];
         Bwd3<S, l>::issue(dz, wl, i16, g, Aop, Bop);
         SCHED_FENCE();
+        TSTAMP(10 + 4 * l);
         Bwd3<S, l + 1>::dw(dW, Aup, Bup);
         SCHED_FENCE();
+        TSTAMP(11 + 4 * l);
         FringeDW<S, l>::run(FP, T, dzf, g);
+        TSTAMP(12 + 4 * l);
         if constexpr (l > 0) {
             f32x4 dzp[C::MT(l - 1)];
             float dzpf[NFd];
             Bwd3<S, l>::da(T, lds, i16, g, dz, dzf, dzp, dzpf);
             SCHED_FENCE();
+            TSTAMP(13 + 4 * l);
             Pipe3<S, l - 1>::run(dW, FP, T, lds, wl, i16, g, dzp, dzpf, Aop, Bop);
         } else {
             Bwd3<S, 0>::dw(dW, Aop, Bop);
+            TSTAMP(13);
         }
     }
 };
@@ -447,10 +469,10 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
     }
-    float* wl = lds + C::STATIC_FLOATS + wave * C::WAVE_FLOATS;
+    float* wl = lds + C::STATIC_FLOATS + wave * C::WAVE3_FLOATS;
     {
         float4* z = reinterpret_cast<float4*>(wl);
-        for (int e = lane; e < C::WAVE_FLOATS / 4; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = lane; e < C::WAVE3_FLOATS / 4; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     TB_STAMP(1);
@@ -470,10 +492,10 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     const long W = (long)gridDim.x * FAST_WAVES;
     const long wg = (long)blockIdx.x * FAST_WAVES + wave;
 
-    if (g == 0) wl[C::aoff(0) + i16 * C::PA(0) + d_in] = 1.f;
+    if (g == 0) wl[C::aoff3(0) + d_in * C::PR + i16] = 1.f;
 #pragma unroll
     for (int l = 1; l < C::NLM3; ++l)
-        if (C::in(l) % 16 == 0 && g == 0) wl[C::aoff(l) + i16 * C::PA(l) + C::in(l)] = 1.f;
+        if (C::in(l) % 16 == 0 && g == 0) wl[C::aoff3(l) + C::in(l) * C::PR + i16] = 1.f;
     f32x4 A0[C::MTF(0) > 0 ? C::MTF(0) : 1], B0[C::MTF(0) > 0 ? C::MTF(0) : 1];
     Fwd3<S, 0>::preload(A0, B0, lds, i16, g);
 
@@ -500,32 +522,38 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         for (int t = 0; t < C::KS0; ++t) {
             T.x0[t] = xn[t];
             const int u = 4 * t + g;
-            if (u < d_in) wl[C::aoff(0) + i16 * C::PA(0) + u] = xn[t];
+            if (u < d_in) wl[C::aoff3(0) + u * C::PR + i16] = xn[t];
         }
 #pragma unroll
         for (int o = 0; o < d_out; ++o) y[o] = yn[o];
         fetch(tile + W);
+        TSTAMP(0);
         Fwd3<S, 0>::run(T, lds, wl, i16, g, A0, B0);
         // likelihood on the all-fringe last layer
         float dzf[NFd];
 #pragma unroll
         for (int o = 0; o < d_out; ++o) dzf[o] = rvalid ? lik_delta<S>(T.af[L][o], y[o], inv_var, g == 0, stat) : 0.f;
+        TSTAMP(30);
         FringeDW<S, L>::run(FP, T, dzf, g);
         // delta of layer L-1, then the pipeline
         f32x4 dzL[C::MT(L)];
         f32x4 dzp[C::MT(L - 1)];
         float dzpf[NFd];
         Bwd3<S, L>::da(T, lds, i16, g, dzL, dzf, dzp, dzpf);
+        TSTAMP(31);
         {
             constexpr int LM = L - 1;
             float Aop[Bwd3<S, LM>::MTd][4], Bop[C::NT(LM)][4];
             Bwd3<S, LM>::issue(dzp, wl, i16, g, Aop, Bop);
+            TSTAMP(32);
             FringeDW<S, LM>::run(FP, T, dzpf, g);
+            TSTAMP(33);
             if constexpr (LM > 0) {
                 f32x4 dzq[C::MT(LM - 1)];
                 float dzqf[NFd];
                 Bwd3<S, LM>::da(T, lds, i16, g, dzp, dzpf, dzq, dzqf);
                 SCHED_FENCE();
+                TSTAMP(34);
                 Pipe3<S, LM - 1>::run(dW, FP, T, lds, wl, i16, g, dzq, dzqf, Aop, Bop);
             } else {
                 Bwd3<S, 0>::dw(dW, Aop, Bop);

@@ -13,10 +13,10 @@ out=(C.c_uint64*64)()
 dbg.tbnn_debug_tile_stamps.argtypes=[C.c_void_p, C.POINTER(C.c_uint64)]
 dbg.tbnn_debug_tile_stamps(ch._h, out)
 t=np.array(list(out),dtype=np.float64)
-seq=[(0,'start',0),(1,'fwd L0',8),(2,'fwd L1',56),(3,'fwd L2',56),(4,'fwd L3',14),(9,'lik',0),(19,'iss3',0),(21,'dA3',4),
-     (16,'iss2',0),(17,'dW3',16),(18,'dA2',56),(13,'iss1',0),(14,'dW2',64),(15,'dA1',56),(10,'iss0',0),(11,'dW1',64),(12,'dW0',16)]
-prev=t[0]; tot=0
+seq=[(0,'start',0),(1,'fwd L0',6),(2,'fwd L1',39),(3,'fwd L2',39),(4,'fwd VL',0),(30,'lik',0),(31,'frDW3+dA3',0),(32,'iss2',0),(33,'frDW2',0),(34,'dA2',39),
+     (14,'iss1',0),(15,'dW2',48),(16,'frDW1',0),(17,'dA1',39),(10,'iss0',0),(11,'dW1',48),(12,'frDW0',0),(13,'dW0',12)]
+prev=t[0]
 for k,name,m in seq[1:]:
     d=t[k]-prev; prev=t[k]
-    print(f'{name:8s} cycles {d:8.0f}  mfma {m:4d}  ideal {m*32:6d}')
-print('total', t[12]-t[0], 'ideal', 410*32)
+    print(f'{name:10s} cycles {d:8.0f}  mfma {m:4d}  ideal {m*32:6d}')
+print('total', t[13]-t[0], 'ideal', 270*32)
