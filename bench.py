@@ -72,17 +72,25 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # TBNN_BENCH_SINGLE_GPU=1 (test hook): every rank uses GPU 0 and the collectives run over gloo on host
+    # copies -- exercises the N > 1 control flow on a 1-GPU box.  Normal runs: one rank per GPU over RCCL.
+    single_gpu = os.environ.get("TBNN_BENCH_SINGLE_GPU", "0") == "1"
+    dev = 0 if single_gpu else local_rank
+    torch.cuda.set_device(dev)
+    cdev = "cpu" if single_gpu else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if single_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
     layers, lik, X, Y, theta0, eta0 = synth_problem(DIMS, N_ROWS)
     eps_warm, eps = bench_eps("c2")
     if args.eps is not None:
         eps_warm = eps = args.eps
     kern = {"auto": nat.KERNEL_AUTO, "generic": nat.KERNEL_GENERIC, "fast": nat.KERNEL_FAST}[args.kernel]
-    ch = nat.Chain(layers, likelihood=lik, device=local_rank, seed=50, chain_id=rank, kernel=kern)
+    ch = nat.Chain(layers, likelihood=lik, device=dev, seed=50, chain_id=rank, kernel=kern)
     # inputs resident in HBM before the timed region (torch owns the buffers)
     dX = torch.from_numpy(X).cuda()
     dY = torch.from_numpy(Y).cuda()
@@ -91,7 +99,7 @@ def main():
     ch.set_state(theta0)
     ch.set_hypers(eta0)
     sample = torch.empty(ch.P + ch.H, dtype=torch.float32, device="cuda")
-    gathered = torch.empty(world * (ch.P + ch.H), dtype=torch.float32, device="cuda") if world > 1 else None
+    gathered = torch.empty(world * (ch.P + ch.H), dtype=torch.float32, device=cdev) if world > 1 else None
 
     def run(epochs, profile_stride, eps):
         ch.set_profiling(profile_stride)
@@ -103,7 +111,10 @@ def main():
             done += k
             if world > 1:                      # checkpoint-time gather over RCCL/xGMI
                 ch.export_sample_device(sample.data_ptr())
-                dist.all_gather_into_tensor(gathered, sample)
+                if single_gpu:
+                    dist.all_gather(list(gathered.chunk(world)), sample.cpu())
+                else:
+                    dist.all_gather_into_tensor(gathered, sample)
         return outs
 
     def fence():
@@ -118,11 +129,11 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         acc = torch.tensor([float(np.mean([o["accept_prob"] for o in outs])),
-                            float(np.mean([o["accepted"] for o in outs]))], dtype=torch.float64, device="cuda")
+                            float(np.mean([o["accepted"] for o in outs]))], dtype=torch.float64, device=cdev)
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
         acc_prob, acc_frac = (acc / world).tolist()
     else:

@@ -91,3 +91,25 @@ def test_hyper_transition_changes_weight_target(native):
     lp, _ = o.target_log_prob_and_grad(spec, th2, eta2, X, Y, np.float64)
     assert abs(out["logp_old"] - lp) <= 4e-6 * abs(lp) + 1e-3
     ch.close()
+
+
+def test_bench_multi_rank_control_flow(tmp_path):
+    """bench.py's N > 1 path (barrier, per-rank chains, sample gather, max-over-ranks timing) with two ranks
+    sharing the one GPU of the test box (TBNN_BENCH_SINGLE_GPU=1: collectives over gloo); the real runs use
+    one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--sampling-step", "3"]
+    env = dict(os.environ, TBNN_BENCH_SINGLE_GPU="1", OMP_NUM_THREADS="4")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["chains"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0.05
