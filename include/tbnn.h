@@ -38,7 +38,8 @@ extern "C" {
 
 /* activation layer that follows a dense layer
  * (tensorBNN/activationFunctions.py:27-63) */
-enum { TBNN_ACT_NONE = 0, TBNN_ACT_RELU = 1, TBNN_ACT_TANH = 2, TBNN_ACT_SIGMOID = 3 };
+enum { TBNN_ACT_NONE = 0, TBNN_ACT_RELU = 1, TBNN_ACT_TANH = 2, TBNN_ACT_SIGMOID = 3,
+       TBNN_ACT_EXP = 4 /* activationFunctions.py:14-24 */, TBNN_ACT_ELU = 5 /* :66-76 */ };
 /* prior family of a dense layer: CauchyDenseLayer (= DenseLayer) layer.py:101,
  * GaussianDenseLayer layer.py:282 */
 enum { TBNN_PRIOR_CAUCHY = 0, TBNN_PRIOR_GAUSSIAN = 1 };

@@ -37,10 +37,10 @@ static int net_P(const onet* n) { int p = 0; for (int l = 0; l < n->nl; ++l) p +
 static int net_H(const onet* n) { return 4 * n->nl + (n->lik == 0 ? 1 : 0); }
 
 static inline float actf(float z, int a) {
-    switch (a) { case 1: return z > 0.f ? z : 0.f; case 2: return tanhf(z); case 3: return 1.f / (1.f + expf(-z)); default: return z; }
+    switch (a) { case 1: return z > 0.f ? z : 0.f; case 2: return tanhf(z); case 3: return 1.f / (1.f + expf(-z)); case 4: return expf(z); case 5: return z > 0.f ? z : expm1f(z); default: return z; }
 }
 static inline float dactf(float a, int act) {
-    switch (act) { case 1: return a > 0.f ? 1.f : 0.f; case 2: return 1.f - a * a; case 3: return a * (1.f - a); default: return 1.f; }
+    switch (act) { case 1: return a > 0.f ? 1.f : 0.f; case 2: return 1.f - a * a; case 3: return a * (1.f - a); case 4: return a; case 5: return a > 0.f ? 1.f : a + 1.f; default: return 1.f; }
 }
 static float lik_sigma(const onet* n, const float* eta) {
     float s = n->lik == 0 ? eta[net_H(n) - 1] * eta[net_H(n) - 1] : n->fixed_sd;   /* likelihood.py:88 / :162 */

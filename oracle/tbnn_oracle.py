@@ -43,7 +43,7 @@ import numpy as np
 # ----------------------------------------------------------------------------
 # Descriptors (the oracle's own; deliberately independent of the product's)
 # ----------------------------------------------------------------------------
-ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_EXP, ACT_ELU = 0, 1, 2, 3, 4, 5
 PRIOR_CAUCHY, PRIOR_GAUSSIAN = 0, 1
 LIK_GAUSSIAN, LIK_FIXED_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2
 
@@ -167,6 +167,10 @@ def activate(z, act):
         return np.tanh(z)
     if act == ACT_SIGMOID:
         return (z.dtype.type(1) / (z.dtype.type(1) + np.exp(-z))).astype(z.dtype)
+    if act == ACT_EXP:                      # activationFunctions.py:23
+        return np.exp(z)
+    if act == ACT_ELU:                      # activationFunctions.py:75 (gen_nn_ops.elu)
+        return np.where(z > 0, z, np.expm1(z)).astype(z.dtype)
     raise ValueError(act)
 
 
@@ -181,6 +185,10 @@ def act_grad_from_output(a, act):
         return one - a * a
     if act == ACT_SIGMOID:
         return a * (one - a)
+    if act == ACT_EXP:
+        return a
+    if act == ACT_ELU:
+        return np.where(a > 0, one, a + one).astype(a.dtype)
     raise ValueError(act)
 
 

@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtbnn.so")
 
-ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_EXP, ACT_ELU = 0, 1, 2, 3, 4, 5
 PRIOR_CAUCHY, PRIOR_GAUSSIAN = 0, 1
 LIK_GAUSSIAN, LIK_FIXED_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST = 0, 1, 2

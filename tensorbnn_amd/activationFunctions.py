@@ -1,8 +1,8 @@
 """Activation plug-ins (reference: tensorBNN/activationFunctions.py).
 
-Relu / Sigmoid / Tanh are fused into the native kernels as the epilogue of the
-dense layer they follow.  The remaining reference activations (Exp, Elu,
-Softmax, Leaky_relu, Prelu, SquarePrelu) are outside this build's hot-path
+Relu / Sigmoid / Tanh / Exp / Elu are fused into the native kernels as the epilogue
+of the dense layer they follow.  The remaining reference activations (Softmax,
+Leaky_relu, Prelu, SquarePrelu) are outside this build's hot-path
 scope: ``network.add`` rejects them loudly.
 """
 import numpy as np
@@ -52,15 +52,26 @@ class _Unsupported(_Activation):
     def __init__(self, *a, **k):
         raise NotImplementedError(
             f"{type(self).__name__}: not covered by the MI355X HMC path (SURVEY.md section 8(f) rank 3); "
-            "supported activations: Relu, Sigmoid, Tanh")
+            "supported activations: Relu, Sigmoid, Tanh, Exp, Elu")
 
 
-class Exp(_Unsupported):
+class Exp(_Activation):
+    """activationFunctions.py:14-24"""
+    act_kind = nat.ACT_EXP
     _name = "Exp"
 
+    def predict(self, inputTensor, _):
+        return np.exp(np.asarray(inputTensor))
 
-class Elu(_Unsupported):
+
+class Elu(_Activation):
+    """activationFunctions.py:66-76"""
+    act_kind = nat.ACT_ELU
     _name = "elu"
+
+    def predict(self, inputTensor, _):
+        z = np.asarray(inputTensor)
+        return np.where(z > 0, z, np.expm1(z))
 
 
 class Softmax(_Unsupported):

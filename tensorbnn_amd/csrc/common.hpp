@@ -55,6 +55,8 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
         case TBNN_ACT_RELU: return fmaxf(z, 0.f);                  // activationFunctions.py:36
         case TBNN_ACT_TANH: return tanhf(z);                       // :62
         case TBNN_ACT_SIGMOID: return 1.f / (1.f + expf(-z));      // :49
+        case TBNN_ACT_EXP: return expf(z);                         // :23
+        case TBNN_ACT_ELU: return z > 0.f ? z : expm1f(z);         // :75
         default: return z;
     }
 }
@@ -64,6 +66,8 @@ __device__ __forceinline__ float act_bwd(float a, int act) {
         case TBNN_ACT_RELU: return a > 0.f ? 1.f : 0.f;
         case TBNN_ACT_TANH: return 1.f - a * a;
         case TBNN_ACT_SIGMOID: return a * (1.f - a);
+        case TBNN_ACT_EXP: return a;
+        case TBNN_ACT_ELU: return a > 0.f ? 1.f : a + 1.f;
         default: return 1.f;
     }
 }

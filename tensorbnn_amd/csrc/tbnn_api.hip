@@ -77,7 +77,7 @@ static int build_netdev(const tbnn_net_desc* d, NetDev& nd) {
         const tbnn_layer_desc& L = d->layers[l];
         if (L.in_dim < 1 || L.out_dim < 1) return fail(-1, "layer dims must be >= 1");
         if (l > 0 && L.in_dim != d->layers[l - 1].out_dim) return fail(-1, "layer dims do not chain");
-        if (L.act < TBNN_ACT_NONE || L.act > TBNN_ACT_SIGMOID) return fail(-1, "unknown activation");
+        if (L.act < TBNN_ACT_NONE || L.act > TBNN_ACT_ELU) return fail(-1, "unknown activation");
         if (L.prior != TBNN_PRIOR_CAUCHY && L.prior != TBNN_PRIOR_GAUSSIAN) return fail(-1, "unknown prior");
         nd.in[l] = L.in_dim; nd.out[l] = L.out_dim; nd.act[l] = L.act; nd.prior[l] = L.prior;
         nd.offW[l] = off; off += L.in_dim * L.out_dim;

@@ -56,6 +56,8 @@ CASES = {
     # single row, single layer
     "tiny": dict(dims=[3, 1], n=1, act=o.ACT_NONE, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN),
     "sigmoid_hidden": dict(dims=[4, 7, 3], n=130, act=o.ACT_SIGMOID, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN),
+    "elu_hidden": dict(dims=[3, 20, 17, 2], n=333, act=o.ACT_ELU, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN),
+    "exp_hidden": dict(dims=[2, 6, 1], n=70, act=o.ACT_EXP, prior=o.PRIOR_CAUCHY, lik=o.LIK_FIXED_GAUSSIAN),
 }
 
 

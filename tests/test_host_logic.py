@@ -70,7 +70,7 @@ def test_add_builds_reference_state_layout():
 
 
 def test_unsupported_plugins_fail_loudly():
-    from tensorbnn_amd.activationFunctions import Elu, Relu
+    from tensorbnn_amd.activationFunctions import Softmax as Elu, Relu
     from tensorbnn_amd.network import network
     with pytest.raises(NotImplementedError):
         Elu()

@@ -105,7 +105,7 @@ def _torch_target(spec, theta, eta, X, Y):
             off += l.out_dim
             tot = tot + prior(l, et[4 * i:4 * i + 4], W, b, hyper)
             z = W @ a + b
-            a = {o.ACT_NONE: lambda v: v, o.ACT_RELU: torch.relu, o.ACT_TANH: torch.tanh, o.ACT_SIGMOID: torch.sigmoid}[l.act](z)
+            a = {o.ACT_NONE: lambda v: v, o.ACT_RELU: torch.relu, o.ACT_TANH: torch.tanh, o.ACT_SIGMOID: torch.sigmoid, o.ACT_EXP: torch.exp, o.ACT_ELU: torch.nn.functional.elu}[l.act](z)
         if not hyper or spec.likelihood == o.LIK_GAUSSIAN:
             tot = tot + lik(a)
         return tot
@@ -123,6 +123,8 @@ CASES = {
     "c2": ([5, 50, 50, 50, 1], 96, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
     "c5": ([20, 100, 100, 2], 64, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI),
     "sig": ([4, 7, 3], 50, o.ACT_SIGMOID, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN),
+    "elu": ([3, 20, 17, 2], 40, o.ACT_ELU, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN),
+    "exp": ([2, 6, 1], 30, o.ACT_EXP, o.PRIOR_CAUCHY, o.LIK_FIXED_GAUSSIAN),
 }
 
 
