@@ -693,6 +693,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #undef TB_STAMP
 }
 
+#ifndef TBNN_NO_FAST_REGISTRY
 // ---------------------------------------------------------------------------
 // registry of ahead-of-time instantiations (shapes of BASELINE.json's configs)
 // ---------------------------------------------------------------------------
@@ -764,3 +765,4 @@ static inline void fast_image_map(int id, int* map) {
         default: break;
     }
 }
+#endif  // TBNN_NO_FAST_REGISTRY

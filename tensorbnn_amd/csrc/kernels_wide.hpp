@@ -1,0 +1,677 @@
+// Wide-layer path (hidden widths above the register budget of k_fwd_bwd_fast3: BASELINE configs[3]
+// 10->200->200->200->1 and configs[4] 20->100->100->2), gfx950 f32 MFMA (v_mfma_f32_16x16x4_f32).
+//
+// A 200x200 layer has 169 dW tiles = 676 accumulator registers per lane: the gradient of a middle
+// layer cannot ride along in the registers of the wave that runs the forward/backward chain.  The
+// pass is therefore split in two kernels:
+//
+//   k_chain_wide   one wave = one 16-row tile through forward, likelihood and the delta chain with
+//                  every activation in registers (the C/D layout of layer l-1 is the B-operand layout
+//                  of layer l, kernels_fast.hpp).  The middle layers' weights do not fit in LDS
+//                  (200x200 fp32 = 160 KB): all four waves of the workgroup consume ONE weight stream
+//                  (W_1 .. W_NM, then W_NM^T .. W_1^T, pre-swizzled into MFMA A-operand order by
+//                  k_update) through a 4-slot LDS ring, one k-group (16 input slots x all output
+//                  tiles) per slot, refilled from L2 two chunks ahead.  dW of the FIRST layer (fan-in
+//                  <= 32) and of the LAST layer (<= 2 outputs, VALU) are accumulated in registers as
+//                  in the narrow kernel.  For every middle layer l the wave stores a_l (+ ones slot)
+//                  and delta_l to HBM in 1-KB [16 rows][16 slots] blocks.
+//   k_dw_wide      dW_l = delta_l^T a_l (contraction over ALL rows) for the middle layers: each
+//                  workgroup owns a row range and the whole 13x13-tile output (43 tiles per wave),
+//                  streams the 1-KB blocks through a 4-slot LDS ring and writes its partial dW to a
+//                  private slab; k_reduce_wide sums the slabs in fixed order (deterministic).
+//
+// Algorithmic HBM traffic of the split: 2 arrays (a_l, delta_l) x n x 4 B x padded width per middle
+// layer, written once and read once (C4: 3.3 GB each way per gradient ~ 1 ms of HBM time against
+// 3.1 ms of MFMA time at peak).
+//
+// Reference math: layer.py:278 (W@a+b), activationFunctions.py:36/49/62, likelihood.py:88-94,226-236,
+// BNN_functions.py:23-32; reverse mode SURVEY A12.
+#pragma once
+#include <type_traits>
+#include "kernels_fast.hpp"
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
+#define SFOR_LAMBDA(name) [&](auto name##_) __attribute__((always_inline))
+#define SFOR_VAL(name) decltype(name##_)::value
+
+#define WIDE_WAVES 4
+#define WIDE_THREADS 256
+#define WIDE_RING 4
+
+template <class S>
+struct WideCfg {
+    static constexpr int NL = S::NL;
+    static_assert(NL >= 3, "the wide path needs at least one middle layer");
+    static constexpr int in(int l) { return S::D[l]; }
+    static constexpr int out(int l) { return S::D[l + 1]; }
+    static constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+    static constexpr int r4(int a) { return (a + 3) & ~3; }
+    static constexpr int NM = NL - 2;                 // middle layers 1 .. NM
+    static constexpr int LL = NL - 1;                 // last layer (VALU)
+    static constexpr int d_in = in(0), d_out = out(LL);
+    static_assert(d_out <= 2, "last layer runs on the VALU (<= 2 outputs)");
+    // a_l = input of layer l (l = 1..LL): in(l) real units + the ones pseudo-unit, in the padded slot order of
+    // kernels_fast.hpp (slot_of / unit_of / ones_slot: identity on full 16-unit groups, the last partial group
+    // spread over the lane groups first so that it needs only ceil(rem/4) MFMA k-steps)
+    static constexpr int TR(int l) { return cdiv(in(l), 16); }          // register tiles (real units)
+    static constexpr int TA(int l) { return cdiv(in(l) + 1, 16); }      // stored tiles (with the ones slot)
+    static constexpr int ksteps(int K, int kg) { int rem = K - 16 * kg; return rem >= 16 ? 4 : (rem <= 0 ? 0 : (rem + 3) / 4); }
+    static constexpr int KG(int K) { return cdiv(K, 16); }
+    static constexpr int aroff(int l) { int o = 0; for (int m = 1; m < l; ++m) o += TR(m); return o; }   // a_l in the register file
+    static constexpr int ACT_TILES = aroff(LL + 1);
+    static constexpr int maxT() { int m = 0; for (int l = 1; l <= LL; ++l) m = TR(l) > m ? TR(l) : m; return m; }
+    static constexpr int MAXT = maxT();
+    // layer 0
+    static constexpr int KG0 = KG(d_in), NT0 = cdiv(d_in + 1, 16), MT0 = TR(1);
+    static constexpr int DW0_TILES = MT0 * NT0;
+    // ---- permanent part of the weight image (LDS resident): W_0 operands, biases 0..NM, W_LL, b_LL
+    static constexpr int W0_OFF = 0;
+    static constexpr int W0_FLOATS = MT0 * KG0 * 256;
+    static constexpr int boff(int l) { int o = W0_OFF + W0_FLOATS; for (int m = 0; m < l; ++m) o += 16 * TR(m + 1); return o; }   // bias of layer l <= NM
+    static constexpr int WLP = 16 * TR(LL);                                   // pitch of W_LL rows
+    static constexpr int WL_OFF = boff(NM + 1);
+    static constexpr int BL_OFF = WL_OFF + d_out * WLP;
+    static constexpr int PERM_FLOATS = r4(BL_OFF + d_out);
+    // ---- the weight stream: chunks of one k-group each.  Segment order F(1)..F(NM), B(NM)..B(1).
+    //   F(l) chunk kg: granule t < TR(l+1): lane (i, g) holds W_l[16t+i][16kg+4g+s], s = 0..3
+    //   B(l) chunk kg: granule u < TR(l)  : lane (i, g) holds W_l[16kg+4g+s][16u+i]
+    static constexpr int GF(int l) { return r4(TR(l + 1)); }
+    static constexpr int GB(int l) { return r4(TR(l)); }
+    static constexpr int cF(int l) { int c = 0; for (int m = 1; m < l; ++m) c += KG(in(m)); return c; }           // first chunk of F(l)
+    static constexpr int cB(int l) { int c = cF(NM + 1); for (int m = NM; m > l; --m) c += KG(out(m)); return c; } // first chunk of B(l)
+    static constexpr int NCH = cB(0);
+    static constexpr int chunk_gran(int c) {
+        for (int l = 1; l <= NM; ++l) if (c >= cF(l) && c < cF(l) + KG(in(l))) return GF(l);
+        for (int l = NM; l >= 1; --l) if (c >= cB(l) && c < cB(l) + KG(out(l))) return GB(l);
+        return 0;
+    }
+    static constexpr int chunk_off(int c) { int o = PERM_FLOATS; for (int k = 0; k < c; ++k) o += chunk_gran(k) * 256; return o; }   // floats
+    static constexpr int IMG_FLOATS = chunk_off(NCH);
+    static constexpr int maxGran() { int m = 0; for (int c = 0; c < NCH; ++c) m = chunk_gran(c) > m ? chunk_gran(c) : m; return m; }
+    static constexpr int SLOT_FLOATS = maxGran() * 256;
+    static constexpr int NGW = maxGran() / WIDE_WAVES;          // granules per wave per chunk
+    static_assert(NCH >= 3, "ring priming assumes >= 3 chunks");
+    // ---- LDS layout (floats)
+    static constexpr int RING_OFF = PERM_FLOATS;
+    static constexpr int PX = 16 * NT0 + 4;                     // x image pitch
+    static constexpr int XIMG_OFF = RING_OFF + WIDE_RING * SLOT_FLOATS;
+    static constexpr int XIMG_FLOATS = 16 * PX;
+    static constexpr int DZB = 4, PZ = 16 * DZB + 4;            // delta_0 transposed DZB tiles at a time
+    static constexpr int SCR_OFF = XIMG_OFF + WIDE_WAVES * XIMG_FLOATS;
+    static constexpr int SCR_FLOATS = 16 * PZ;
+    static constexpr int LDS_FLOATS = SCR_OFF + WIDE_WAVES * SCR_FLOATS;
+    // ---- parameters
+    static constexpr int offW(int l) { int p = 0; for (int m = 0; m < l; ++m) p += in(m) * out(m) + out(m); return p; }
+    static constexpr int P() { return offW(NL); }
+    // compact slab of k_chain_wide: [layer 0 params][last layer params]
+    static constexpr int SA_L0 = 0, SA_LL = in(0) * out(0) + out(0);
+    static constexpr int SA_FLOATS = r4(SA_LL + in(LL) * d_out + d_out);
+    // ---- HBM activation / delta arrays (per middle layer l): blocks [row tile][tile][16 rows][16 slots]
+    static constexpr int TZ(int l) { return TR(l + 1); }        // tiles of delta_l (outputs of layer l)
+    static constexpr long act_off(int l, long ntiles) { long o = 0; for (int m = 1; m < l; ++m) o += ntiles * (TA(m) + TZ(m)) * 256; return o; }   // a_l
+    static constexpr long dz_off(int l, long ntiles) { return act_off(l, ntiles) + ntiles * TA(l) * 256; }
+    static constexpr long store_floats(long ntiles) { return act_off(NM + 1, ntiles); }
+    // ---- k_dw_wide: tiles of dW_l per wave
+    static constexpr int QM(int l) { return TZ(l) / 4; }                        // whole M tiles per wave (m = wave + 4j)
+    static constexpr int RM(int l) { return TZ(l) % 4; }                        // left-over M tiles, shared out as (m, u) pairs
+    static constexpr int QP(int l) { return cdiv(RM(l) * TA(l), 4); }           // pairs per wave
+    static constexpr int DWT(int l) { return QM(l) * TA(l) + QP(l); }           // accumulator tiles per wave
+    static constexpr int maxDWT() { int m = 0; for (int l = 1; l <= NM; ++l) m = DWT(l) > m ? DWT(l) : m; return m; }
+    static constexpr int SB(int l) { return TA(l) + TZ(l); }                    // 1-KB blocks per row tile
+    static constexpr int maxSB() { int m = 0; for (int l = 1; l <= NM; ++l) m = SB(l) > m ? SB(l) : m; return m; }
+    static constexpr int DW_SLOT_FLOATS = maxSB() * 256;
+    static constexpr int DW_NGW = cdiv(maxSB(), WIDE_WAVES);
+    static constexpr int slabB_off(int l) { int o = 0; for (int m = 1; m < l; ++m) o += r4(in(m) * out(m) + out(m)); return o; }   // within one WG's slab
+    static constexpr int SB_FLOATS = slabB_off(NM + 1);
+    static constexpr long dw_cost(int l) { return (long)DWT(l); }
+};
+
+// y = sum over the 16 lanes of a lane group (same lane >> 4)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_chain_wide
+// ---------------------------------------------------------------------------------------------
+template <class S>
+struct WideRegs {
+    using C = WideCfg<S>;
+    f32x4 a[C::MAXT];               // the current layer's input a_l, D layout: tile t reg j of lane (r, g) = unit 16t+4g+j of row r
+    float x[C::KG0 * 4];            // x[4kg+s] = X[row][16kg+4g+s]
+};
+
+// top of chunk c: park the chunk fetched one step ago (c+2) in its ring slot, fetch chunk c+3.
+template <class S, int c>
+__device__ __forceinline__ void wide_stage(int base, f32x4 (&stg)[WideCfg<S>::NGW], float* __restrict__ ring,
+                                           const float* __restrict__ img, int wave, int lane) {
+    using C = WideCfg<S>;
+    constexpr int cw = (c + 2) % C::NCH, cl = (c + 3) % C::NCH;
+    float* dst = ring + ((base + c + 2) & (WIDE_RING - 1)) * C::SLOT_FLOATS + wave * 256 + lane * 4;
+#pragma unroll
+    for (int j = 0; j < C::NGW; ++j)
+        if (j < C::chunk_gran(cw) / WIDE_WAVES) *reinterpret_cast<f32x4*>(dst + j * WIDE_WAVES * 256) = stg[j];
+    const float* src = img + C::chunk_off(cl) + wave * 256 + lane * 4;
+#pragma unroll
+    for (int j = 0; j < C::NGW; ++j)
+        if (j < C::chunk_gran(cl) / WIDE_WAVES) stg[j] = *reinterpret_cast<const f32x4*>(src + j * WIDE_WAVES * 256);
+}
+
+template <class S>
+__global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_chain_wide(
+    NetDev nd, const float* __restrict__ qimg, const float* __restrict__ eta,
+    const float* __restrict__ X, const float* __restrict__ Y, long n,
+    float* __restrict__ store, float* __restrict__ slabA, double* __restrict__ pstat)
+{
+    using C = WideCfg<S>;
+    static_assert(C::LDS_FLOATS * 4 + 64 <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+    __shared__ double red[WIDE_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    constexpr int d_in = C::d_in, d_out = C::d_out, NM = C::NM, LL = C::LL;
+    const long ntiles = (n + 15) / 16;
+    const long nblk = (ntiles + WIDE_WAVES - 1) / WIDE_WAVES;
+
+    // ---- prologue: permanent image -> LDS; prime the ring (chunks 0, 1 in slots 0, 1; chunk 2 in registers)
+    for (int e = tid; e < C::PERM_FLOATS / 4; e += WIDE_THREADS)
+        reinterpret_cast<float4*>(lds)[e] = reinterpret_cast<const float4*>(qimg)[e];
+    float* ring = lds + C::RING_OFF;
+    f32x4 stg[C::NGW];
+    sfor<0, 2>(SFOR_LAMBDA(c) {
+        constexpr int c = SFOR_VAL(c);
+#pragma unroll
+        for (int j = 0; j < C::NGW; ++j)
+            if (j < C::chunk_gran(c) / WIDE_WAVES)
+                *reinterpret_cast<f32x4*>(ring + c * C::SLOT_FLOATS + (wave + j * WIDE_WAVES) * 256 + lane * 4) =
+                    *reinterpret_cast<const f32x4*>(qimg + C::chunk_off(c) + (wave + j * WIDE_WAVES) * 256 + lane * 4);
+    });
+#pragma unroll
+    for (int j = 0; j < C::NGW; ++j)
+        stg[j] = (j < C::chunk_gran(2) / WIDE_WAVES)
+                     ? *reinterpret_cast<const f32x4*>(qimg + C::chunk_off(2) + (wave + j * WIDE_WAVES) * 256 + lane * 4)
+                     : f32x4{0.f, 0.f, 0.f, 0.f};
+    float* ximg = lds + C::XIMG_OFF + wave * C::XIMG_FLOATS;
+    float* scr = lds + C::SCR_OFF + wave * C::SCR_FLOATS;
+    for (int e = lane; e < C::XIMG_FLOATS; e += 64) ximg[e] = 0.f;
+    __syncthreads();
+    if (g == 0) ximg[i16 * C::PX + d_in] = 1.f;               // ones column of the x image (db_0)
+
+    const float sigma = lik_sigma(nd, eta);
+    const float inv_var = 1.f / (sigma * sigma);
+    double stat = 0.0;
+    f32x4 dW0[C::DW0_TILES];
+#pragma unroll
+    for (int t = 0; t < C::DW0_TILES; ++t) dW0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accL[d_out][C::TR(LL)];
+    float accbL[d_out];
+#pragma unroll
+    for (int o = 0; o < d_out; ++o) {
+        accbL[o] = 0.f;
+#pragma unroll
+        for (int t = 0; t < C::TR(LL); ++t) accL[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    float xn[C::KG0 * 4], yn[d_out];
+    auto fetch = [&](long tile) {
+        const long row = tile * 16 + i16;
+        const bool ok = tile < ntiles && row < n;
+#pragma unroll
+        for (int k = 0; k < C::KG0 * 4; ++k) {
+            const int u = unit_of(d_in, 16 * (k / 4) + 4 * g + (k % 4), false);
+            xn[k] = (ok && u >= 0) ? X[row * d_in + u] : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) yn[o] = ok ? Y[row * d_out + o] : 0.f;
+    };
+    fetch((long)blockIdx.x * WIDE_WAVES + wave);
+    int base = 0;                                              // ring slot of chunk 0 of the current block
+
+    for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        // the weight stream is the same for every block: hide the pointer from loop-invariant code motion,
+        // or every chunk load is hoisted out of the row loop (and spilled)
+        int opaque0 = 0;
+        asm volatile("" : "+s"(opaque0));
+        const float* img = qimg + opaque0;
+        const long tile = blk * WIDE_WAVES + wave;
+        const bool tvalid = tile < ntiles;
+        const bool rvalid = tile * 16 + i16 < n;
+        WideRegs<S> T;
+        float y[d_out];
+#pragma unroll
+        for (int k = 0; k < C::KG0 * 4; ++k) T.x[k] = xn[k];
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) y[o] = yn[o];
+        fetch((blk + gridDim.x) * WIDE_WAVES + wave);
+        // x image for dW_0 (slots < d_in only: the ones column stays)
+#pragma unroll
+        for (int k = 0; k < C::KG0 * 4; ++k) {
+            const int u = unit_of(d_in, 16 * (k / 4) + 4 * g + (k % 4), false);
+            if (u >= 0) ximg[i16 * C::PX + u] = T.x[k];
+        }
+
+        // ---- layer 0 (weights resident in LDS)
+        {
+            constexpr int MT = C::MT0;
+            f32x4 acc[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(lds + C::boff(0) + 16 * t + 4 * g);
+#pragma unroll
+            for (int kg = 0; kg < C::KG0; ++kg) {
+                f32x4 A[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) A[t] = *reinterpret_cast<const f32x4*>(lds + C::W0_OFF + (t * C::KG0 + kg) * 256 + lane * 4);
+#pragma unroll
+                for (int s = 0; s < C::ksteps(d_in, kg); ++s)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t] = mfma16(A[t][s], T.x[4 * kg + s], acc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T.a[t][r] = actc_fwd<S::act(0)>(acc[t][r]);
+        }
+
+        // ---- middle layers, forward: a_l -> a_{l+1}; a_l (+ ones slot) goes to HBM for k_dw_wide
+        sfor<1, NM + 1>(SFOR_LAMBDA(l) {
+            constexpr int l = SFOR_VAL(l);
+            {   // store a_l
+                f32x4 v[C::MAXT + 1];
+#pragma unroll
+                for (int t = 0; t < C::TA(l); ++t) {
+                    v[t] = t < C::TR(l) ? T.a[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    constexpr int os = ones_slot(C::in(l));
+                    if (t == os / 16 && g == (os % 16) / 4) v[t][os % 4] = 1.f;
+                }
+                if (tvalid) {
+                    float* p = store + C::act_off(l, ntiles) + ((size_t)tile * C::TA(l)) * 256 + i16 * 16 + g * 4;
+#pragma unroll
+                    for (int t = 0; t < C::TA(l); ++t) *reinterpret_cast<f32x4*>(p + t * 256) = v[t];
+                }
+            }
+            constexpr int MT = C::TR(l + 1);
+            f32x4 acc[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * t + 4 * g);
+            sfor<0, C::KG(C::in(l))>(SFOR_LAMBDA(kg) {
+                constexpr int kg = SFOR_VAL(kg), c = C::cF(l) + kg;
+                wide_stage<S, c>(base, stg, ring, img, wave, lane);
+                const float* sl = ring + ((base + c) & (WIDE_RING - 1)) * C::SLOT_FLOATS + lane * 4;
+                f32x4 A[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) A[t] = *reinterpret_cast<const f32x4*>(sl + t * 256);
+#pragma unroll
+                for (int s = 0; s < C::ksteps(C::in(l), kg); ++s)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t] = mfma16(A[t][s], T.a[kg][s], acc[t]);
+                __syncthreads();
+            });
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T.a[t][r] = actc_fwd<S::HACT>(acc[t][r]);
+        });
+
+        // ---- last layer on the VALU: f_o = b_o + sum_u W[o][u] a_LL[u]
+        f32x4 dz[C::MAXT];
+        {
+            constexpr int TP = C::TR(LL);
+            float dzl[d_out];
+#pragma unroll
+            for (int o = 0; o < d_out; ++o) {
+                float p = 0.f;
+#pragma unroll
+                for (int t = 0; t < TP; ++t) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p = fmaf(w[r], T.a[t][r], p);
+                }
+                p += __shfl_xor(p, 16, 64);
+                p += __shfl_xor(p, 32, 64);
+                const float fi = actc_fwd<S::LACT>(p + lds[C::BL_OFF + o]);
+                dzl[o] = rvalid ? lik_delta<S>(fi, y[o], inv_var, g == 0, stat) : 0.f;
+                accbL[o] += dzl[o];
+            }
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < d_out; ++o) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        accL[o][t][r] = fmaf(dzl[o], T.a[t][r], accL[o][t][r]);
+                        d[r] = fmaf(w[r], dzl[o], d[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz[t][r] = actc_bwd_mul<S::HACT>(d[r], T.a[t][r]);
+            }
+        }
+
+        // ---- delta chain through the middle layers: delta_l (held in dz) -> delta_{l-1}
+        sfor<0, NM>(SFOR_LAMBDA(li) {
+            constexpr int l = NM - SFOR_VAL(li);
+            if (tvalid) {       // delta_l -> HBM
+                float* p = store + C::dz_off(l, ntiles) + ((size_t)tile * C::TZ(l)) * 256 + i16 * 16 + g * 4;
+#pragma unroll
+                for (int t = 0; t < C::MAXT; ++t)
+                    if (t < C::TZ(l)) *reinterpret_cast<f32x4*>(p + t * 256) = dz[t];
+            }
+            constexpr int MU = C::TR(l);
+            // a_l (for act') comes back from the block this lane stored in the forward pass: nothing but the
+            // current layer's operand stays in registers across the chain
+            f32x4 arel[MU];
+            {
+                const float* p = store + C::act_off(l, ntiles) + ((size_t)(tvalid ? tile : 0) * C::TA(l)) * 256 + i16 * 16 + g * 4;
+#pragma unroll
+                for (int u = 0; u < MU; ++u) arel[u] = tvalid ? *reinterpret_cast<const f32x4*>(p + u * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            f32x4 acc[MU];
+#pragma unroll
+            for (int u = 0; u < MU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            sfor<0, C::KG(C::out(l))>(SFOR_LAMBDA(kg) {
+                constexpr int kg = SFOR_VAL(kg), c = C::cB(l) + kg;
+                wide_stage<S, c>(base, stg, ring, img, wave, lane);
+                const float* sl = ring + ((base + c) & (WIDE_RING - 1)) * C::SLOT_FLOATS + lane * 4;
+                f32x4 A[MU];
+#pragma unroll
+                for (int u = 0; u < MU; ++u) A[u] = *reinterpret_cast<const f32x4*>(sl + u * 256);
+#pragma unroll
+                for (int s = 0; s < C::ksteps(C::out(l), kg); ++s)
+#pragma unroll
+                    for (int u = 0; u < MU; ++u) acc[u] = mfma16(A[u][s], dz[kg][s], acc[u]);
+                __syncthreads();
+            });
+#pragma unroll
+            for (int u = 0; u < MU; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz[u][r] = actc_bwd_mul<S::act(l - 1)>(acc[u][r], arel[u][r]);
+        });
+
+        // ---- dW_0 += delta_0^T [x, 1]: contraction over the 16 rows (on the lanes): transpose through LDS
+        {
+            float Bop[C::NT0][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < C::NT0; ++nt) Bop[nt][s] = ximg[(4 * g + s) * C::PX + 16 * nt + i16];
+#pragma unroll
+            for (int b0 = 0; b0 < C::MT0; b0 += C::DZB) {
+#pragma unroll
+                for (int t = b0; t < b0 + C::DZB && t < C::MT0; ++t)
+                    *reinterpret_cast<f32x4*>(scr + i16 * C::PZ + 16 * (t - b0) + 4 * g) = dz[t];
+                float Aop[C::DZB][4];
+#pragma unroll
+                for (int t = b0; t < b0 + C::DZB && t < C::MT0; ++t)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) Aop[t - b0][s] = scr[(4 * g + s) * C::PZ + 16 * (t - b0) + i16];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = b0; t < b0 + C::DZB && t < C::MT0; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < C::NT0; ++nt)
+                            dW0[t * C::NT0 + nt] = mfma16(Aop[t - b0][s], Bop[nt][s], dW0[t * C::NT0 + nt]);
+            }
+        }
+        base = (base + C::NCH) & (WIDE_RING - 1);
+    }
+
+    // ---- epilogue: compact slab [layer 0][last layer] of this workgroup
+    const double wtot = wave_sum(stat);
+    if (lane == 0) red[wave] = wtot;
+    __syncthreads();                                   // ring is dead
+    float* slab = slabA + (size_t)blockIdx.x * C::SA_FLOATS;
+    {
+        // dW_0: stage the 4 waves' copies [wave][tile][lane] (EP tiles per pass, whole LDS is free now), wave t%4 sums tile t
+        constexpr int EP = C::LDS_FLOATS / (WIDE_WAVES * 256) < C::DW0_TILES ? C::LDS_FLOATS / (WIDE_WAVES * 256) : C::DW0_TILES;
+        static_assert(EP >= 1, "no room to stage dW_0");
+        f32x4* stgb = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+        for (int t0 = 0; t0 < C::DW0_TILES; t0 += EP) {
+#pragma unroll
+            for (int t = t0; t < t0 + EP && t < C::DW0_TILES; ++t) stgb[(wave * EP + (t - t0)) * 64 + lane] = dW0[t];
+            __syncthreads();
+#pragma unroll
+            for (int t = t0; t < t0 + EP && t < C::DW0_TILES; ++t)
+                if ((t & (WIDE_WAVES - 1)) == wave) {
+                    const f32x4 c0 = stgb[(t - t0) * 64 + lane], c1 = stgb[(EP + t - t0) * 64 + lane],
+                                c2 = stgb[(2 * EP + t - t0) * 64 + lane], c3 = stgb[(3 * EP + t - t0) * 64 + lane];
+                    const int mt = t / C::NT0, nt = t % C::NT0;
+                    const int col = 16 * nt + i16, row0 = 16 * mt + 4 * g;
+                    if (col <= d_in) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = unit_of(C::out(0), row0 + r, false);
+                            if (row >= 0)
+                                slab[C::SA_L0 + (col < d_in ? row * d_in + col : d_in * C::out(0) + row)] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
+                        }
+                    }
+                }
+            __syncthreads();
+        }
+    }
+    {
+        // last layer: reduce the per-row partials over the 16 lanes of a lane group, then over the 4 waves
+        constexpr int TP = C::TR(LL), inL = C::in(LL);
+        float* lb = lds;                               // [wave][o][slot], then [wave][o] biases
+        static_assert(WIDE_WAVES * d_out * (16 * TP + 1) <= C::LDS_FLOATS, "last-layer staging does not fit");
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) {
+#pragma unroll
+            for (int t = 0; t < TP; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = row16_sum(accL[o][t][r]);
+                    if (i16 == 0) lb[(wave * d_out + o) * (16 * TP + 1) + 16 * t + 4 * g + r] = v;
+                }
+            const float vb = row16_sum(accbL[o]);
+            if (lane == 0) lb[(wave * d_out + o) * (16 * TP + 1) + 16 * TP] = vb;
+        }
+        __syncthreads();
+        for (int e = tid; e < d_out * (inL + 1); e += WIDE_THREADS) {
+            const int o = e / (inL + 1), u = e - o * (inL + 1);
+            const int s = u < inL ? slot_of(inL, u) : 16 * TP;
+            float v[WIDE_WAVES];
+#pragma unroll
+            for (int w = 0; w < WIDE_WAVES; ++w) v[w] = lb[(w * d_out + o) * (16 * TP + 1) + s];
+            slab[C::SA_LL + (u < inL ? o * inL + u : inL * d_out + o)] = (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    }
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < WIDE_WAVES; ++w) t += red[w];
+        pstat[blockIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dw_wide: dW_l / db_l of the middle layers from the stored blocks
+// ---------------------------------------------------------------------------------------------
+// Workgroup b of layer l's group (wg_lo[l] <= b < wg_lo[l+1]) owns row tiles [rt0, rt1) and the whole
+// dW_l: wave w accumulates M tiles {w, w+4, ..} x all N tiles plus QP (m, u) pairs of the left-over
+// M tiles.  A operand = delta block (k = data row 4s+g, m = out slot), B operand = a block: both are
+// plain lane-linear reads of the [16 rows][16 slots] block (float offset 64 s + lane).
+struct WideDwArgs {
+    int wg_lo[TBNN_MAX_LAYERS + 1];      // first workgroup of middle layer l (index l-1); [NM] = total
+};
+
+template <class S, int l>
+__device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, long ntiles, long rt0, long rt1,
+                                              float* __restrict__ slab, float* lds, int wave, int lane) {
+    using C = WideCfg<S>;
+    constexpr int TAl = C::TA(l), TZl = C::TZ(l), QM = C::QM(l), RM = C::RM(l), QP = C::QP(l), SB = C::SB(l);
+    constexpr int NT = QM * TAl + QP;
+    constexpr int NG = C::cdiv(SB, WIDE_WAVES);
+    const float* abase = store + C::act_off(l, ntiles);
+    const float* zbase = store + C::dz_off(l, ntiles);
+    f32x4 acc[NT > 0 ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // left-over pairs of this wave: p = wave + 4q -> (m = 4 QM + p / TA, u = p % TA); invalid ones recompute pair 0
+    int pm[QP > 0 ? QP : 1], pu[QP > 0 ? QP : 1];
+    bool pv[QP > 0 ? QP : 1];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        const int p = wave + 4 * q;
+        pv[q] = p < RM * TAl;
+        const int pp = pv[q] ? p : 0;
+        pm[q] = 4 * QM + pp / TAl; pu[q] = pp % TAl;
+    }
+    // slot layout: [a blocks 0..TA-1][delta blocks 0..TZ-1], 256 floats each
+    f32x4 stg[NG];
+    auto gload = [&](long rt) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int b = wave + 4 * j;
+            if (b < SB && rt < rt1) {
+                const float* src = b < TAl ? abase + ((size_t)rt * TAl + b) * 256 : zbase + ((size_t)rt * TZl + (b - TAl)) * 256;
+                stg[j] = *reinterpret_cast<const f32x4*>(src + lane * 4);
+            } else stg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto park = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int b = wave + 4 * j;
+            if (b < SB) *reinterpret_cast<f32x4*>(lds + slot * C::DW_SLOT_FLOATS + b * 256 + lane * 4) = stg[j];
+        }
+    };
+    // prime: row tiles rt0, rt0+1 parked; rt0+2 in registers
+    gload(rt0); park(0);
+    gload(rt0 + 1); park(1);
+    gload(rt0 + 2);
+    __syncthreads();
+    int it = 0;
+    for (long rt = rt0; rt < rt1; ++rt, ++it) {
+        park((it + 2) & (WIDE_RING - 1));
+        gload(rt + 3);
+        const float* sl = lds + (it & (WIDE_RING - 1)) * C::DW_SLOT_FLOATS + lane;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float B[TAl], A[QM > 0 ? QM : 1];
+#pragma unroll
+            for (int u = 0; u < TAl; ++u) B[u] = sl[u * 256 + 64 * s];
+#pragma unroll
+            for (int j = 0; j < QM; ++j) A[j] = sl[(TAl + wave + 4 * j) * 256 + 64 * s];
+#pragma unroll
+            for (int j = 0; j < QM; ++j)
+#pragma unroll
+                for (int u = 0; u < TAl; ++u) acc[j * TAl + u] = mfma16(A[j], B[u], acc[j * TAl + u]);
+#pragma unroll
+            for (int q = 0; q < QP; ++q) {
+                const float a = sl[(TAl + pm[q]) * 256 + 64 * s], b = sl[pu[q] * 256 + 64 * s];
+                acc[QM * TAl + q] = mfma16(a, b, acc[QM * TAl + q]);
+            }
+        }
+        __syncthreads();
+    }
+    // write-out in theta order: D layout lane (n = lane & 15, g) reg j = dW[out 16m+4g+j][in 16u+n]
+    const int nn = lane & 15, gg = lane >> 4;
+    constexpr int inl = C::in(l), outl = C::out(l);
+    auto put = [&](int m, int u, const f32x4& v) {
+        const int col = unit_of(inl, 16 * u + nn, true);          // inl: the ones pseudo-unit (bias column)
+        if (col >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = unit_of(outl, 16 * m + 4 * gg + j, false);
+                if (row >= 0) slab[col < inl ? row * inl + col : inl * outl + row] = v[j];
+            }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < QM; ++j)
+#pragma unroll
+        for (int u = 0; u < TAl; ++u) put(wave + 4 * j, u, acc[j * TAl + u]);
+#pragma unroll
+    for (int q = 0; q < QP; ++q)
+        if (pv[q]) put(pm[q], pu[q], acc[QM * TAl + q]);
+}
+
+template <class S>
+__global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dw_wide(
+    WideDwArgs args, const float* __restrict__ store, long n, float* __restrict__ slabB)
+{
+    using C = WideCfg<S>;
+    static_assert(WIDE_RING * C::DW_SLOT_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) float lds[WIDE_RING * C::DW_SLOT_FLOATS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long ntiles = (n + 15) / 16;
+    const int b = blockIdx.x;
+    int l = 1;
+#pragma unroll
+    for (int m = 2; m <= C::NM; ++m) if (b >= args.wg_lo[m - 1]) l = m;
+    const int nwg = args.wg_lo[l] - args.wg_lo[l - 1], bl = b - args.wg_lo[l - 1];
+    const long per = (ntiles + nwg - 1) / nwg;
+    const long rt0 = (long)bl * per, rt1 = rt0 + per < ntiles ? rt0 + per : ntiles;
+    float* slab = slabB + (size_t)b * C::SB_FLOATS;     // every workgroup gets SB_FLOATS (only its layer's part is used)
+    const long r0 = rt0 < ntiles ? rt0 : ntiles, r1 = rt1 > r0 ? rt1 : r0;
+    sfor<1, C::NM + 1>(SFOR_LAMBDA(m) {
+        constexpr int m = SFOR_VAL(m);
+        if (l == m) dw_wide_layer<S, m>(store, ntiles, r0, r1, slab + C::slabB_off(m), lds, wave, lane);
+    });
+}
+
+// sum the partial slabs in fixed order into one dense gradient row (pitch P) for k_update
+template <class S>
+__global__ __launch_bounds__(256) void k_reduce_wide(WideDwArgs args, const float* __restrict__ slabA, int nA,
+                                                      const float* __restrict__ slabB, float* __restrict__ out)
+{
+    using C = WideCfg<S>;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= C::P()) return;
+    int l = 0;
+#pragma unroll
+    for (int m = 1; m < C::NL; ++m) if (j >= C::offW(m)) l = m;
+    const int k = j - C::offW(l);
+    const float* src; int cnt; size_t pitch;
+    if (l == 0) { src = slabA + C::SA_L0 + k; cnt = nA; pitch = C::SA_FLOATS; }
+    else if (l == C::LL) { src = slabA + C::SA_LL + k; cnt = nA; pitch = C::SA_FLOATS; }
+    else { src = slabB + (size_t)args.wg_lo[l - 1] * C::SB_FLOATS + C::slabB_off(l) + k; cnt = args.wg_lo[l] - args.wg_lo[l - 1]; pitch = C::SB_FLOATS; }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 3 < cnt; w += 4) {
+        s0 += src[(size_t)w * pitch]; s1 += src[(size_t)(w + 1) * pitch];
+        s2 += src[(size_t)(w + 2) * pitch]; s3 += src[(size_t)(w + 3) * pitch];
+    }
+    for (; w < cnt; ++w) s0 += src[(size_t)w * pitch];
+    out[j] = (s0 + s1) + (s2 + s3);
+}
+
+// host: flat parameter index -> offsets in the wide weight image
+template <class S>
+static void wide_image_map(int* map) {
+    using C = WideCfg<S>;
+    const int P = C::P();
+    for (int l = 0; l < C::NL; ++l) {
+        const int in = C::in(l), out = C::out(l), ow = C::offW(l);
+        for (int i = 0; i < out; ++i) {
+            const int ri = slot_of(out, i);
+            for (int k = 0; k < in; ++k) {
+                const int ck = slot_of(in, k);
+                int m0, m1 = -1;
+                if (l == 0) {
+                    m0 = C::W0_OFF + (((ri / 16) * C::KG0 + ck / 16) * 64 + ((ck % 16) / 4) * 16 + ri % 16) * 4 + ck % 4;
+                } else if (l == C::LL) {
+                    m0 = C::WL_OFF + i * C::WLP + ck;
+                } else {
+                    m0 = C::chunk_off(C::cF(l) + ck / 16) + ((ri / 16) * 64 + ((ck % 16) / 4) * 16 + ri % 16) * 4 + ck % 4;
+                    m1 = C::chunk_off(C::cB(l) + ri / 16) + ((ck / 16) * 64 + ((ri % 16) / 4) * 16 + ck % 16) * 4 + ri % 4;
+                }
+                map[ow + i * in + k] = m0;
+                map[P + ow + i * in + k] = m1;
+            }
+            map[ow + in * out + i] = l == C::LL ? C::BL_OFF + i : C::boff(l) + ri;
+            map[P + ow + in * out + i] = -1;
+        }
+    }
+}

@@ -17,6 +17,7 @@
 #include "kernels_fast.hpp"
 #include "kernels_fast2.hpp"
 #include "kernels_fast3.hpp"
+#include "wide_api.hpp"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -48,6 +49,9 @@ struct tbnn_ctx {
     bool q_img_valid = false;             // h->qimg mirrors h->q (maintained by k_update)
     // fused-pass workspace
     int grid = 0, pitch = 0; float* slabs = nullptr; double* pstat = nullptr; float* scratch = nullptr;
+    // wide-layer path (kernels_wide.hpp): a fast-kernel variant with its own workspace
+    int wide_id = -1; WidePlan wplan; float* wstore = nullptr; float* wslabA = nullptr; float* wslabB = nullptr;
+    int nslab = 0;                        // gradient slabs k_update reduces (wide: 1, already reduced)
     int* imgmap = nullptr; float* qimg = nullptr; float* qimg_cur = nullptr; int img_floats = 0;   // fast kernel: padded weight images
     size_t scratchPerWG = 0;
     Scal* sc = nullptr; Scal* sc_host = nullptr; Scal* sc_out = nullptr;   // sc_out: device copy for host
@@ -114,7 +118,7 @@ extern "C" int tbnn_destroy(tbnn_handle h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->own_data) { hipFree(h->dX); hipFree(h->dY); }
     float* bufs[] = {h->q_cur, h->g_cur, h->q, h->p, h->g, h->eta, h->p0_inj, h->logu_inj, h->tmp,
-                     h->slabs, h->scratch, h->hyp_ws};
+                     h->slabs, h->scratch, h->hyp_ws, h->wstore, h->wslabA, h->wslabB};
     for (float* b : bufs) if (b) hipFree(b);
     if (h->pstat) hipFree(h->pstat);
     if (h->imgmap) hipFree(h->imgmap);
@@ -176,7 +180,21 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
     h->kernel = TBNN_KERNEL_GENERIC; h->kernel_name = "generic";
     const int want = desc->kernel;
     const int fid = fast_lookup(nd);
-    if (want == TBNN_KERNEL_FAST && fid < 0) return bail(-1, "TBNN_KERNEL_FAST requested but no specialised kernel covers this shape");
+    const int wid = fid < 0 ? wide_lookup(nd) : -1;
+    if (want == TBNN_KERNEL_FAST && fid < 0 && wid < 0) return bail(-1, "TBNN_KERNEL_FAST requested but no specialised kernel covers this shape");
+    if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && wid >= 0) {
+        h->kernel = TBNN_KERNEL_FAST; h->wide_id = wid; h->kernel_name = wide_name(wid);
+        wide_plan(wid, 16, h->wplan);
+        h->img_floats = h->wplan.img_floats;
+        std::vector<int> map(2 * (size_t)nd.P);
+        wide_image_map_id(wid, map.data());
+        HIPB(hipMalloc(&h->imgmap, map.size() * sizeof(int)));
+        HIPB(hipMemcpy(h->imgmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPB(hipMalloc(&h->qimg, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg_cur, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg, 0, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
+    }
     if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && fid >= 0) {
         h->kernel = TBNN_KERNEL_FAST; h->fast_id = fid; h->kernel_name = fast_name(fid);
         // experimental two-waves-per-SIMD variant (kernels_fast2.hpp): measured equal to v1, off by default
@@ -218,8 +236,16 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
     if (h->slabs) { hipFree(h->slabs); h->slabs = nullptr; }
     if (h->pstat) { hipFree(h->pstat); h->pstat = nullptr; }
     if (h->scratch) { hipFree(h->scratch); h->scratch = nullptr; }
+    for (float** b : {&h->wstore, &h->wslabA, &h->wslabB}) if (*b) { hipFree(*b); *b = nullptr; }
     int grid;
-    if (h->kernel == TBNN_KERNEL_FAST) {
+    if (h->wide_id >= 0) {
+        wide_plan(h->wide_id, n, h->wplan);
+        grid = h->wplan.gridA;
+        h->scratchPerWG = 0;
+        HIPCHK(hipMalloc(&h->wstore, h->wplan.store_floats * sizeof(float)));
+        HIPCHK(hipMalloc(&h->wslabA, h->wplan.slabA_floats * sizeof(float)));
+        HIPCHK(hipMalloc(&h->wslabB, h->wplan.slabB_floats * sizeof(float)));
+    } else if (h->kernel == TBNN_KERNEL_FAST) {
         grid = fast_grid(h->fast_id, n);
         h->scratchPerWG = 0;
     } else {
@@ -231,7 +257,9 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
     // tbnn_forward always uses the generic forward kernel: keep a scratch for it
     h->grid = grid;
     h->pitch = (nd.P + 3) & ~3;                  // float4-readable slabs
-    HIPCHK(hipMalloc(&h->slabs, (size_t)grid * h->pitch * sizeof(float)));
+    h->nslab = h->wide_id >= 0 ? 1 : grid;
+    HIPCHK(hipMalloc(&h->slabs, (size_t)h->nslab * h->pitch * sizeof(float)));
+    HIPCHK(hipMemset(h->slabs, 0, (size_t)h->nslab * h->pitch * sizeof(float)));
     HIPCHK(hipMalloc(&h->pstat, (size_t)grid * sizeof(double)));
     return 0;
 }
@@ -312,7 +340,10 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
         hipEventCreate(&a); hipEventCreate(&b); h->pev.push_back(a); h->pev.push_back(b);
         hipEventRecord(a, h->stream);
     }
-    if (h->kernel == TBNN_KERNEL_FAST) {
+    if (h->wide_id >= 0) {
+        if (wide_launch(h->wplan, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->wstore, h->wslabA, h->wslabB, h->pstat, h->slabs))
+            return fail(-2, "wide kernel launch failed");
+    } else if (h->kernel == TBNN_KERNEL_FAST) {
         int rc = h->fast_ver == 3 ? fast3_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat)
                : h->fast_ver == 2 ? fast2_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat)
                                   : fast_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat);
@@ -328,7 +359,7 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
 static void launch_update(tbnn_ctx* h, int mode, float eps, const float* eta, float* q, float* g) {
     const int gx = (h->pitch / 4 + UPD_COLS - 1) / UPD_COLS;
     const bool img = h->kernel == TBNN_KERNEL_FAST && q == h->q;
-    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, h->nd, mode, eps, eta, h->slabs, h->grid,
+    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, h->nd, mode, eps, eta, h->slabs, h->nslab,
                        h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg);
     if (img && (mode == UPD_FIRST || mode == UPD_MID)) h->q_img_valid = true;
 }
@@ -372,7 +403,7 @@ extern "C" int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* et
     int rc = launch_fwd_bwd(h, dq, de);
     if (rc) return rc;
     const int gx = (h->pitch / 4 + UPD_COLS - 1) / UPD_COLS;
-    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, nd, (int)UPD_GRAD_ONLY, 0.f, de, h->slabs, h->grid,
+    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, nd, (int)UPD_GRAD_ONLY, 0.f, de, h->slabs, h->nslab,
                        h->pitch, h->q_cur, h->g_cur, const_cast<float*>(dq), h->p, h->tmp, (const int*)nullptr, (float*)nullptr);
     // EN_TRACE leaves the chain's scalar record alone; stat comes from the slabs
     if (!h->trace || h->trace_cap < 2) {
@@ -592,7 +623,7 @@ extern "C" int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, 
 // [0] start, [1] prologue done, [2] first tile done, [3] tile loop done, [4] end
 extern "C" int tbnn_debug_stamps(tbnn_handle h, uint64_t* out5) {
     NEED(h);
-    if (h->kernel != TBNN_KERNEL_FAST || !h->dX) return fail(-1, "debug_stamps: fast kernel + data required");
+    if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0 || !h->dX) return fail(-1, "debug_stamps: narrow fast kernel + data required");
     HIPCHK(hipSetDevice(h->device));
     unsigned long long* d = nullptr;
     HIPCHK(hipMalloc(&d, 16 * sizeof(unsigned long long)));

@@ -1,0 +1,91 @@
+// Registry + launchers of the wide-layer kernels (kernels_wide.hpp).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#define TBNN_NO_FAST_REGISTRY
+#include "wide_api.hpp"
+#include "kernels_wide.hpp"
+
+using WShapeC4 = Shape<TBNN_ACT_RELU, TBNN_ACT_NONE, false, 10, 200, 200, 200, 1>;      // BASELINE configs[3]
+using WShapeC5 = Shape<TBNN_ACT_RELU, TBNN_ACT_SIGMOID, true, 20, 100, 100, 2>;         // BASELINE configs[4]
+using WShapeT1 = Shape<TBNN_ACT_TANH, TBNN_ACT_NONE, false, 3, 20, 36, 2>;              // test: ragged widths, one middle layer
+using WShapeT2 = Shape<TBNN_ACT_SIGMOID, TBNN_ACT_SIGMOID, true, 20, 32, 16, 48, 2>;    // test: widths % 16 == 0 (ones slot in its own tile)
+
+template <class S>
+static bool wshape_matches(const NetDev& nd) {
+    if (nd.nl != S::NL) return false;
+    if ((nd.lik == TBNN_LIK_BERNOULLI) != S::BERN) return false;
+    for (int l = 0; l < S::NL; ++l)
+        if (nd.in[l] != S::D[l] || nd.out[l] != S::D[l + 1] || nd.act[l] != S::act(l)) return false;
+    return true;
+}
+
+int wide_lookup(const NetDev& nd) {
+    if (wshape_matches<WShapeC4>(nd)) return 0;
+    if (wshape_matches<WShapeC5>(nd)) return 1;
+    if (wshape_matches<WShapeT1>(nd)) return 2;
+    if (wshape_matches<WShapeT2>(nd)) return 3;
+    return -1;
+}
+const char* wide_name(int id) {
+    switch (id) {
+        case 0: return "wide<relu;10,200,200,200,1>";
+        case 1: return "wide<relu,sigmoid,bernoulli;20,100,100,2>";
+        case 2: return "wide<tanh;3,20,36,2>";
+        case 3: return "wide<sigmoid,sigmoid,bernoulli;20,32,16,48,2>";
+        default: return "wide<none>";
+    }
+}
+
+template <class S>
+static void plan_t(long n, WidePlan& p) {
+    using C = WideCfg<S>;
+    const long ntiles = (n + 15) / 16, nblk = (ntiles + WIDE_WAVES - 1) / WIDE_WAVES;
+    p.gridA = (int)std::min<long>(nblk, 256);
+    // 256 dW workgroups shared out over the middle layers in proportion to their MFMA count
+    long tot = 0;
+    for (int l = 1; l <= C::NM; ++l) tot += C::dw_cost(l);
+    int budget = (int)std::min<long>(256, std::max<long>(ntiles, C::NM)), used = 0;
+    p.wg_lo[0] = 0;
+    for (int l = 1; l <= C::NM; ++l) {
+        int w = l == C::NM ? budget - used : (int)std::max<long>(1, (budget * C::dw_cost(l)) / tot);
+        w = std::max(1, w);
+        used += w;
+        p.wg_lo[l] = used;
+    }
+    p.gridB = used;
+    p.store_floats = (size_t)C::store_floats(ntiles);
+    p.slabA_floats = (size_t)p.gridA * C::SA_FLOATS;
+    p.slabB_floats = (size_t)p.gridB * C::SB_FLOATS;
+    p.img_floats = C::IMG_FLOATS;
+}
+
+template <class S>
+static int launch_t(const WidePlan& p, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta, const float* X,
+                    const float* Y, long n, float* store, float* slabA, float* slabB, double* pstat, float* out) {
+    using C = WideCfg<S>;
+    WideDwArgs a;
+    for (int i = 0; i <= TBNN_MAX_LAYERS; ++i) a.wg_lo[i] = p.wg_lo[i];
+    hipLaunchKernelGGL(k_chain_wide<S>, dim3(p.gridA), dim3(WIDE_THREADS), 0, st, nd, qimg, eta, X, Y, n, store, slabA, pstat);
+    hipLaunchKernelGGL(k_dw_wide<S>, dim3(p.gridB), dim3(WIDE_THREADS), 0, st, a, (const float*)store, n, slabB);
+    hipLaunchKernelGGL(k_reduce_wide<S>, dim3((C::P() + 255) / 256), dim3(256), 0, st, a, (const float*)slabA, p.gridA,
+                       (const float*)slabB, out);
+    return 0;
+}
+
+#define WIDE_DISPATCH(id, CALL)                                   \
+    switch (id) {                                                 \
+        case 0: { using S = WShapeC4; CALL; } break;              \
+        case 1: { using S = WShapeC5; CALL; } break;              \
+        case 2: { using S = WShapeT1; CALL; } break;              \
+        case 3: { using S = WShapeT2; CALL; } break;              \
+        default: break;                                           \
+    }
+
+void wide_image_map_id(int id, int* map) { WIDE_DISPATCH(id, wide_image_map<S>(map)); }
+void wide_plan(int id, long n, WidePlan& plan) { plan.id = id; WIDE_DISPATCH(id, plan_t<S>(n, plan)); }
+int wide_launch(const WidePlan& plan, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
+                const float* X, const float* Y, long n, float* store, float* slabA, float* slabB, double* pstat, float* out) {
+    int rc = -1;
+    WIDE_DISPATCH(plan.id, rc = launch_t<S>(plan, st, nd, qimg, eta, X, Y, n, store, slabA, slabB, pstat, out));
+    return rc;
+}

@@ -58,6 +58,9 @@ CASES = {
     "sigmoid_hidden": dict(dims=[4, 7, 3], n=130, act=o.ACT_SIGMOID, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN),
     "elu_hidden": dict(dims=[3, 20, 17, 2], n=333, act=o.ACT_ELU, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN),
     "exp_hidden": dict(dims=[2, 6, 1], n=70, act=o.ACT_EXP, prior=o.PRIOR_CAUCHY, lik=o.LIK_FIXED_GAUSSIAN),
+    # wide-path test shapes (kernels_wide.hpp): ragged widths / widths that are multiples of 16
+    "wide_t1": dict(dims=[3, 20, 36, 2], n=517, act=o.ACT_TANH, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN),
+    "wide_t2": dict(dims=[20, 32, 16, 48, 2], n=1030, act=o.ACT_SIGMOID, prior=o.PRIOR_CAUCHY, lik=o.LIK_BERNOULLI),
 }
 
 
@@ -79,6 +82,25 @@ FAST_CASES = ["c1", "trainreg", "c2_small", "c2_ragged", "sigmoid_hidden"]
 def test_logp_grad_fast(native, case):
     """the shape-specialised MFMA kernel (TBNN_KERNEL_FAST must exist for these shapes)"""
     spec, X, Y, theta, eta = problem(case)
+    check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+
+
+WIDE_CASES = ["wide_t1", "wide_t2", "c5_small", "c4_small"]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_logp_grad_wide(native, case):
+    """the two-kernel wide-layer path (k_chain_wide + k_dw_wide) must cover these shapes"""
+    spec, X, Y, theta, eta = problem(case)
+    ch = make_chain(native, spec, native.KERNEL_FAST)
+    assert ch.kernel_name.startswith("wide<"), ch.kernel_name
+    ch.close()
+    check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 129, 5000 + 3])
+def test_logp_grad_wide_ragged_rows(native, n):
+    spec, X, Y, theta, eta = o.synth_problem([3, 20, 36, 2], n, o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN)
     check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
 
 
