@@ -23,6 +23,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value", "-Wno-unused-result"]
+    flags += os.environ.get("TBNN_EXTRA_FLAGS", "").split()      # diagnostic builds (-DWIDE_DBG_...)
     os.makedirs(OBJ_DIR, exist_ok=True)
     # one hipcc per translation unit, side by side (the two kernel families take ~1 min each)
     procs, objs = [], []

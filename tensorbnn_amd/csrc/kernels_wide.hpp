@@ -41,6 +41,14 @@ __device__ __forceinline__ void sfor(F&& f) {
 #define WIDE_WAVES 4
 #define WIDE_THREADS 256
 #define WIDE_RING 4
+#ifndef WIDE_PD
+#define WIDE_PD 2      // weight-stream register sets: chunk c+2+k (k < WIDE_PD) is in flight while chunk c is consumed
+#endif
+#ifdef WIDE_DBG_NOBARRIER
+#define WIDE_CHUNK_BARRIER() do {} while (0)           // timing experiment (results wrong)
+#else
+#define WIDE_CHUNK_BARRIER() __syncthreads()
+#endif
 
 template <class S>
 struct WideCfg {
@@ -89,9 +97,18 @@ struct WideCfg {
         for (int l = NM; l >= 1; --l) if (c >= cB(l) && c < cB(l) + KG(out(l))) return GB(l);
         return 0;
     }
-    static constexpr int chunk_off(int c) { int o = PERM_FLOATS; for (int k = 0; k < c; ++k) o += chunk_gran(k) * 256; return o; }   // floats
-    static constexpr int IMG_FLOATS = chunk_off(NCH);
     static constexpr int maxGran() { int m = 0; for (int c = 0; c < NCH; ++c) m = chunk_gran(c) > m ? chunk_gran(c) : m; return m; }
+    // 1-KB granule j of chunk c sits at PERM + (j * GS + c) KB: the granules of ONE chunk -- which every workgroup of
+    // the grid reads at about the same time -- are GS KB apart (GS odd), so they spread over the L2 channels
+    // instead of queueing on the one or two channels a contiguous 16-KB chunk maps to (measured: 2.6x on k_chain_wide)
+#ifdef WIDE_DENSE_STREAM
+    static constexpr int gran_off(int c, int j) { int o = PERM_FLOATS; for (int k = 0; k < c; ++k) o += chunk_gran(k) * 256; return o + j * 256; }
+    static constexpr int IMG_FLOATS = gran_off(NCH, 0);
+#else
+    static constexpr int GS = NCH | 1;
+    static constexpr int gran_off(int c, int j) { return PERM_FLOATS + (j * GS + c) * 256; }
+    static constexpr int IMG_FLOATS = PERM_FLOATS + maxGran() * GS * 256;
+#endif
     static constexpr int SLOT_FLOATS = maxGran() * 256;
     static constexpr int NGW = maxGran() / WIDE_WAVES;          // granules per wave per chunk
     static_assert(NCH >= 3, "ring priming assumes >= 3 chunks");
@@ -151,18 +168,39 @@ struct WideRegs {
 
 // top of chunk c: park the chunk fetched one step ago (c+2) in its ring slot, fetch chunk c+3.
 template <class S, int c>
-__device__ __forceinline__ void wide_stage(int base, f32x4 (&stg)[WideCfg<S>::NGW], float* __restrict__ ring,
+__device__ __forceinline__ void wide_stage(int base, f32x4 (&stgs)[WIDE_PD][WideCfg<S>::NGW], float* __restrict__ ring,
                                            const float* __restrict__ img, int wave, int lane) {
     using C = WideCfg<S>;
-    constexpr int cw = (c + 2) % C::NCH, cl = (c + 3) % C::NCH;
+#ifdef WIDE_DBG_NOSTREAM
+    return;                                            // timing experiment: ring never refilled (results wrong)
+#endif
+    constexpr int cw = (c + 2) % C::NCH, cl = (c + 2 + WIDE_PD) % C::NCH;
+    f32x4 (&stg)[C::NGW] = stgs[0];                    // oldest set: chunk c+2
     float* dst = ring + ((base + c + 2) & (WIDE_RING - 1)) * C::SLOT_FLOATS + wave * 256 + lane * 4;
 #pragma unroll
     for (int j = 0; j < C::NGW; ++j)
-        if (j < C::chunk_gran(cw) / WIDE_WAVES) *reinterpret_cast<f32x4*>(dst + j * WIDE_WAVES * 256) = stg[j];
-    const float* src = img + C::chunk_off(cl) + wave * 256 + lane * 4;
+        if (j < C::chunk_gran(cw) / WIDE_WAVES) {
+#ifdef WIDE_DBG_NOPARK
+            asm volatile("" :: "v"(stg[j]));           // timing experiment: loads stay alive, no LDS write (results wrong)
+#else
+            *reinterpret_cast<f32x4*>(dst + j * WIDE_WAVES * 256) = stg[j];
+#endif
+        }
+    // rotate the sets (register renaming inside the unrolled block; plain moves only at the loop back-edge)
+#pragma unroll
+    for (int k = 0; k + 1 < WIDE_PD; ++k)
+#pragma unroll
+        for (int j = 0; j < C::NGW; ++j) stgs[k][j] = stgs[k + 1][j];
+    const float* src = img + C::gran_off(cl, 0) + wave * (C::gran_off(cl, 1) - C::gran_off(cl, 0)) + lane * 4;
 #pragma unroll
     for (int j = 0; j < C::NGW; ++j)
-        if (j < C::chunk_gran(cl) / WIDE_WAVES) stg[j] = *reinterpret_cast<const f32x4*>(src + j * WIDE_WAVES * 256);
+        if (j < C::chunk_gran(cl) / WIDE_WAVES) {
+#ifdef WIDE_DBG_NOLOAD
+            asm volatile("" : "+v"(stgs[WIDE_PD - 1][j]));   // timing experiment: no global load (results wrong)
+#else
+            stgs[WIDE_PD - 1][j] = *reinterpret_cast<const f32x4*>(src + j * WIDE_WAVES * (C::gran_off(cl, 1) - C::gran_off(cl, 0)));
+#endif
+        }
 }
 
 template <class S>
@@ -185,20 +223,23 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     for (int e = tid; e < C::PERM_FLOATS / 4; e += WIDE_THREADS)
         reinterpret_cast<float4*>(lds)[e] = reinterpret_cast<const float4*>(qimg)[e];
     float* ring = lds + C::RING_OFF;
-    f32x4 stg[C::NGW];
+    f32x4 stg[WIDE_PD][C::NGW];
     sfor<0, 2>(SFOR_LAMBDA(c) {
         constexpr int c = SFOR_VAL(c);
 #pragma unroll
         for (int j = 0; j < C::NGW; ++j)
             if (j < C::chunk_gran(c) / WIDE_WAVES)
                 *reinterpret_cast<f32x4*>(ring + c * C::SLOT_FLOATS + (wave + j * WIDE_WAVES) * 256 + lane * 4) =
-                    *reinterpret_cast<const f32x4*>(qimg + C::chunk_off(c) + (wave + j * WIDE_WAVES) * 256 + lane * 4);
+                    *reinterpret_cast<const f32x4*>(qimg + C::gran_off(c, 0) + (wave + j * WIDE_WAVES) * (C::gran_off(c, 1) - C::gran_off(c, 0)) + lane * 4);
     });
+    sfor<0, WIDE_PD>(SFOR_LAMBDA(k) {
+        constexpr int k = SFOR_VAL(k), c = (2 + k) % C::NCH;
 #pragma unroll
-    for (int j = 0; j < C::NGW; ++j)
-        stg[j] = (j < C::chunk_gran(2) / WIDE_WAVES)
-                     ? *reinterpret_cast<const f32x4*>(qimg + C::chunk_off(2) + (wave + j * WIDE_WAVES) * 256 + lane * 4)
-                     : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < C::NGW; ++j)
+            stg[k][j] = (j < C::chunk_gran(c) / WIDE_WAVES)
+                            ? *reinterpret_cast<const f32x4*>(qimg + C::gran_off(c, 0) + (wave + j * WIDE_WAVES) * (C::gran_off(c, 1) - C::gran_off(c, 0)) + lane * 4)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+    });
     float* ximg = lds + C::XIMG_OFF + wave * C::XIMG_FLOATS;
     float* scr = lds + C::SCR_OFF + wave * C::SCR_FLOATS;
     for (int e = lane; e < C::XIMG_FLOATS; e += 64) ximg[e] = 0.f;
@@ -243,6 +284,11 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         const float* img = qimg + opaque0;
         const long tile = blk * WIDE_WAVES + wave;
         const bool tvalid = tile < ntiles;
+#ifdef WIDE_DBG_STORE0
+        const long stile = tile & 1023;                // timing experiment: a_l / delta_l blocks stay in L2 (results wrong)
+#else
+        const long stile = tile;
+#endif
         const bool rvalid = tile * 16 + i16 < n;
         WideRegs<S> T;
         float y[d_out];
@@ -292,7 +338,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                     if (t == os / 16 && g == (os % 16) / 4) v[t][os % 4] = 1.f;
                 }
                 if (tvalid) {
-                    float* p = store + C::act_off(l, ntiles) + ((size_t)tile * C::TA(l)) * 256 + i16 * 16 + g * 4;
+                    float* p = store + C::act_off(l, ntiles) + ((size_t)stile * C::TA(l)) * 256 + i16 * 16 + g * 4;
 #pragma unroll
                     for (int t = 0; t < C::TA(l); ++t) *reinterpret_cast<f32x4*>(p + t * 256) = v[t];
                 }
@@ -312,7 +358,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                 for (int s = 0; s < C::ksteps(C::in(l), kg); ++s)
 #pragma unroll
                     for (int t = 0; t < MT; ++t) acc[t] = mfma16(A[t][s], T.a[kg][s], acc[t]);
-                __syncthreads();
+                WIDE_CHUNK_BARRIER();
             });
 #pragma unroll
             for (int t = 0; t < MT; ++t)
@@ -361,7 +407,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         sfor<0, NM>(SFOR_LAMBDA(li) {
             constexpr int l = NM - SFOR_VAL(li);
             if (tvalid) {       // delta_l -> HBM
-                float* p = store + C::dz_off(l, ntiles) + ((size_t)tile * C::TZ(l)) * 256 + i16 * 16 + g * 4;
+                float* p = store + C::dz_off(l, ntiles) + ((size_t)stile * C::TZ(l)) * 256 + i16 * 16 + g * 4;
 #pragma unroll
                 for (int t = 0; t < C::MAXT; ++t)
                     if (t < C::TZ(l)) *reinterpret_cast<f32x4*>(p + t * 256) = dz[t];
@@ -371,7 +417,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             // current layer's operand stays in registers across the chain
             f32x4 arel[MU];
             {
-                const float* p = store + C::act_off(l, ntiles) + ((size_t)(tvalid ? tile : 0) * C::TA(l)) * 256 + i16 * 16 + g * 4;
+                const float* p = store + C::act_off(l, ntiles) + ((size_t)(tvalid ? stile : 0) * C::TA(l)) * 256 + i16 * 16 + g * 4;
 #pragma unroll
                 for (int u = 0; u < MU; ++u) arel[u] = tvalid ? *reinterpret_cast<const f32x4*>(p + u * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -389,7 +435,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                 for (int s = 0; s < C::ksteps(C::out(l), kg); ++s)
 #pragma unroll
                     for (int u = 0; u < MU; ++u) acc[u] = mfma16(A[u][s], dz[kg][s], acc[u]);
-                __syncthreads();
+                WIDE_CHUNK_BARRIER();
             });
 #pragma unroll
             for (int u = 0; u < MU; ++u)
@@ -664,8 +710,8 @@ static void wide_image_map(int* map) {
                 } else if (l == C::LL) {
                     m0 = C::WL_OFF + i * C::WLP + ck;
                 } else {
-                    m0 = C::chunk_off(C::cF(l) + ck / 16) + ((ri / 16) * 64 + ((ck % 16) / 4) * 16 + ri % 16) * 4 + ck % 4;
-                    m1 = C::chunk_off(C::cB(l) + ri / 16) + ((ck / 16) * 64 + ((ri % 16) / 4) * 16 + ck % 16) * 4 + ri % 4;
+                    m0 = C::gran_off(C::cF(l) + ck / 16, ri / 16) + (((ck % 16) / 4) * 16 + ri % 16) * 4 + ck % 4;
+                    m1 = C::gran_off(C::cB(l) + ri / 16, ck / 16) + (((ri % 16) / 4) * 16 + ck % 16) * 4 + ri % 4;
                 }
                 map[ow + i * in + k] = m0;
                 map[P + ow + i * in + k] = m1;
