@@ -39,8 +39,18 @@ __device__ __forceinline__ void sfor(F&& f) {
 #define SFOR_VAL(name) decltype(name##_)::value
 
 #define WIDE_WAVES 4
+// diagnostic build only (-DWIDE_STAMPS): shader-clock stamps of workgroup 0 / wave 0 during its SECOND block
+#ifdef WIDE_STAMPS
+__device__ unsigned long long g_wide_stamps[256];
+#define WSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (wstamp_on) g_wide_stamps[k] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WSTAMP(k) do { } while (0)
+#endif
 #define WIDE_THREADS 256
 #define WIDE_RING 4
+#ifndef WIDE_DW_PD
+#define WIDE_DW_PD 1   // k_dw_wide: row tiles in flight from HBM beyond the two parked in LDS (measured: 1 = 2 = 4)
+#endif
 #ifndef WIDE_PD
 #define WIDE_PD 2      // weight-stream register sets: chunk c+2+k (k < WIDE_PD) is in flight while chunk c is consumed
 #endif
@@ -95,6 +105,11 @@ struct WideCfg {
     static constexpr int chunk_gran(int c) {
         for (int l = 1; l <= NM; ++l) if (c >= cF(l) && c < cF(l) + KG(in(l))) return GF(l);
         for (int l = NM; l >= 1; --l) if (c >= cB(l) && c < cB(l) + KG(out(l))) return GB(l);
+        return 0;
+    }
+    static constexpr int chunk_tiles(int c) {                  // tiles a wave reads from chunk c (unpadded)
+        for (int l = 1; l <= NM; ++l) if (c >= cF(l) && c < cF(l) + KG(in(l))) return TR(l + 1);
+        for (int l = NM; l >= 1; --l) if (c >= cB(l) && c < cB(l) + KG(out(l))) return TR(l);
         return 0;
     }
     static constexpr int maxGran() { int m = 0; for (int c = 0; c < NCH; ++c) m = chunk_gran(c) > m ? chunk_gran(c) : m; return m; }
@@ -164,7 +179,26 @@ struct WideRegs {
     using C = WideCfg<S>;
     f32x4 a[C::MAXT];               // the current layer's input a_l, D layout: tile t reg j of lane (r, g) = unit 16t+4g+j of row r
     float x[C::KG0 * 4];            // x[4kg+s] = X[row][16kg+4g+s]
+    // relu hidden layers: act'(a_l) for the delta chain is one bit per element (bit 4t+j of word (4t+j)/32),
+    // kept for l = 1..NM -- no activation stays in registers and nothing is re-read
+    unsigned relu[C::NM > 0 ? C::NM : 1][(4 * C::MAXT + 31) / 32];
 };
+
+// a -> relu mask bits of layer slot l (index l-1)
+template <class S, int NT>
+__device__ __forceinline__ void relu_mask_make(unsigned (&m)[(4 * WideCfg<S>::MAXT + 31) / 32], const f32x4* a) {
+#pragma unroll
+    for (int w = 0; w < (4 * WideCfg<S>::MAXT + 31) / 32; ++w) m[w] = 0u;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m[(4 * t + r) / 32] |= (a[t][r] > 0.f) ? (1u << ((4 * t + r) % 32)) : 0u;
+}
+// acc * relu'(a): sign-extended bit field -> all-ones / zero -> AND (2 VALU ops)
+__device__ __forceinline__ float relu_mask_apply(unsigned m, int bit, float acc) {
+    const int keep = __builtin_amdgcn_sbfe(m, bit, 1);
+    return __int_as_float(__float_as_int(acc) & keep);
+}
 
 // top of chunk c: park the chunk fetched one step ago (c+2) in its ring slot, fetch chunk c+3.
 template <class S, int c>
@@ -201,6 +235,16 @@ __device__ __forceinline__ void wide_stage(int base, f32x4 (&stgs)[WIDE_PD][Wide
             stgs[WIDE_PD - 1][j] = *reinterpret_cast<const f32x4*>(src + j * WIDE_WAVES * (C::gran_off(cl, 1) - C::gran_off(cl, 0)));
 #endif
         }
+}
+
+// A operands of chunk c (already visible in its ring slot: parked two chunks earlier, one barrier ago)
+template <class S, int c>
+__device__ __forceinline__ void wide_load_A(int base, f32x4 (&A)[WideCfg<S>::MAXT], const float* __restrict__ ring, int lane) {
+    using C = WideCfg<S>;
+    const float* sl = ring + ((base + c) & (WIDE_RING - 1)) * C::SLOT_FLOATS + lane * 4;
+#pragma unroll
+    for (int t = 0; t < C::MAXT; ++t)
+        if (t < C::chunk_tiles(c % C::NCH)) A[t] = *reinterpret_cast<const f32x4*>(sl + t * 256);
 }
 
 template <class S>
@@ -245,6 +289,12 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     for (int e = lane; e < C::XIMG_FLOATS; e += 64) ximg[e] = 0.f;
     __syncthreads();
     if (g == 0) ximg[i16 * C::PX + d_in] = 1.f;               // ones column of the x image (db_0)
+#ifdef WIDE_APREFETCH
+    // the A operands of chunk c+1 are read at the top of chunk c (double buffer): the LDS latency sits under
+    // chunk c's MFMAs and the barrier's lgkmcnt(0) finds the queue empty
+    f32x4 Acur[C::MAXT];
+    wide_load_A<S, 0>(0, Acur, ring, lane);
+#endif
 
     const float sigma = lik_sigma(nd, eta);
     const float inv_var = 1.f / (sigma * sigma);
@@ -279,6 +329,10 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         // the weight stream is the same for every block: hide the pointer from loop-invariant code motion,
         // or every chunk load is hoisted out of the row loop (and spilled)
+#ifdef WIDE_STAMPS
+        const bool wstamp_on = blockIdx.x == 0 && tid == 0 && blk == (long)blockIdx.x + gridDim.x;
+#endif
+        WSTAMP(0);
         int opaque0 = 0;
         asm volatile("" : "+s"(opaque0));
         const float* img = qimg + opaque0;
@@ -324,8 +378,10 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) T.a[t][r] = actc_fwd<S::act(0)>(acc[t][r]);
+            if constexpr (S::HACT == TBNN_ACT_RELU) relu_mask_make<S, MT>(T.relu[0], T.a);
         }
 
+        WSTAMP(1);
         // ---- middle layers, forward: a_l -> a_{l+1}; a_l (+ ones slot) goes to HBM for k_dw_wide
         sfor<1, NM + 1>(SFOR_LAMBDA(l) {
             constexpr int l = SFOR_VAL(l);
@@ -349,23 +405,35 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             for (int t = 0; t < MT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * t + 4 * g);
             sfor<0, C::KG(C::in(l))>(SFOR_LAMBDA(kg) {
                 constexpr int kg = SFOR_VAL(kg), c = C::cF(l) + kg;
+#ifndef WIDE_APREFETCH
                 wide_stage<S, c>(base, stg, ring, img, wave, lane);
-                const float* sl = ring + ((base + c) & (WIDE_RING - 1)) * C::SLOT_FLOATS + lane * 4;
-                f32x4 A[MT];
-#pragma unroll
-                for (int t = 0; t < MT; ++t) A[t] = *reinterpret_cast<const f32x4*>(sl + t * 256);
+                f32x4 Acur[C::MAXT];
+                wide_load_A<S, c>(base, Acur, ring, lane);
+#else
+                f32x4 Anext[C::MAXT];
+                wide_load_A<S, c + 1>(base, Anext, ring, lane);
+                wide_stage<S, c>(base, stg, ring, img, wave, lane);
+#endif
 #pragma unroll
                 for (int s = 0; s < C::ksteps(C::in(l), kg); ++s)
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) acc[t] = mfma16(A[t][s], T.a[kg][s], acc[t]);
+                    for (int t = 0; t < MT; ++t) acc[t] = mfma16(Acur[t][s], T.a[kg][s], acc[t]);
+                WSTAMP(8 + 2 * c);
                 WIDE_CHUNK_BARRIER();
+                WSTAMP(9 + 2 * c);
+#ifdef WIDE_APREFETCH
+#pragma unroll
+                for (int t = 0; t < C::MAXT; ++t) Acur[t] = Anext[t];
+#endif
             });
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) T.a[t][r] = actc_fwd<S::HACT>(acc[t][r]);
+            if constexpr (S::HACT == TBNN_ACT_RELU && l + 1 <= NM) relu_mask_make<S, MT>(T.relu[l], T.a);
         });
 
+        WSTAMP(2);
         // ---- last layer on the VALU: f_o = b_o + sum_u W[o][u] a_LL[u]
         f32x4 dz[C::MAXT];
         {
@@ -403,6 +471,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             }
         }
 
+        WSTAMP(3);
         // ---- delta chain through the middle layers: delta_l (held in dz) -> delta_{l-1}
         sfor<0, NM>(SFOR_LAMBDA(li) {
             constexpr int l = NM - SFOR_VAL(li);
@@ -415,34 +484,51 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             constexpr int MU = C::TR(l);
             // a_l (for act') comes back from the block this lane stored in the forward pass: nothing but the
             // current layer's operand stays in registers across the chain
-            f32x4 arel[MU];
-            {
-                const float* p = store + C::act_off(l, ntiles) + ((size_t)(tvalid ? stile : 0) * C::TA(l)) * 256 + i16 * 16 + g * 4;
-#pragma unroll
-                for (int u = 0; u < MU; ++u) arel[u] = tvalid ? *reinterpret_cast<const f32x4*>(p + u * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            constexpr bool RELU = S::HACT == TBNN_ACT_RELU;
+            // issue the re-read three chunks before the end of the segment: short live range, latency still covered
+            constexpr int KGB = C::KG(C::out(l)), KG_RELOAD = KGB > 3 ? KGB - 3 : 0;
+            f32x4 arel[RELU ? 1 : MU];
             f32x4 acc[MU];
 #pragma unroll
             for (int u = 0; u < MU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             sfor<0, C::KG(C::out(l))>(SFOR_LAMBDA(kg) {
                 constexpr int kg = SFOR_VAL(kg), c = C::cB(l) + kg;
-                wide_stage<S, c>(base, stg, ring, img, wave, lane);
-                const float* sl = ring + ((base + c) & (WIDE_RING - 1)) * C::SLOT_FLOATS + lane * 4;
-                f32x4 A[MU];
+                if constexpr (!RELU && kg == KG_RELOAD) {
+                    const float* p = store + C::act_off(l, ntiles) + ((size_t)(tvalid ? stile : 0) * C::TA(l)) * 256 + i16 * 16 + g * 4;
 #pragma unroll
-                for (int u = 0; u < MU; ++u) A[u] = *reinterpret_cast<const f32x4*>(sl + u * 256);
+                    for (int u = 0; u < MU; ++u) arel[u] = tvalid ? *reinterpret_cast<const f32x4*>(p + u * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#ifndef WIDE_APREFETCH
+                wide_stage<S, c>(base, stg, ring, img, wave, lane);
+                f32x4 Acur[C::MAXT];
+                wide_load_A<S, c>(base, Acur, ring, lane);
+#else
+                f32x4 Anext[C::MAXT];
+                wide_load_A<S, c + 1>(base, Anext, ring, lane);
+                wide_stage<S, c>(base, stg, ring, img, wave, lane);
+#endif
 #pragma unroll
                 for (int s = 0; s < C::ksteps(C::out(l), kg); ++s)
 #pragma unroll
-                    for (int u = 0; u < MU; ++u) acc[u] = mfma16(A[u][s], dz[kg][s], acc[u]);
+                    for (int u = 0; u < MU; ++u) acc[u] = mfma16(Acur[u][s], dz[kg][s], acc[u]);
+                WSTAMP(8 + 2 * c);
                 WIDE_CHUNK_BARRIER();
+                WSTAMP(9 + 2 * c);
+#ifdef WIDE_APREFETCH
+#pragma unroll
+                for (int u = 0; u < C::MAXT; ++u) Acur[u] = Anext[u];
+#endif
             });
 #pragma unroll
             for (int u = 0; u < MU; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dz[u][r] = actc_bwd_mul<S::act(l - 1)>(acc[u][r], arel[u][r]);
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (RELU) dz[u][r] = relu_mask_apply(T.relu[l - 1][(4 * u + r) / 32], (4 * u + r) % 32, acc[u][r]);
+                    else dz[u][r] = actc_bwd_mul<S::act(l - 1)>(acc[u][r], arel[u][r]);
+                }
         });
 
+        WSTAMP(4);
         // ---- dW_0 += delta_0^T [x, 1]: contraction over the 16 rows (on the lanes): transpose through LDS
         {
             float Bop[C::NT0][4];
@@ -469,6 +555,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                             dW0[t * C::NT0 + nt] = mfma16(Aop[t - b0][s], Bop[nt][s], dW0[t * C::NT0 + nt]);
             }
         }
+        WSTAMP(5);
         base = (base + C::NCH) & (WIDE_RING - 1);
     }
 
@@ -574,33 +661,38 @@ __device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, l
         pm[q] = 4 * QM + pp / TAl; pu[q] = pp % TAl;
     }
     // slot layout: [a blocks 0..TA-1][delta blocks 0..TZ-1], 256 floats each
-    f32x4 stg[NG];
-    auto gload = [&](long rt) {
+    f32x4 stg[WIDE_DW_PD][NG];
+    auto gload = [&](long rt, f32x4 (&dst)[NG]) {
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const int b = wave + 4 * j;
             if (b < SB && rt < rt1) {
                 const float* src = b < TAl ? abase + ((size_t)rt * TAl + b) * 256 : zbase + ((size_t)rt * TZl + (b - TAl)) * 256;
-                stg[j] = *reinterpret_cast<const f32x4*>(src + lane * 4);
-            } else stg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dst[j] = *reinterpret_cast<const f32x4*>(src + lane * 4);
+            } else dst[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto park = [&](int slot) {
+    auto park = [&](int slot, const f32x4 (&src)[NG]) {
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const int b = wave + 4 * j;
-            if (b < SB) *reinterpret_cast<f32x4*>(lds + slot * C::DW_SLOT_FLOATS + b * 256 + lane * 4) = stg[j];
+            if (b < SB) *reinterpret_cast<f32x4*>(lds + slot * C::DW_SLOT_FLOATS + b * 256 + lane * 4) = src[j];
         }
     };
-    // prime: row tiles rt0, rt0+1 parked; rt0+2 in registers
-    gload(rt0); park(0);
-    gload(rt0 + 1); park(1);
-    gload(rt0 + 2);
+    // prime: row tiles rt0, rt0+1 parked; rt0+2 .. rt0+1+PD in registers
+    gload(rt0, stg[0]); park(0, stg[0]);
+    gload(rt0 + 1, stg[0]); park(1, stg[0]);
+#pragma unroll
+    for (int k = 0; k < WIDE_DW_PD; ++k) gload(rt0 + 2 + k, stg[k]);
     __syncthreads();
     int it = 0;
     for (long rt = rt0; rt < rt1; ++rt, ++it) {
-        park((it + 2) & (WIDE_RING - 1));
-        gload(rt + 3);
+        park((it + 2) & (WIDE_RING - 1), stg[0]);
+#pragma unroll
+        for (int k = 0; k + 1 < WIDE_DW_PD; ++k)
+#pragma unroll
+            for (int j = 0; j < NG; ++j) stg[k][j] = stg[k + 1][j];
+        gload(rt + 2 + WIDE_DW_PD, stg[WIDE_DW_PD - 1]);
         const float* sl = lds + (it & (WIDE_RING - 1)) * C::DW_SLOT_FLOATS + lane;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {

@@ -89,3 +89,9 @@ int wide_launch(const WidePlan& plan, hipStream_t st, const NetDev& nd, const fl
     WIDE_DISPATCH(plan.id, rc = launch_t<S>(plan, st, nd, qimg, eta, X, Y, n, store, slabA, slabB, pstat, out));
     return rc;
 }
+
+#ifdef WIDE_STAMPS
+extern "C" int tbnn_debug_wide_stamps(unsigned long long* out256) {
+    return hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_wide_stamps), 256 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

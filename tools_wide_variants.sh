@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev: build diagnostic variants of the wide kernels on the GPU box and time them
-for V in "" "-DWIDE_DENSE_STREAM"; do
+for V in "-DWIDE_DW_PD=1" "-DWIDE_DW_PD=2" "-DWIDE_DW_PD=3 -DWIDE_PD=1" "-DWIDE_DW_PD=4"; do
   echo "=== variant: [$V]"
   TBNN_EXTRA_FLAGS="$V" python3 -m tensorbnn_amd.build --force > /dev/null 2>&1
   cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
