@@ -31,10 +31,21 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DIMS = [5, 50, 50, 50, 1]
-N_ROWS = 100_000
-L = 50
 PEAK_TFLOPS = 157.3
+HYPER_EPS = 2e-5       # configs[4] hyper transition (L_h = 100): scan 3e-5 -> 0.85..0.13, 1e-5 -> 0.99 (tools_hyperprobe.py)
+# --workload: c2 = BASELINE configs[1] (the metric's config, default); c4 / c5 = configs[3] / configs[4]
+# (extra lines for the wide-layer path, same JSON contract)
+WORKLOADS = {
+    "c2": dict(dims=[5, 50, 50, 50, 1], n=100_000, L=50, lik="gaussian", steps=200, warmup=20, cpu_epochs=4, cpu_L=50,
+               text="BASELINE configs[1]: 5->50->50->50->1 Relu BNN (Cauchy DenseLayer, GaussianLikelihood sd=0.1), "
+                    "100k-row fp32 synthetic regression, L=50 leapfrog, 1 chain per GPU"),
+    "c4": dict(dims=[10, 200, 200, 200, 1], n=1_000_000, L=100, lik="gaussian", steps=20, warmup=20, cpu_epochs=1, cpu_L=3,
+               text="BASELINE configs[3]: 10->200->200->200->1 Relu BNN (Cauchy DenseLayer, GaussianLikelihood sd=0.1), "
+                    "1M-row fp32 synthetic regression, L=100 leapfrog, 1 chain per GPU"),
+    "c5": dict(dims=[20, 100, 100, 2], n=500_000, L=50, lik="bernoulli", steps=60, warmup=20, cpu_epochs=1, cpu_L=20,
+               text="BASELINE configs[4]: 20->100->100->2 Relu/Sigmoid BNN (Cauchy DenseLayer, BernoulliLikelihood), "
+                    "500k-row fp32 synthetic classification, L=50 leapfrog + hyper-HMC (L_h=100) per epoch, 1 chain per GPU"),
+}
 
 
 def algorithmic_flops(dims, n):
@@ -45,14 +56,23 @@ def algorithmic_flops(dims, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--eps", type=float, default=None, help="leapfrog step size (default: fixture value)")
     ap.add_argument("--sampling-step", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-epochs", type=int, default=4)
+    ap.add_argument("--cpu-epochs", type=int, default=None)
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fast"])
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    DIMS, N_ROWS, L = wl["dims"], wl["n"], wl["L"]
+    if args.steps is None:
+        args.steps = wl["steps"]
+    if args.warmup is None:
+        args.warmup = wl["warmup"]
+    if args.cpu_epochs is None:
+        args.cpu_epochs = wl["cpu_epochs"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -85,8 +105,10 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
 
-    layers, lik, X, Y, theta0, eta0 = synth_problem(DIMS, N_ROWS)
-    eps_warm, eps = bench_eps("c2")
+    layers, lik, X, Y, theta0, eta0 = synth_problem(
+        DIMS, N_ROWS, likelihood=nat.LIK_BERNOULLI if wl["lik"] == "bernoulli" else nat.LIK_GAUSSIAN)
+    eps_warm, eps = bench_eps(args.workload)
+    hyper = args.workload == "c5"          # configs[4]: hyper-HMC on the priors enabled (network.py:414-471)
     if args.eps is not None:
         eps_warm = eps = args.eps
     kern = {"auto": nat.KERNEL_AUTO, "generic": nat.KERNEL_GENERIC, "fast": nat.KERNEL_FAST}[args.kernel]
@@ -101,13 +123,20 @@ def main():
     sample = torch.empty(ch.P + ch.H, dtype=torch.float32, device="cuda")
     gathered = torch.empty(world * (ch.P + ch.H), dtype=torch.float32, device=cdev) if world > 1 else None
 
+    hyp_acc = []
+
     def run(epochs, profile_stride, eps):
         ch.set_profiling(profile_stride)
         outs = []
         done = 0
         while done < epochs:
             k = min(args.sampling_step, epochs - done)
-            outs += ch.hmc_run(eps, L, k)
+            if hyper:                          # weight transition + hyper transition per epoch (hyper steps not counted)
+                for _ in range(k):
+                    outs.append(ch.hmc_step(eps, L))
+                    hyp_acc.append(ch.hyper_step(HYPER_EPS, 100)["accept_prob"])
+            else:
+                outs += ch.hmc_run(eps, L, k)
             done += k
             if world > 1:                      # checkpoint-time gather over RCCL/xGMI
                 ch.export_sample_device(sample.data_ptr())
@@ -123,6 +152,7 @@ def main():
         torch.cuda.synchronize()
 
     run(args.warmup, 0, eps_warm)
+    hyp_acc.clear()
     fence()
     t0 = time.perf_counter()
     outs = run(args.steps, 10, eps)
@@ -151,7 +181,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch") if args.workload == "c2" else tj.get(args.workload, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = None
@@ -167,34 +198,37 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import c_oracle
             import tbnn_oracle as o
-            spec = o.make_spec(DIMS)
+            bern = wl["lik"] == "bernoulli"
+            spec = o.make_spec(DIMS, likelihood=o.LIK_BERNOULLI if bern else o.LIK_GAUSSIAN,
+                               final_act=o.ACT_SIGMOID if bern else o.ACT_NONE)
             co = c_oracle.COracle(spec, X, Y)
             th = theta0.copy()
             rng = np.random.default_rng(0)
-            co.logp_grad(th, eta0)          # warm the thread pool
+            if args.workload == "c2":
+                co.logp_grad(th, eta0)      # warm the thread pool
             tc = time.perf_counter()
             for e in range(args.cpu_epochs):
                 p0 = rng.standard_normal(ch.P).astype(np.float32)
                 # from the initial state only the warm-up step size is stable; the arithmetic per epoch is identical
-                th, _, _, _, _ = co.hmc_step(th, eta0, eps_warm, L, p0, float(np.log(rng.random())))
+                th, _, _, _, _ = co.hmc_step(th, eta0, eps_warm, wl["cpu_L"], p0, float(np.log(rng.random())))
             tc = time.perf_counter() - tc
-            cpu = {"value": round(args.cpu_epochs * L / tc, 3), "unit": "leapfrog steps/s", "cores": co.threads,
+            cpu = {"value": round(args.cpu_epochs * wl["cpu_L"] / tc, 3), "unit": "leapfrog steps/s", "cores": co.threads,
                    "kind": "port",
-                   "sample": f"{args.cpu_epochs} epochs x L={L} (+1 bootstrap gradient per epoch, as the reference "
-                             f"pays, Q10) of the same 100k-row workload, OpenMP C restatement oracle/c"}
+                   "sample": f"{args.cpu_epochs} epochs x L={wl['cpu_L']} (+1 bootstrap gradient per epoch, as the reference "
+                             f"pays, Q10) of the same {N_ROWS}-row workload, OpenMP C restatement oracle/c"}
         line = {
             "metric": "leapfrog steps/sec (whole node)", "value": round(value, 2), "unit": "leapfrog steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 5->50->50->50->1 Relu BNN (Cauchy DenseLayer, "
-                                   "GaussianLikelihood sd=0.1), 100k-row fp32 synthetic regression, L=50 leapfrog, "
-                                   "1 chain per GPU", "leapfrog_per_step": L, "eps": eps, "eps_warmup": eps_warm,
+            "config": {"workload": wl["text"], "leapfrog_per_step": L, "eps": eps, "eps_warmup": eps_warm,
                        "rows": N_ROWS, "chains": world, "parallelism": f"{world} independent chains",
                        "kernel": ch.kernel_name},
             "accept_ratio": round(acc_prob, 4), "accepted_fraction": round(acc_frac, 4),
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if hyper:
+            line["hyper_accept_ratio"] = round(float(np.mean(hyp_acc)), 4) if hyp_acc else None
         print(json.dumps(line), flush=True)
     ch.close()
     if world > 1:

@@ -14,7 +14,9 @@ from . import _native as nat
 # The chain starts far from equilibrium (log-prob -2.7e7), where only eps <= 4e-5 is stable; the
 # warm-up epochs use the safe value, the timed epochs the value that puts the mean acceptance
 # probability in [0.6, 0.9] (scan recorded in tests/golden/bench_eps.json).
-_BENCH_EPS = {"c2": (2.0e-5, 8.0e-5)}
+_BENCH_EPS = {"c2": (2.0e-5, 8.0e-5),
+              "c4": (1.0e-6, 1.6e-5),      # configs[3], L=100: scan 8e-6 -> 0.93, 1.6e-5 -> 0.86, 3.2e-5 unstable
+              "c5": (5.0e-5, 2.0e-4)}      # configs[4], L=50: scan 1e-4 -> 0.99, 2e-4 -> 0.84, 4e-4 -> 0.75
 
 
 def bench_eps(cfg: str):
