@@ -57,8 +57,11 @@ __device__ unsigned long long g_wide_stamps[256];
 #ifdef WIDE_DBG_NOBARRIER
 #define WIDE_CHUNK_BARRIER() do {} while (0)           // timing experiment (results wrong)
 #else
-#define WIDE_CHUNK_BARRIER() __syncthreads()
+#define WIDE_CHUNK_BARRIER() do { if constexpr (!C::RESIDENT) __syncthreads(); } while (0)
 #endif
+
+// test hook: shapes listed here take the streamed-weights path even though their image would fit in LDS
+template <class S> struct WideForceStream { static constexpr bool value = false; };
 
 template <class S>
 struct WideCfg {
@@ -116,25 +119,26 @@ struct WideCfg {
     // 1-KB granule j of chunk c sits at PERM + (j * GS + c) KB: the granules of ONE chunk -- which every workgroup of
     // the grid reads at about the same time -- are GS KB apart (GS odd), so they spread over the L2 channels
     // instead of queueing on the one or two channels a contiguous 16-KB chunk maps to (measured: 2.6x on k_chain_wide)
-#ifdef WIDE_DENSE_STREAM
-    static constexpr int gran_off(int c, int j) { int o = PERM_FLOATS; for (int k = 0; k < c; ++k) o += chunk_gran(k) * 256; return o + j * 256; }
-    static constexpr int IMG_FLOATS = gran_off(NCH, 0);
-#else
+    static constexpr int PX = 16 * NT0 + 4;                     // x image pitch
+    static constexpr int XIMG_FLOATS = 16 * PX;
+    static constexpr int DZB = 4, PZ = 16 * DZB + 4;            // delta_0 transposed DZB tiles at a time
+    static constexpr int SCR_FLOATS = 16 * PZ;
+    // RESIDENT: the whole image (dense, unpadded chunks) fits in LDS next to the per-wave scratch -> no stream, no
+    // ring, no barriers in the row loop (configs[4]: 100-wide layers); otherwise the 4-slot ring (configs[3])
+    static constexpr int dense_off(int c) { int o = PERM_FLOATS; for (int k = 0; k < c; ++k) o += chunk_tiles(k) * 256; return o; }
+    static constexpr bool RESIDENT = !WideForceStream<S>::value &&
+                                     (dense_off(NCH) + WIDE_WAVES * (XIMG_FLOATS + SCR_FLOATS)) * 4 + 64 <= 160 * 1024;
     static constexpr int GS = NCH | 1;
-    static constexpr int gran_off(int c, int j) { return PERM_FLOATS + (j * GS + c) * 256; }
-    static constexpr int IMG_FLOATS = PERM_FLOATS + maxGran() * GS * 256;
-#endif
+    static constexpr int gran_off(int c, int j) { return RESIDENT ? dense_off(c) + j * 256 : PERM_FLOATS + (j * GS + c) * 256; }
+    static constexpr int gran_step(int c) { return gran_off(c, 1) - gran_off(c, 0); }
+    static constexpr int IMG_FLOATS = RESIDENT ? dense_off(NCH) : PERM_FLOATS + maxGran() * GS * 256;
     static constexpr int SLOT_FLOATS = maxGran() * 256;
     static constexpr int NGW = maxGran() / WIDE_WAVES;          // granules per wave per chunk
     static_assert(NCH >= 3, "ring priming assumes >= 3 chunks");
     // ---- LDS layout (floats)
     static constexpr int RING_OFF = PERM_FLOATS;
-    static constexpr int PX = 16 * NT0 + 4;                     // x image pitch
-    static constexpr int XIMG_OFF = RING_OFF + WIDE_RING * SLOT_FLOATS;
-    static constexpr int XIMG_FLOATS = 16 * PX;
-    static constexpr int DZB = 4, PZ = 16 * DZB + 4;            // delta_0 transposed DZB tiles at a time
+    static constexpr int XIMG_OFF = RESIDENT ? IMG_FLOATS : RING_OFF + WIDE_RING * SLOT_FLOATS;
     static constexpr int SCR_OFF = XIMG_OFF + WIDE_WAVES * XIMG_FLOATS;
-    static constexpr int SCR_FLOATS = 16 * PZ;
     static constexpr int LDS_FLOATS = SCR_OFF + WIDE_WAVES * SCR_FLOATS;
     // ---- parameters
     static constexpr int offW(int l) { int p = 0; for (int m = 0; m < l; ++m) p += in(m) * out(m) + out(m); return p; }
@@ -208,6 +212,7 @@ __device__ __forceinline__ void wide_stage(int base, f32x4 (&stgs)[WIDE_PD][Wide
 #ifdef WIDE_DBG_NOSTREAM
     return;                                            // timing experiment: ring never refilled (results wrong)
 #endif
+    if constexpr (C::RESIDENT) return;
     constexpr int cw = (c + 2) % C::NCH, cl = (c + 2 + WIDE_PD) % C::NCH;
     f32x4 (&stg)[C::NGW] = stgs[0];                    // oldest set: chunk c+2
     float* dst = ring + ((base + c + 2) & (WIDE_RING - 1)) * C::SLOT_FLOATS + wave * 256 + lane * 4;
@@ -225,14 +230,14 @@ __device__ __forceinline__ void wide_stage(int base, f32x4 (&stgs)[WIDE_PD][Wide
     for (int k = 0; k + 1 < WIDE_PD; ++k)
 #pragma unroll
         for (int j = 0; j < C::NGW; ++j) stgs[k][j] = stgs[k + 1][j];
-    const float* src = img + C::gran_off(cl, 0) + wave * (C::gran_off(cl, 1) - C::gran_off(cl, 0)) + lane * 4;
+    const float* src = img + C::gran_off(cl, 0) + wave * C::gran_step(cl) + lane * 4;
 #pragma unroll
     for (int j = 0; j < C::NGW; ++j)
         if (j < C::chunk_gran(cl) / WIDE_WAVES) {
 #ifdef WIDE_DBG_NOLOAD
             asm volatile("" : "+v"(stgs[WIDE_PD - 1][j]));   // timing experiment: no global load (results wrong)
 #else
-            stgs[WIDE_PD - 1][j] = *reinterpret_cast<const f32x4*>(src + j * WIDE_WAVES * (C::gran_off(cl, 1) - C::gran_off(cl, 0)));
+            stgs[WIDE_PD - 1][j] = *reinterpret_cast<const f32x4*>(src + j * WIDE_WAVES * C::gran_step(cl));
 #endif
         }
 }
@@ -241,7 +246,8 @@ __device__ __forceinline__ void wide_stage(int base, f32x4 (&stgs)[WIDE_PD][Wide
 template <class S, int c>
 __device__ __forceinline__ void wide_load_A(int base, f32x4 (&A)[WideCfg<S>::MAXT], const float* __restrict__ ring, int lane) {
     using C = WideCfg<S>;
-    const float* sl = ring + ((base + c) & (WIDE_RING - 1)) * C::SLOT_FLOATS + lane * 4;
+    // RESIDENT: `ring` is the LDS base and the chunk sits at its image offset
+    const float* sl = (C::RESIDENT ? ring + C::gran_off(c % C::NCH, 0) : ring + ((base + c) & (WIDE_RING - 1)) * C::SLOT_FLOATS) + lane * 4;
 #pragma unroll
     for (int t = 0; t < C::MAXT; ++t)
         if (t < C::chunk_tiles(c % C::NCH)) A[t] = *reinterpret_cast<const f32x4*>(sl + t * 256);
@@ -264,24 +270,24 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     const long nblk = (ntiles + WIDE_WAVES - 1) / WIDE_WAVES;
 
     // ---- prologue: permanent image -> LDS; prime the ring (chunks 0, 1 in slots 0, 1; chunk 2 in registers)
-    for (int e = tid; e < C::PERM_FLOATS / 4; e += WIDE_THREADS)
+    for (int e = tid; e < (C::RESIDENT ? C::IMG_FLOATS : C::PERM_FLOATS) / 4; e += WIDE_THREADS)
         reinterpret_cast<float4*>(lds)[e] = reinterpret_cast<const float4*>(qimg)[e];
-    float* ring = lds + C::RING_OFF;
+    float* ring = C::RESIDENT ? lds : lds + C::RING_OFF;
     f32x4 stg[WIDE_PD][C::NGW];
     sfor<0, 2>(SFOR_LAMBDA(c) {
         constexpr int c = SFOR_VAL(c);
 #pragma unroll
         for (int j = 0; j < C::NGW; ++j)
-            if (j < C::chunk_gran(c) / WIDE_WAVES)
+            if (!C::RESIDENT && j < C::chunk_gran(c) / WIDE_WAVES)
                 *reinterpret_cast<f32x4*>(ring + c * C::SLOT_FLOATS + (wave + j * WIDE_WAVES) * 256 + lane * 4) =
-                    *reinterpret_cast<const f32x4*>(qimg + C::gran_off(c, 0) + (wave + j * WIDE_WAVES) * (C::gran_off(c, 1) - C::gran_off(c, 0)) + lane * 4);
+                    *reinterpret_cast<const f32x4*>(qimg + C::gran_off(c, 0) + (wave + j * WIDE_WAVES) * C::gran_step(c) + lane * 4);
     });
     sfor<0, WIDE_PD>(SFOR_LAMBDA(k) {
         constexpr int k = SFOR_VAL(k), c = (2 + k) % C::NCH;
 #pragma unroll
         for (int j = 0; j < C::NGW; ++j)
-            stg[k][j] = (j < C::chunk_gran(c) / WIDE_WAVES)
-                            ? *reinterpret_cast<const f32x4*>(qimg + C::gran_off(c, 0) + (wave + j * WIDE_WAVES) * (C::gran_off(c, 1) - C::gran_off(c, 0)) + lane * 4)
+            stg[k][j] = (!C::RESIDENT && j < C::chunk_gran(c) / WIDE_WAVES)
+                            ? *reinterpret_cast<const f32x4*>(qimg + C::gran_off(c, 0) + (wave + j * WIDE_WAVES) * C::gran_step(c) + lane * 4)
                             : f32x4{0.f, 0.f, 0.f, 0.f};
     });
     float* ximg = lds + C::XIMG_OFF + wave * C::XIMG_FLOATS;
@@ -759,30 +765,38 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     });
 }
 
-// sum the partial slabs in fixed order into one dense gradient row (pitch P) for k_update
+// sum the partial slabs in fixed order into one dense gradient row (pitch P) for k_update:
+// 64 parameters x 4 slab groups per block, fixed-order combine (deterministic)
 template <class S>
 __global__ __launch_bounds__(256) void k_reduce_wide(WideDwArgs args, const float* __restrict__ slabA, int nA,
                                                       const float* __restrict__ slabB, float* __restrict__ out)
 {
     using C = WideCfg<S>;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= C::P()) return;
-    int l = 0;
+    __shared__ float part[4][64];
+    const int x = threadIdx.x, y = threadIdx.y;
+    const int j = blockIdx.x * 64 + x;
+    float tot = 0.f;
+    if (j < C::P()) {
+        int l = 0;
 #pragma unroll
-    for (int m = 1; m < C::NL; ++m) if (j >= C::offW(m)) l = m;
-    const int k = j - C::offW(l);
-    const float* src; int cnt; size_t pitch;
-    if (l == 0) { src = slabA + C::SA_L0 + k; cnt = nA; pitch = C::SA_FLOATS; }
-    else if (l == C::LL) { src = slabA + C::SA_LL + k; cnt = nA; pitch = C::SA_FLOATS; }
-    else { src = slabB + (size_t)args.wg_lo[l - 1] * C::SB_FLOATS + C::slabB_off(l) + k; cnt = args.wg_lo[l] - args.wg_lo[l - 1]; pitch = C::SB_FLOATS; }
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 3 < cnt; w += 4) {
-        s0 += src[(size_t)w * pitch]; s1 += src[(size_t)(w + 1) * pitch];
-        s2 += src[(size_t)(w + 2) * pitch]; s3 += src[(size_t)(w + 3) * pitch];
+        for (int m = 1; m < C::NL; ++m) if (j >= C::offW(m)) l = m;
+        const int k = j - C::offW(l);
+        const float* src; int cnt; size_t pitch;
+        if (l == 0) { src = slabA + C::SA_L0 + k; cnt = nA; pitch = C::SA_FLOATS; }
+        else if (l == C::LL) { src = slabA + C::SA_LL + k; cnt = nA; pitch = C::SA_FLOATS; }
+        else { src = slabB + (size_t)args.wg_lo[l - 1] * C::SB_FLOATS + C::slabB_off(l) + k; cnt = args.wg_lo[l] - args.wg_lo[l - 1]; pitch = C::SB_FLOATS; }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int w = y;
+        for (; w + 12 < cnt; w += 16) {
+            s0 += src[(size_t)w * pitch]; s1 += src[(size_t)(w + 4) * pitch];
+            s2 += src[(size_t)(w + 8) * pitch]; s3 += src[(size_t)(w + 12) * pitch];
+        }
+        for (; w < cnt; w += 4) s0 += src[(size_t)w * pitch];
+        tot = (s0 + s1) + (s2 + s3);
     }
-    for (; w < cnt; ++w) s0 += src[(size_t)w * pitch];
-    out[j] = (s0 + s1) + (s2 + s3);
+    part[y][x] = tot;
+    __syncthreads();
+    if (y == 0 && j < C::P()) out[j] = (part[0][x] + part[1][x]) + (part[2][x] + part[3][x]);
 }
 
 // host: flat parameter index -> offsets in the wide weight image

@@ -10,6 +10,8 @@ using WShapeC5 = Shape<TBNN_ACT_RELU, TBNN_ACT_SIGMOID, true, 20, 100, 100, 2>; 
 using WShapeT1 = Shape<TBNN_ACT_TANH, TBNN_ACT_NONE, false, 3, 20, 36, 2>;              // test: ragged widths, one middle layer
 using WShapeT2 = Shape<TBNN_ACT_SIGMOID, TBNN_ACT_SIGMOID, true, 20, 32, 16, 48, 2>;    // test: widths % 16 == 0 (ones slot in its own tile)
 
+template <> struct WideForceStream<WShapeT2> { static constexpr bool value = true; };   // keeps the ring path under the small-shape tests
+
 template <class S>
 static bool wshape_matches(const NetDev& nd) {
     if (nd.nl != S::NL) return false;
@@ -67,7 +69,7 @@ static int launch_t(const WidePlan& p, hipStream_t st, const NetDev& nd, const f
     for (int i = 0; i <= TBNN_MAX_LAYERS; ++i) a.wg_lo[i] = p.wg_lo[i];
     hipLaunchKernelGGL(k_chain_wide<S>, dim3(p.gridA), dim3(WIDE_THREADS), 0, st, nd, qimg, eta, X, Y, n, store, slabA, pstat);
     hipLaunchKernelGGL(k_dw_wide<S>, dim3(p.gridB), dim3(WIDE_THREADS), 0, st, a, (const float*)store, n, slabB);
-    hipLaunchKernelGGL(k_reduce_wide<S>, dim3((C::P() + 255) / 256), dim3(256), 0, st, a, (const float*)slabA, p.gridA,
+    hipLaunchKernelGGL(k_reduce_wide<S>, dim3((C::P() + 63) / 64), dim3(64, 4), 0, st, a, (const float*)slabA, p.gridA,
                        (const float*)slabB, out);
     return 0;
 }
