@@ -153,6 +153,29 @@ int tbnn_set_epoch(tbnn_handle h, uint32_t epoch);
  * chain's stream (fills fwdbwd_us); stride <= 0 turns it off */
 int tbnn_set_profiling(tbnn_handle h, int stride);
 
+/* ---- RCCL over xGMI.  librccl.so is resolved with dlopen on the first
+ * tbnn_comm_* call: single-GPU use never loads it.  One communicator per chain handle; every
+ * collective is enqueued on the chain's own stream (no host sync inside a transition). ---- */
+#define TBNN_COMM_ID_BYTES 128
+typedef struct tbnn_comm* tbnn_comm_handle;
+/* rank 0 draws the id (ncclGetUniqueId); the host hands it to the other ranks (torch.distributed
+ * broadcast, MPI, a file ...) */
+int tbnn_comm_unique_id(unsigned char id[TBNN_COMM_ID_BYTES]);
+/* ncclCommInitRank on the chain's device; collective over all `world` ranks */
+int tbnn_comm_create(tbnn_handle h, int world, int rank, const unsigned char id[TBNN_COMM_ID_BYTES],
+                     tbnn_comm_handle* out);
+int tbnn_comm_destroy(tbnn_comm_handle c);
+/* checkpoint-time gather (network.py:610-663 writes one chain; with N chains every rank ends up
+ * with all N samples): all-gather of (theta, eta) = P+H floats per rank.  d_out: device buffer of
+ * world*(P+H) floats or NULL (library-owned buffer); host_out: world*(P+H) floats or NULL. */
+int tbnn_gather_samples(tbnn_handle h, tbnn_comm_handle c, float* d_out, float* host_out);
+/* row-sharded single chain: the ranks of `c` hold disjoint row blocks of (X, Y) and identical
+ * theta / eta / seed / chain_id; the data-term gradient (P floats) and the likelihood statistic are
+ * all-reduced after every fused pass, so every rank takes the same leapfrog trajectory and the same
+ * Metropolis decision.  n_total = rows over all ranks (normaliser of the Gaussian likelihood).
+ * c == NULL switches back to the unsharded chain. */
+int tbnn_set_row_shard(tbnn_handle h, tbnn_comm_handle c, int64_t n_total);
+
 /* ---- (eps, L) adapter: paramAdapter (tensorBNN/paramAdapter.py:11-292), host C++ ---- */
 typedef struct tbnn_adapter* tbnn_adapter_handle;
 /* paramAdapter.__init__ :39-93 (k = burnin/averagingSteps, network.py:229-230) */

@@ -75,6 +75,11 @@ SYMBOLS = [
     ("tbnn_debug_draw", C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_int32, _fp, _fp]),
     ("tbnn_set_epoch", C.c_int, [_H, C.c_uint32]),
     ("tbnn_set_profiling", C.c_int, [_H, C.c_int]),
+    ("tbnn_comm_unique_id", C.c_int, [C.POINTER(C.c_ubyte)]),
+    ("tbnn_comm_create", C.c_int, [_H, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(_H)]),
+    ("tbnn_comm_destroy", C.c_int, [_H]),
+    ("tbnn_gather_samples", C.c_int, [_H, _H, C.c_void_p, _fp]),
+    ("tbnn_set_row_shard", C.c_int, [_H, _H, C.c_int64]),
     ("tbnn_adapter_create", C.c_int, [C.c_float, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_double, C.c_float, C.c_float, C.c_int32,
                                       C.c_uint64, C.POINTER(_H)]),
@@ -244,6 +249,48 @@ class Chain:
 
     def set_profiling(self, stride: int):
         _check(lib.tbnn_set_profiling(self._h, int(stride)))
+
+    def gather_samples(self, comm: "Comm", d_out_ptr: int = 0) -> np.ndarray:
+        """RCCL all-gather of (theta, eta) over the communicator: returns [world, P+H]"""
+        out = np.empty((comm.world, self.P + self.H), dtype=np.float32)
+        _check(lib.tbnn_gather_samples(self._h, comm._c, C.c_void_p(d_out_ptr) if d_out_ptr else None, _p(out)))
+        return out
+
+    def set_row_shard(self, comm: Optional["Comm"], n_total: int = 0):
+        """row-sharded single chain: this rank's set_data rows are one block of n_total rows (None: back to unsharded)"""
+        _check(lib.tbnn_set_row_shard(self._h, comm._c if comm is not None else None, int(n_total)))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    _check(lib.tbnn_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """tbnn_comm_* : an RCCL communicator bound to a chain's device and stream (librccl.so is dlopen'ed on first use)"""
+
+    def __init__(self, chain: "Chain", world: int, rank: int, uid: bytes):
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError("uid must be COMM_ID_BYTES long")
+        self.world, self.rank = int(world), int(rank)
+        self._c = _H()
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(uid)
+        _check(lib.tbnn_comm_create(chain._h, self.world, self.rank, buf, C.byref(self._c)))
+
+    def close(self):
+        if getattr(self, "_c", None):
+            lib.tbnn_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Adapter:

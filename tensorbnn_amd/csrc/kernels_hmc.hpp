@@ -124,6 +124,27 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     }
 }
 
+// row-sharded chains: sum the per-workgroup slabs into ONE dense row (the all-reduce operand);
+// 64 parameters x 4 slab groups per block, fixed order
+__global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slabs, int nslab, int pitch, int P,
+                                                      float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int x = threadIdx.x, y = threadIdx.y, j = blockIdx.x * 64 + x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < P) {
+        const float* src = slabs + j;
+        int w = y;
+        for (; w + 12 < nslab; w += 16) {
+            s0 += src[(size_t)w * pitch]; s1 += src[(size_t)(w + 4) * pitch];
+            s2 += src[(size_t)(w + 8) * pitch]; s3 += src[(size_t)(w + 12) * pitch];
+        }
+        for (; w < nslab; w += 4) s0 += src[(size_t)w * pitch];
+    }
+    part[y][x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (y == 0 && j < P) out[j] = (part[0][x] + part[1][x]) + (part[2][x] + part[3][x]);
+}
+
 // scatter a flat theta into the padded weight image (bootstrap / tbnn_logp_grad)
 __global__ __launch_bounds__(256) void k_make_image(int P, const float* __restrict__ q,
                                                     const int* __restrict__ imgmap, float* __restrict__ qimg) {

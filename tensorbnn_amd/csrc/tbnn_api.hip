@@ -2,6 +2,8 @@
 // One handle = one chain = one device + one stream; a whole transition is
 // enqueued without a host round-trip and one small record is read back.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +33,15 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define NEED(h)                                                                                \
     do { if (!(h)) return fail(-1, "null handle"); } while (0)
 
+#define PSTAT_CAP 512                     // entries of the per-workgroup statistic buffer (>= any grid)
+
+struct tbnn_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+    int device = 0;
+    float* gbuf = nullptr; size_t gbuf_floats = 0;     // library-owned gather buffer
+};
+
 struct tbnn_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -52,6 +63,8 @@ struct tbnn_ctx {
     // wide-layer path (kernels_wide.hpp): a fast-kernel variant with its own workspace
     int wide_id = -1; WidePlan wplan; float* wstore = nullptr; float* wslabA = nullptr; float* wslabB = nullptr;
     int nslab = 0;                        // gradient slabs k_update reduces (wide: 1, already reduced)
+    // row-sharded chain (tbnn_set_row_shard): all-reduce of the dense data-term gradient row + statistic
+    tbnn_comm* shard = nullptr; long n_total = 0; float* grow = nullptr; double* pstat_red = nullptr;
     int* imgmap = nullptr; float* qimg = nullptr; float* qimg_cur = nullptr; int img_floats = 0;   // fast kernel: padded weight images
     size_t scratchPerWG = 0;
     Scal* sc = nullptr; Scal* sc_host = nullptr; Scal* sc_out = nullptr;   // sc_out: device copy for host
@@ -118,9 +131,10 @@ extern "C" int tbnn_destroy(tbnn_handle h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->own_data) { hipFree(h->dX); hipFree(h->dY); }
     float* bufs[] = {h->q_cur, h->g_cur, h->q, h->p, h->g, h->eta, h->p0_inj, h->logu_inj, h->tmp,
-                     h->slabs, h->scratch, h->hyp_ws, h->wstore, h->wslabA, h->wslabB};
+                     h->slabs, h->scratch, h->hyp_ws, h->wstore, h->wslabA, h->wslabB, h->grow};
     for (float* b : bufs) if (b) hipFree(b);
     if (h->pstat) hipFree(h->pstat);
+    if (h->pstat_red) hipFree(h->pstat_red);
     if (h->imgmap) hipFree(h->imgmap);
     if (h->qimg) hipFree(h->qimg);
     if (h->qimg_cur) hipFree(h->qimg_cur);
@@ -260,7 +274,14 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
     h->nslab = h->wide_id >= 0 ? 1 : grid;
     HIPCHK(hipMalloc(&h->slabs, (size_t)h->nslab * h->pitch * sizeof(float)));
     HIPCHK(hipMemset(h->slabs, 0, (size_t)h->nslab * h->pitch * sizeof(float)));
-    HIPCHK(hipMalloc(&h->pstat, (size_t)grid * sizeof(double)));
+    if (grid > PSTAT_CAP) return fail(-2, "grid exceeds PSTAT_CAP");
+    HIPCHK(hipMalloc(&h->pstat, (size_t)PSTAT_CAP * sizeof(double)));
+    HIPCHK(hipMemset(h->pstat, 0, (size_t)PSTAT_CAP * sizeof(double)));      // entries >= grid stay zero
+    if (h->pstat_red) { hipFree(h->pstat_red); h->pstat_red = nullptr; }
+    HIPCHK(hipMalloc(&h->pstat_red, (size_t)PSTAT_CAP * sizeof(double)));
+    HIPCHK(hipMemset(h->pstat_red, 0, (size_t)PSTAT_CAP * sizeof(double)));
+    if (h->grow) { hipFree(h->grow); h->grow = nullptr; }
+    HIPCHK(hipMalloc(&h->grow, (size_t)h->pitch * sizeof(float)));
     return 0;
 }
 
@@ -322,6 +343,110 @@ extern "C" int tbnn_get_hypers(tbnn_handle h, float* eta) {
     return 0;
 }
 
+// ---- RCCL, resolved at run time (no link-time dependency: single-GPU users never load it) ----
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+    if (g_rccl.lib) return 0;
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(-5, std::string("cannot load librccl.so: ") + dlerror());
+    RcclApi a; a.lib = lib;
+#define RSYM(field, name) do { *(void**)(&a.field) = dlsym(lib, name); if (!a.field) return fail(-5, std::string("librccl.so lacks ") + name); } while (0)
+    RSYM(GetUniqueId, "ncclGetUniqueId"); RSYM(CommInitRank, "ncclCommInitRank"); RSYM(CommDestroy, "ncclCommDestroy");
+    RSYM(AllReduce, "ncclAllReduce"); RSYM(AllGather, "ncclAllGather"); RSYM(GetErrorString, "ncclGetErrorString");
+#undef RSYM
+    g_rccl = a;
+    return 0;
+}
+#define NCCLCHK(expr)                                                                          \
+    do {                                                                                       \
+        ncclResult_t r_ = (expr);                                                              \
+        if (r_ != ncclSuccess) return fail(-5, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) == TBNN_COMM_ID_BYTES, "ncclUniqueId size");
+
+extern "C" int tbnn_comm_unique_id(unsigned char id[TBNN_COMM_ID_BYTES]) {
+    if (!id) return fail(-1, "null id");
+    int rc = rccl_load(); if (rc) return rc;
+    ncclUniqueId u;
+    NCCLCHK(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, TBNN_COMM_ID_BYTES);
+    return 0;
+}
+extern "C" int tbnn_comm_create(tbnn_handle h, int world, int rank, const unsigned char id[TBNN_COMM_ID_BYTES],
+                                tbnn_comm_handle* out) {
+    NEED(h);
+    if (!out || !id) return fail(-1, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(-1, "bad world/rank");
+    int rc = rccl_load(); if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    ncclUniqueId u; memcpy(&u, id, TBNN_COMM_ID_BYTES);
+    tbnn_comm* c = new (std::nothrow) tbnn_comm();
+    if (!c) return fail(-4, "out of host memory");
+    c->world = world; c->rank = rank; c->device = h->device;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) { delete c; return fail(-5, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
+    *out = c;
+    return 0;
+}
+extern "C" int tbnn_comm_destroy(tbnn_comm_handle c) {
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    if (c->gbuf) hipFree(c->gbuf);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    delete c;
+    return 0;
+}
+extern "C" int tbnn_gather_samples(tbnn_handle h, tbnn_comm_handle c, float* d_out, float* host_out) {
+    NEED(h); if (!c) return fail(-1, "null communicator");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t per = (size_t)h->nd.P + h->nd.H, tot = per * c->world;
+    if (!d_out) {
+        if (c->gbuf_floats < tot) {
+            if (c->gbuf) hipFree(c->gbuf);
+            c->gbuf = nullptr; c->gbuf_floats = 0;
+            HIPCHK(hipMalloc(&c->gbuf, tot * sizeof(float))); c->gbuf_floats = tot;
+        }
+        d_out = c->gbuf;
+    }
+    // (theta, eta) staged contiguously in tmp (P+H floats)
+    HIPCHK(hipMemcpyAsync(h->tmp, h->q_cur, (size_t)h->nd.P * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->tmp + h->nd.P, h->eta, (size_t)h->nd.H * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    NCCLCHK(g_rccl.AllGather(h->tmp, d_out, per, ncclFloat, c->comm, h->stream));
+    if (host_out) HIPCHK(hipMemcpyAsync(host_out, d_out, tot * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int tbnn_set_row_shard(tbnn_handle h, tbnn_comm_handle c, int64_t n_total) {
+    NEED(h);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (c && n_total < 1) return fail(-1, "n_total must be >= 1");
+    h->shard = c; h->n_total = c ? (long)n_total : 0;
+    h->cur_valid = false;
+    return 0;
+}
+// rows that normalise the likelihood / entries of the statistic buffer to sum
+static inline long rows_total(const tbnn_ctx* h) { return h->shard ? h->n_total : h->n; }
+static inline int stat_entries(const tbnn_ctx* h) { return h->shard ? PSTAT_CAP : h->grid; }
+// local statistic buffer: entries >= grid stay zero; the all-reduced copy is separate (ranks may have different grids)
+static inline const double* stat_ptr(const tbnn_ctx* h) { return h->shard ? h->pstat_red : h->pstat; }
+// the gradient slabs k_update reduces
+static inline const float* grad_slabs(const tbnn_ctx* h) { return (h->shard && h->wide_id < 0) ? h->grow : h->slabs; }
+static inline int grad_nslab(const tbnn_ctx* h) { return h->shard ? 1 : h->nslab; }
+
 // ---- launch helpers (all on h->stream, no sync) ----
 // q == h->q: the leapfrog position, whose padded image h->qimg is maintained by k_update;
 // any other q gets its image built here (h->qimg_cur).
@@ -352,6 +477,17 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
         hipLaunchKernelGGL(k_fwd_bwd_generic, dim3(h->grid), dim3(GEN_RB), 0, h->stream, h->nd, q, eta, h->dX,
                            h->dY, h->n, h->scratch, h->scratchPerWG, h->slabs, h->pitch, h->pstat);
     }
+    if (h->shard) {
+        // dense data-term gradient row (the wide path already has one) + statistic, summed over the ranks in place
+        float* row = h->slabs;
+        if (h->wide_id < 0) {
+            hipLaunchKernelGGL(k_slab_reduce, dim3((h->nd.P + 63) / 64), dim3(64, 4), 0, h->stream, (const float*)h->slabs, h->nslab,
+                               h->pitch, h->nd.P, h->grow);
+            row = h->grow;
+        }
+        NCCLCHK(g_rccl.AllReduce(row, row, (size_t)h->nd.P, ncclFloat, ncclSum, h->shard->comm, h->stream));
+        NCCLCHK(g_rccl.AllReduce(h->pstat, h->pstat_red, (size_t)PSTAT_CAP, ncclDouble, ncclSum, h->shard->comm, h->stream));
+    }
     if (prof) hipEventRecord(b, h->stream);
     HIPCHK(hipGetLastError());
     return 0;
@@ -359,13 +495,13 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
 static void launch_update(tbnn_ctx* h, int mode, float eps, const float* eta, float* q, float* g) {
     const int gx = (h->pitch / 4 + UPD_COLS - 1) / UPD_COLS;
     const bool img = h->kernel == TBNN_KERNEL_FAST && q == h->q;
-    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, h->nd, mode, eps, eta, h->slabs, h->nslab,
+    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, h->nd, mode, eps, eta, grad_slabs(h), grad_nslab(h),
                        h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg);
     if (img && (mode == UPD_FIRST || mode == UPD_MID)) h->q_img_valid = true;
 }
 static void launch_energy(tbnn_ctx* h, int which, const float* eta, const float* q, double* slot) {
-    hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, h->nd, which, eta, q, h->p, h->q_cur, h->pstat,
-                       h->grid, h->n, h->sc, slot);
+    hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, h->nd, which, eta, q, h->p, h->q_cur, stat_ptr(h),
+                       stat_entries(h), rows_total(h), h->sc, slot);
 }
 // make (logp, grad, stat) at q_cur valid
 static int ensure_current(tbnn_ctx* h, double* slot) {
@@ -403,21 +539,21 @@ extern "C" int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* et
     int rc = launch_fwd_bwd(h, dq, de);
     if (rc) return rc;
     const int gx = (h->pitch / 4 + UPD_COLS - 1) / UPD_COLS;
-    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, nd, (int)UPD_GRAD_ONLY, 0.f, de, h->slabs, h->nslab,
+    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, nd, (int)UPD_GRAD_ONLY, 0.f, de, grad_slabs(h), grad_nslab(h),
                        h->pitch, h->q_cur, h->g_cur, const_cast<float*>(dq), h->p, h->tmp, (const int*)nullptr, (float*)nullptr);
     // EN_TRACE leaves the chain's scalar record alone; stat comes from the slabs
     if (!h->trace || h->trace_cap < 2) {
         if (h->trace) hipFree(h->trace);
         HIPCHK(hipMalloc(&h->trace, 4096 * sizeof(double))); h->trace_cap = 4096;
     }
-    hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, nd, (int)EN_TRACE, de, dq, h->p, h->q_cur, h->pstat,
-                       h->grid, h->n, h->sc, h->trace);
+    hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, nd, (int)EN_TRACE, de, dq, h->p, h->q_cur, stat_ptr(h),
+                       stat_entries(h), rows_total(h), h->sc, h->trace);
     HIPCHK(hipGetLastError());
     double lp = 0.0;
     HIPCHK(hipMemcpyAsync(&lp, h->trace, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (grad) HIPCHK(hipMemcpyAsync(grad, h->tmp, (size_t)nd.P * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     std::vector<double> ps;
-    if (stat) { ps.resize(h->grid); HIPCHK(hipMemcpyAsync(ps.data(), h->pstat, (size_t)h->grid * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
+    if (stat) { ps.resize(stat_entries(h)); HIPCHK(hipMemcpyAsync(ps.data(), stat_ptr(h), ps.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream)); }
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->profile) drain_profile(h);
     if (logp) *logp = lp;
@@ -551,7 +687,7 @@ extern "C" int tbnn_hyper_logp_grad(tbnn_handle h, const float* eta, double* log
     if (rc) return rc;
     float* de = h->eta;
     if (eta) { HIPCHK(hipMemcpyAsync(h->tmp + nd.P, eta, (size_t)nd.H * sizeof(float), hipMemcpyHostToDevice, h->stream)); de = h->tmp + nd.P; }
-    hipLaunchKernelGGL(k_hyper, dim3(1), dim3(HYP_THREADS), 0, h->stream, nd, (int)HYP_EVAL, 0.f, 0, de, h->q_cur, h->n,
+    hipLaunchKernelGGL(k_hyper, dim3(1), dim3(HYP_THREADS), 0, h->stream, nd, (int)HYP_EVAL, 0.f, 0, de, h->q_cur, rows_total(h),
                        (const float*)nullptr, (const float*)nullptr, 0u, h->key0, h->key1, h->sc, h->hyp_ws, h->sc_out);
     HIPCHK(hipGetLastError());
     std::vector<float> ws(hyper_ws_bytes(nd) / sizeof(float));
@@ -579,7 +715,7 @@ extern "C" int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const fl
     // the hyper transition uses the epoch counter of the weight transition that preceded it
     const uint32_t ep = h->epoch > 0 ? h->epoch - 1 : 0;
     hipLaunchKernelGGL(k_hyper, dim3(1), dim3(HYP_THREADS), 0, h->stream, nd, (int)HYP_STEP, eps_h, (int)L_h, h->eta, h->q_cur,
-                       h->n, d_p0, d_lu, ep, h->key0, h->key1, h->sc, h->hyp_ws, h->sc_out);
+                       rows_total(h), d_p0, d_lu, ep, h->key0, h->key1, h->sc, h->hyp_ws, h->sc_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipMemcpyAsync(h->sc_host, h->sc_out, sizeof(Scal), hipMemcpyDeviceToHost, h->stream));

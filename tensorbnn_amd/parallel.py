@@ -90,3 +90,40 @@ def write_chain_folders(root, stacked, shapes, layer_names, n_hyper):
                 f.write((" ".join(str(x) for x in shp) + "\n").encode("utf-8"))
             f.write(f"{n_samp} 1 {len(shapes)}\n".encode("utf-8"))
             f.write(str(n_hyper).encode("utf-8"))
+
+
+# ---------------------------------------------------------------------------------------------
+# native RCCL communicator (include/tbnn.h, tbnn_comm_*) and the row-sharded single chain
+# ---------------------------------------------------------------------------------------------
+def row_block(n: int, rank: int, world: int):
+    """rows [lo, hi) of rank `rank`: contiguous blocks, multiples of 16 rows (one MFMA row tile) except the last"""
+    tiles = (n + 15) // 16
+    per = (tiles + world - 1) // world
+    lo = min(n, rank * per * 16)
+    hi = min(n, (rank + 1) * per * 16)
+    return lo, hi
+
+
+def make_comm(chain):
+    """One native communicator per chain: rank 0 draws the RCCL unique id, torch.distributed (any backend)
+    carries it to the other ranks, every rank joins on its chain's device."""
+    from . import _native as nat
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    box = [nat.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    return nat.Comm(chain, world, rank, box[0])
+
+
+def shard_rows(chain, X, Y, comm):
+    """Row-sharded single chain: every rank keeps rows row_block(n, rank, world) of (X, Y) and
+    the same (theta, eta, seed, chain_id); the native library all-reduces the data-term gradient (P floats) and
+    the likelihood statistic over RCCL/xGMI after every fused pass."""
+    n = X.shape[0]
+    lo, hi = row_block(n, comm.rank, comm.world)
+    if hi <= lo:
+        raise ValueError(f"rank {comm.rank} of {comm.world} would hold no rows (n={n})")
+    chain.set_data(np.ascontiguousarray(X[lo:hi]), np.ascontiguousarray(Y[lo:hi]))
+    chain.set_row_shard(comm, n)
+    return lo, hi
