@@ -153,6 +153,15 @@ int tbnn_set_epoch(tbnn_handle h, uint32_t epoch);
  * chain's stream (fills fwdbwd_us); stride <= 0 turns it off */
 int tbnn_set_profiling(tbnn_handle h, int stride);
 
+/* ---- kernels for shapes outside the ahead-of-time registries.  The shape-specialised MFMA kernels are
+ * C++ templates; tensorbnn_amd/jit.py instantiates them for a given network with hipcc at run time
+ * (cached .so), and this call hands the result to the library: later tbnn_create calls with
+ * TBNN_KERNEL_AUTO / _FAST for that shape use it.  (The reference gets the same effect from
+ * tf.function tracing + XLA, network.py:359-362.) ---- */
+int tbnn_register_kernel_lib(const char* path);
+/* 0: only the generic kernel covers the shape; 1 / 2: ahead-of-time narrow / wide MFMA kernels; 3: a registered library */
+int tbnn_fused_kernel_available(const tbnn_net_desc* desc);
+
 /* ---- RCCL over xGMI.  librccl.so is resolved with dlopen on the first
  * tbnn_comm_* call: single-GPU use never loads it.  One communicator per chain handle; every
  * collective is enqueued on the chain's own stream (no host sync inside a transition). ---- */

@@ -75,6 +75,8 @@ SYMBOLS = [
     ("tbnn_debug_draw", C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_int32, _fp, _fp]),
     ("tbnn_set_epoch", C.c_int, [_H, C.c_uint32]),
     ("tbnn_set_profiling", C.c_int, [_H, C.c_int]),
+    ("tbnn_register_kernel_lib", C.c_int, [C.c_char_p]),
+    ("tbnn_fused_kernel_available", C.c_int, [C.POINTER(NetDesc)]),
     ("tbnn_comm_unique_id", C.c_int, [C.POINTER(C.c_ubyte)]),
     ("tbnn_comm_create", C.c_int, [_H, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(_H)]),
     ("tbnn_comm_destroy", C.c_int, [_H]),
@@ -128,10 +130,17 @@ class Chain:
     """One HMC chain on one device (tbnn_handle)."""
 
     def __init__(self, layers: Sequence[tuple], likelihood: int = LIK_GAUSSIAN, fixed_sd: float = 0.1,
-                 device: int = 0, seed: int = 50, chain_id: int = 0, kernel: int = KERNEL_AUTO):
+                 device: int = 0, seed: int = 50, chain_id: int = 0, kernel: int = KERNEL_AUTO,
+                 jit: Optional[bool] = None):
+        """jit: compile + register MFMA kernels for a shape outside the ahead-of-time registries (jit.py);
+        None -> the TBNN_JIT environment switch (default on); only consulted for KERNEL_AUTO / KERNEL_FAST."""
         arr = (LayerDesc * len(layers))(*[LayerDesc(*map(int, l)) for l in layers])
         self._layers_keepalive = arr
         desc = NetDesc(len(layers), arr, int(likelihood), float(fixed_sd), int(kernel), 0)
+        if kernel != KERNEL_GENERIC:
+            from . import jit as _jit
+            if (jit if jit is not None else _jit.enabled()) and lib.tbnn_fused_kernel_available(C.byref(desc)) == 0:
+                _jit.ensure_registered(layers, likelihood)
         h = _H()
         _check(lib.tbnn_create(C.byref(desc), int(device), int(seed), int(chain_id), C.byref(h)))
         self._h = h

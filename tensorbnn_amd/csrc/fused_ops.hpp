@@ -1,0 +1,49 @@
+// Table of one shape-specialised implementation of the fused forward+backward pass: what a run-time
+// compiled kernel library (tensorbnn_amd/jit.py -> tbnn_register_kernel_lib) hands to libtbnn.
+// Plain C layout: the table crosses a dlopen boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "common.hpp"
+#include "wide_api.hpp"
+
+#define TBNN_JIT_ABI 1
+enum { TBNN_FAMILY_NARROW = 1, TBNN_FAMILY_WIDE = 2 };
+
+struct FusedOps {
+    int abi;                                  // TBNN_JIT_ABI
+    int family;                               // TBNN_FAMILY_*
+    int nl, dims[TBNN_MAX_LAYERS + 1];        // the shape the kernels were instantiated for
+    int hact, lact, bern;
+    char name[128];
+    int img_floats;                           // padded weight image (k_update scatters theta into it through image_map)
+    void (*image_map)(int* map /* 2P */);
+    // narrow family: one kernel, one gradient slab per workgroup
+    int (*grid)(long n);
+    int (*launch)(int grid, hipStream_t st, const NetDev* nd, const float* qimg, const float* eta, const float* X,
+                  const float* Y, long n, float* slabs, int pitch, double* pstat);
+    // wide family: k_chain_wide + k_dw_wide + k_reduce_wide
+    void (*plan)(long n, WidePlan* plan);
+    int (*wlaunch)(const WidePlan* plan, hipStream_t st, const NetDev* nd, const float* qimg, const float* eta,
+                   const float* X, const float* Y, long n, float* store, float* slabA, float* slabB, double* pstat, float* out);
+};
+
+static inline bool fused_ops_match(const FusedOps& o, const NetDev& nd) {
+    if (o.nl != nd.nl || (nd.lik == TBNN_LIK_BERNOULLI) != (o.bern != 0)) return false;
+    for (int l = 0; l < nd.nl; ++l) {
+        if (nd.in[l] != o.dims[l] || nd.out[l] != o.dims[l + 1]) return false;
+        if (nd.act[l] != (l == nd.nl - 1 ? o.lact : o.hact)) return false;
+    }
+    return true;
+}
+
+template <class S>
+static inline void fused_ops_shape(FusedOps* o, const char* prefix) {
+    o->abi = TBNN_JIT_ABI;
+    o->nl = S::NL;
+    for (int i = 0; i <= S::NL; ++i) o->dims[i] = S::D[i];
+    o->hact = S::HACT; o->lact = S::LACT; o->bern = S::BERN ? 1 : 0;
+    static const char* an[] = {"none", "relu", "tanh", "sigmoid", "exp", "elu"};
+    int k = snprintf(o->name, sizeof(o->name), "%s<%s,%s%s;", prefix, an[S::HACT], an[S::LACT], S::BERN ? ",bernoulli" : "");
+    for (int i = 0; i <= S::NL && k < (int)sizeof(o->name) - 8; ++i) k += snprintf(o->name + k, sizeof(o->name) - k, i ? ",%d" : "%d", S::D[i]);
+    snprintf(o->name + k, sizeof(o->name) - k, ">");
+}

@@ -1,0 +1,32 @@
+// Included by a run-time generated translation unit (tensorbnn_amd/jit.py) after `using S = Shape<...>;`
+// with JIT_FAST3 = 1 (k_fwd_bwd_fast3) or 0 (k_fwd_bwd_fast).
+#pragma once
+#define TBNN_NO_FAST_REGISTRY
+#include "kernels_fast3.hpp"
+#include "fused_ops.hpp"
+
+template <class S, bool F3>
+struct JitNarrow {
+    static int grid(long n) {
+        const long ntiles = (n + 15) / 16, wgs = (ntiles + FAST_WAVES - 1) / FAST_WAVES;
+        return (int)(wgs < 256 ? wgs : 256);
+    }
+    static int launch(int g, hipStream_t st, const NetDev* nd, const float* qimg, const float* eta, const float* X, const float* Y,
+                      long n, float* slabs, int pitch, double* pstat) {
+        if constexpr (F3)
+            hipLaunchKernelGGL(k_fwd_bwd_fast3<S>, dim3(g), dim3(FAST_THREADS), 0, st, *nd, qimg, eta, X, Y, n, slabs, pitch, pstat,
+                               (unsigned long long*)nullptr);
+        else
+            hipLaunchKernelGGL(k_fwd_bwd_fast<S>, dim3(g), dim3(FAST_THREADS), 0, st, *nd, qimg, eta, X, Y, n, slabs, pitch, pstat,
+                               (unsigned long long*)nullptr);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    static void image_map(int* map) { ImageMap<S, 0>::run(map); }
+    static void fill(FusedOps* o) {
+        fused_ops_shape<S>(o, F3 ? "jit-fast3" : "jit-fast");
+        o->family = TBNN_FAMILY_NARROW;
+        o->img_floats = FastCfg<S>::STATIC_FLOATS;
+        o->image_map = &image_map; o->grid = &grid; o->launch = &launch;
+        o->plan = nullptr; o->wlaunch = nullptr;
+    }
+};

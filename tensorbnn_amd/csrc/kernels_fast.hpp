@@ -47,6 +47,8 @@ __device__ __forceinline__ float actc_fwd(float z) {
     if constexpr (ACT == TBNN_ACT_RELU) return __int_as_float(max(__float_as_int(z), 0));
     else if constexpr (ACT == TBNN_ACT_TANH) return tanhf(z);
     else if constexpr (ACT == TBNN_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
+    else if constexpr (ACT == TBNN_ACT_EXP) return expf(z);
+    else if constexpr (ACT == TBNN_ACT_ELU) return z > 0.f ? z : expm1f(z);
     else return z;
 }
 template <int ACT>
@@ -54,6 +56,8 @@ __device__ __forceinline__ float actc_bwd(float a) {
     if constexpr (ACT == TBNN_ACT_RELU) return a > 0.f ? 1.f : 0.f;
     else if constexpr (ACT == TBNN_ACT_TANH) return 1.f - a * a;
     else if constexpr (ACT == TBNN_ACT_SIGMOID) return a * (1.f - a);
+    else if constexpr (ACT == TBNN_ACT_EXP) return a;
+    else if constexpr (ACT == TBNN_ACT_ELU) return a > 0.f ? 1.f : a + 1.f;
     else return 1.f;
 }
 

@@ -596,6 +596,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #undef TB_STAMP
 }
 
+#ifndef TBNN_NO_FAST_REGISTRY
 static inline bool fast3_available(int id) { return id == 0 || id == 1 || id == 2; }
 static inline int fast3_launch(int id, int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
                                const float* X, const float* Y, long n, float* slabs, int pitch, double* pstat,
@@ -608,3 +609,4 @@ static inline int fast3_launch(int id, int grid, hipStream_t st, const NetDev& n
     }
     return 0;
 }
+#endif  // TBNN_NO_FAST_REGISTRY

@@ -28,7 +28,9 @@
 // BNN_functions.py:23-32; reverse mode SURVEY A12.
 #pragma once
 #include <type_traits>
+#include <algorithm>
 #include "kernels_fast.hpp"
+#include "wide_api.hpp"
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
 template <int I, int N, class F>
@@ -827,3 +829,41 @@ static void wide_image_map(int* map) {
         }
     }
 }
+
+// host: workgroup plan and the three launches of one fused pass
+template <class S>
+static inline void wide_plan_t(long n, WidePlan& p) {
+    using C = WideCfg<S>;
+    const long ntiles = (n + 15) / 16, nblk = (ntiles + WIDE_WAVES - 1) / WIDE_WAVES;
+    p.gridA = (int)std::min<long>(nblk, 256);
+    // 256 dW workgroups shared out over the middle layers in proportion to their MFMA count
+    long tot = 0;
+    for (int l = 1; l <= C::NM; ++l) tot += C::dw_cost(l);
+    int budget = (int)std::min<long>(256, std::max<long>(ntiles, C::NM)), used = 0;
+    p.wg_lo[0] = 0;
+    for (int l = 1; l <= C::NM; ++l) {
+        int w = l == C::NM ? budget - used : (int)std::max<long>(1, (budget * C::dw_cost(l)) / tot);
+        w = std::max(1, w);
+        used += w;
+        p.wg_lo[l] = used;
+    }
+    p.gridB = used;
+    p.store_floats = (size_t)C::store_floats(ntiles);
+    p.slabA_floats = (size_t)p.gridA * C::SA_FLOATS;
+    p.slabB_floats = (size_t)p.gridB * C::SB_FLOATS;
+    p.img_floats = C::IMG_FLOATS;
+}
+
+template <class S>
+static inline int wide_launch_t(const WidePlan& p, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta, const float* X,
+                    const float* Y, long n, float* store, float* slabA, float* slabB, double* pstat, float* out) {
+    using C = WideCfg<S>;
+    WideDwArgs a;
+    for (int i = 0; i <= TBNN_MAX_LAYERS; ++i) a.wg_lo[i] = p.wg_lo[i];
+    hipLaunchKernelGGL(k_chain_wide<S>, dim3(p.gridA), dim3(WIDE_THREADS), 0, st, nd, qimg, eta, X, Y, n, store, slabA, pstat);
+    hipLaunchKernelGGL(k_dw_wide<S>, dim3(p.gridB), dim3(WIDE_THREADS), 0, st, a, (const float*)store, n, slabB);
+    hipLaunchKernelGGL(k_reduce_wide<S>, dim3((C::P() + 63) / 64), dim3(64, 4), 0, st, a, (const float*)slabA, p.gridA,
+                       (const float*)slabB, out);
+    return 0;
+}
+

@@ -20,6 +20,8 @@
 #include "kernels_fast2.hpp"
 #include "kernels_fast3.hpp"
 #include "wide_api.hpp"
+#include "fused_ops.hpp"
+#include <mutex>
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -61,6 +63,7 @@ struct tbnn_ctx {
     // fused-pass workspace
     int grid = 0, pitch = 0; float* slabs = nullptr; double* pstat = nullptr; float* scratch = nullptr;
     // wide-layer path (kernels_wide.hpp): a fast-kernel variant with its own workspace
+    const FusedOps* jit = nullptr;         // run-time registered kernel library covering this shape (tbnn_register_kernel_lib)
     int wide_id = -1; WidePlan wplan; float* wstore = nullptr; float* wslabA = nullptr; float* wslabB = nullptr;
     int nslab = 0;                        // gradient slabs k_update reduces (wide: 1, already reduced)
     // row-sharded chain (tbnn_set_row_shard): all-reduce of the dense data-term gradient row + statistic
@@ -111,6 +114,42 @@ static int build_netdev(const tbnn_net_desc* d, NetDev& nd) {
     nd.fixed_sd = d->fixed_sd;
     if (nd.lik == TBNN_LIK_FIXED_GAUSSIAN && !(d->fixed_sd > 0.f)) return fail(-1, "fixed_sd must be > 0");
     return 0;
+}
+
+// ---- kernel libraries compiled at run time for shapes outside the ahead-of-time registries ----
+static std::mutex g_jit_mu;
+static std::vector<FusedOps*> g_jit;              // never freed: handles keep pointers into it
+static const FusedOps* find_jit(const NetDev& nd) {
+    std::lock_guard<std::mutex> lk(g_jit_mu);
+    for (const FusedOps* o : g_jit) if (fused_ops_match(*o, nd)) return o;
+    return nullptr;
+}
+extern "C" int tbnn_register_kernel_lib(const char* path) {
+    if (!path) return fail(-1, "null path");
+    void* lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return fail(-6, std::string("dlopen: ") + dlerror());
+    typedef int (*ops_fn)(FusedOps*);
+    ops_fn fn = (ops_fn)dlsym(lib, "tbnn_jit_ops");
+    if (!fn) { dlclose(lib); return fail(-6, std::string(path) + " does not export tbnn_jit_ops"); }
+    FusedOps* o = new (std::nothrow) FusedOps();
+    if (!o) return fail(-4, "out of host memory");
+    memset(o, 0, sizeof(*o));
+    if (fn(o) != 0 || o->abi != TBNN_JIT_ABI || (o->family != TBNN_FAMILY_NARROW && o->family != TBNN_FAMILY_WIDE)) {
+        delete o; dlclose(lib);
+        return fail(-6, std::string(path) + ": kernel table rejected (ABI mismatch?)");
+    }
+    std::lock_guard<std::mutex> lk(g_jit_mu);
+    g_jit.push_back(o);
+    return 0;
+}
+// 0: generic kernel only; 1: ahead-of-time narrow MFMA kernel; 2: ahead-of-time wide path; 3: registered library
+extern "C" int tbnn_fused_kernel_available(const tbnn_net_desc* desc) {
+    NetDev nd;
+    int rc = build_netdev(desc, nd);
+    if (rc) return rc;
+    if (fast_lookup(nd) >= 0) return 1;
+    if (wide_lookup(nd) >= 0) return 2;
+    return find_jit(nd) ? 3 : 0;
 }
 
 static void default_eta(const NetDev& nd, std::vector<float>& eta) {
@@ -195,7 +234,21 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
     const int want = desc->kernel;
     const int fid = fast_lookup(nd);
     const int wid = fid < 0 ? wide_lookup(nd) : -1;
-    if (want == TBNN_KERNEL_FAST && fid < 0 && wid < 0) return bail(-1, "TBNN_KERNEL_FAST requested but no specialised kernel covers this shape");
+    const FusedOps* jo = (fid < 0 && wid < 0) ? find_jit(nd) : nullptr;
+    if (want == TBNN_KERNEL_FAST && fid < 0 && wid < 0 && !jo) return bail(-1, "TBNN_KERNEL_FAST requested but no specialised kernel covers this shape");
+    if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && jo) {
+        h->kernel = TBNN_KERNEL_FAST; h->jit = jo; h->kernel_name = jo->name;
+        if (jo->family == TBNN_FAMILY_WIDE) { h->wide_id = 1000; jo->plan(16, &h->wplan); }
+        h->img_floats = jo->img_floats;
+        std::vector<int> map(2 * (size_t)nd.P);
+        jo->image_map(map.data());
+        HIPB(hipMalloc(&h->imgmap, map.size() * sizeof(int)));
+        HIPB(hipMemcpy(h->imgmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPB(hipMalloc(&h->qimg, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg_cur, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg, 0, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
+    }
     if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && wid >= 0) {
         h->kernel = TBNN_KERNEL_FAST; h->wide_id = wid; h->kernel_name = wide_name(wid);
         wide_plan(wid, 16, h->wplan);
@@ -253,14 +306,14 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
     for (float** b : {&h->wstore, &h->wslabA, &h->wslabB}) if (*b) { hipFree(*b); *b = nullptr; }
     int grid;
     if (h->wide_id >= 0) {
-        wide_plan(h->wide_id, n, h->wplan);
+        if (h->jit) h->jit->plan(n, &h->wplan); else wide_plan(h->wide_id, n, h->wplan);
         grid = h->wplan.gridA;
         h->scratchPerWG = 0;
         HIPCHK(hipMalloc(&h->wstore, h->wplan.store_floats * sizeof(float)));
         HIPCHK(hipMalloc(&h->wslabA, h->wplan.slabA_floats * sizeof(float)));
         HIPCHK(hipMalloc(&h->wslabB, h->wplan.slabB_floats * sizeof(float)));
     } else if (h->kernel == TBNN_KERNEL_FAST) {
-        grid = fast_grid(h->fast_id, n);
+        grid = h->jit ? h->jit->grid(n) : fast_grid(h->fast_id, n);
         h->scratchPerWG = 0;
     } else {
         const long nblk = (n + GEN_RB - 1) / GEN_RB;
@@ -466,8 +519,12 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
         hipEventRecord(a, h->stream);
     }
     if (h->wide_id >= 0) {
-        if (wide_launch(h->wplan, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->wstore, h->wslabA, h->wslabB, h->pstat, h->slabs))
-            return fail(-2, "wide kernel launch failed");
+        const int rc = h->jit ? h->jit->wlaunch(&h->wplan, h->stream, &h->nd, img, eta, h->dX, h->dY, h->n, h->wstore, h->wslabA, h->wslabB, h->pstat, h->slabs)
+                              : wide_launch(h->wplan, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->wstore, h->wslabA, h->wslabB, h->pstat, h->slabs);
+        if (rc) return fail(-2, "wide kernel launch failed");
+    } else if (h->kernel == TBNN_KERNEL_FAST && h->jit) {
+        if (h->jit->launch(h->grid, h->stream, &h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat))
+            return fail(-2, "registered kernel launch failed");
     } else if (h->kernel == TBNN_KERNEL_FAST) {
         int rc = h->fast_ver == 3 ? fast3_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat)
                : h->fast_ver == 2 ? fast2_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat)
@@ -759,7 +816,7 @@ extern "C" int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, 
 // [0] start, [1] prologue done, [2] first tile done, [3] tile loop done, [4] end
 extern "C" int tbnn_debug_stamps(tbnn_handle h, uint64_t* out5) {
     NEED(h);
-    if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0 || !h->dX) return fail(-1, "debug_stamps: narrow fast kernel + data required");
+    if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0 || h->jit || !h->dX) return fail(-1, "debug_stamps: narrow fast kernel + data required");
     HIPCHK(hipSetDevice(h->device));
     unsigned long long* d = nullptr;
     HIPCHK(hipMalloc(&d, 16 * sizeof(unsigned long long)));

@@ -38,42 +38,6 @@ const char* wide_name(int id) {
     }
 }
 
-template <class S>
-static void plan_t(long n, WidePlan& p) {
-    using C = WideCfg<S>;
-    const long ntiles = (n + 15) / 16, nblk = (ntiles + WIDE_WAVES - 1) / WIDE_WAVES;
-    p.gridA = (int)std::min<long>(nblk, 256);
-    // 256 dW workgroups shared out over the middle layers in proportion to their MFMA count
-    long tot = 0;
-    for (int l = 1; l <= C::NM; ++l) tot += C::dw_cost(l);
-    int budget = (int)std::min<long>(256, std::max<long>(ntiles, C::NM)), used = 0;
-    p.wg_lo[0] = 0;
-    for (int l = 1; l <= C::NM; ++l) {
-        int w = l == C::NM ? budget - used : (int)std::max<long>(1, (budget * C::dw_cost(l)) / tot);
-        w = std::max(1, w);
-        used += w;
-        p.wg_lo[l] = used;
-    }
-    p.gridB = used;
-    p.store_floats = (size_t)C::store_floats(ntiles);
-    p.slabA_floats = (size_t)p.gridA * C::SA_FLOATS;
-    p.slabB_floats = (size_t)p.gridB * C::SB_FLOATS;
-    p.img_floats = C::IMG_FLOATS;
-}
-
-template <class S>
-static int launch_t(const WidePlan& p, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta, const float* X,
-                    const float* Y, long n, float* store, float* slabA, float* slabB, double* pstat, float* out) {
-    using C = WideCfg<S>;
-    WideDwArgs a;
-    for (int i = 0; i <= TBNN_MAX_LAYERS; ++i) a.wg_lo[i] = p.wg_lo[i];
-    hipLaunchKernelGGL(k_chain_wide<S>, dim3(p.gridA), dim3(WIDE_THREADS), 0, st, nd, qimg, eta, X, Y, n, store, slabA, pstat);
-    hipLaunchKernelGGL(k_dw_wide<S>, dim3(p.gridB), dim3(WIDE_THREADS), 0, st, a, (const float*)store, n, slabB);
-    hipLaunchKernelGGL(k_reduce_wide<S>, dim3((C::P() + 63) / 64), dim3(64, 4), 0, st, a, (const float*)slabA, p.gridA,
-                       (const float*)slabB, out);
-    return 0;
-}
-
 #define WIDE_DISPATCH(id, CALL)                                   \
     switch (id) {                                                 \
         case 0: { using S = WShapeC4; CALL; } break;              \
@@ -84,11 +48,11 @@ static int launch_t(const WidePlan& p, hipStream_t st, const NetDev& nd, const f
     }
 
 void wide_image_map_id(int id, int* map) { WIDE_DISPATCH(id, wide_image_map<S>(map)); }
-void wide_plan(int id, long n, WidePlan& plan) { plan.id = id; WIDE_DISPATCH(id, plan_t<S>(n, plan)); }
+void wide_plan(int id, long n, WidePlan& plan) { plan.id = id; WIDE_DISPATCH(id, wide_plan_t<S>(n, plan)); }
 int wide_launch(const WidePlan& plan, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
                 const float* X, const float* Y, long n, float* store, float* slabA, float* slabB, double* pstat, float* out) {
     int rc = -1;
-    WIDE_DISPATCH(plan.id, rc = launch_t<S>(plan, st, nd, qimg, eta, X, Y, n, store, slabA, slabB, pstat, out));
+    WIDE_DISPATCH(plan.id, rc = wide_launch_t<S>(plan, st, nd, qimg, eta, X, Y, n, store, slabA, slabB, pstat, out));
     return rc;
 }
 

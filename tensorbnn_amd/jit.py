@@ -1,0 +1,141 @@
+"""Run-time instantiation of the shape-specialised MFMA kernels (`python -m tensorbnn_amd.jit 5,50,50,1`).
+
+The fused forward+backward kernels are C++ templates over the network shape (csrc/kernels_fast*.hpp,
+csrc/kernels_wide.hpp); libtbnn.so carries ahead-of-time instantiations for BASELINE's configs only.
+For any other network this module writes a ten-line translation unit, compiles it with hipcc for
+gfx950 into a cached shared object and registers it with the library (tbnn_register_kernel_lib), so
+that `Chain(..., kernel=KERNEL_AUTO)` runs on MFMA instead of the generic thread-per-row kernel.
+(The reference gets there through tf.function tracing + XLA, network.py:359-362; here the kernels
+are hand-written and only their *shape parameters* are bound at run time.)
+
+Family choice (first that compiles wins; a shape no family accepts is remembered as `.fail` and
+runs on the generic kernel):
+  * narrow (`k_fwd_bwd_fast3`, else `k_fwd_bwd_fast`): every dW accumulator in one wave's registers --
+    fan-in <= 16, at most NARROW_TILES 16x16 dW tiles in total;
+  * wide (`k_chain_wide` + `k_dw_wide`): >= 3 dense layers, <= 2 outputs, fan-in <= 32,
+    hidden widths <= 256.
+Requirements common to both: one activation for all hidden layers; dense layers only.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from typing import Optional, Sequence
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+NARROW_TILES = 40
+
+
+def cache_dir() -> str:
+    d = os.environ.get("TBNN_JIT_DIR", os.path.join(HERE, "_jit"))
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def enabled() -> bool:
+    return os.environ.get("TBNN_JIT", "1") != "0"
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+def _sources_stamp() -> str:
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".hpp"):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "tbnn.h"), "rb").read())
+    return h.hexdigest()
+
+
+def shape_of(layers: Sequence[tuple], likelihood: int):
+    """(dims, hact, lact, bern) or None when the fused kernels cannot express the network"""
+    from . import _native as nat
+    dims = [int(layers[0][0])] + [int(l[1]) for l in layers]
+    acts = [int(l[2]) for l in layers]
+    if len(layers) < 2:
+        return None
+    hact = acts[0]
+    if any(a != hact for a in acts[:-1]):
+        return None
+    return dims, hact, acts[-1], int(likelihood == nat.LIK_BERNOULLI)
+
+
+def families(dims) -> list:
+    """candidate kernel families for `dims`, best first"""
+    nl = len(dims) - 1
+    out = []
+    tiles = sum(_cdiv(dims[l + 1], 16) * _cdiv(dims[l] + 1, 16) for l in range(nl))
+    if dims[0] <= 16 and tiles <= NARROW_TILES and max(dims) <= 64:
+        if dims[-1] <= 2 and nl >= 2:
+            out.append("fast3")
+        out.append("fast")
+    if nl >= 3 and dims[-1] <= 2 and dims[0] <= 32 and max(dims[1:-1]) <= 256:
+        out.append("wide")
+    return out
+
+
+def source(dims, hact, lact, bern, family) -> str:
+    shape = f"Shape<{hact}, {lact}, {'true' if bern else 'false'}, {', '.join(map(str, dims))}>"
+    if family == "wide":
+        return (f'#include "{CSRC}/jit_wide.hpp"\nusing S = {shape};\n'
+                'extern "C" int tbnn_jit_ops(FusedOps* o) { JitWide<S>::fill(o); return 0; }\n')
+    f3 = "true" if family == "fast3" else "false"
+    return (f'#include "{CSRC}/jit_narrow.hpp"\nusing S = {shape};\n'
+            f'extern "C" int tbnn_jit_ops(FusedOps* o) {{ JitNarrow<S, {f3}>::fill(o); return 0; }}\n')
+
+
+def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Optional[str]:
+    """path of the compiled kernel library for this network, or None (generic kernel)"""
+    sh = shape_of(layers, likelihood)
+    if sh is None:
+        return None
+    dims, hact, lact, bern = sh
+    key = hashlib.sha1(f"{dims}|{hact}|{lact}|{bern}|{_sources_stamp()}".encode()).hexdigest()[:20]
+    d = cache_dir()
+    so, failed = os.path.join(d, f"tbnn_{key}.so"), os.path.join(d, f"tbnn_{key}.fail")
+    if os.path.exists(so):
+        return so
+    if os.path.exists(failed):
+        return None
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    log = []
+    for fam in families(dims):
+        src = os.path.join(d, f"tbnn_{key}_{fam}.hip")
+        with open(src, "w") as f:
+            f.write(source(dims, hact, lact, bern, fam))
+        tmp = so + f".{os.getpid()}.tmp"
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", tmp, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)      # a child process: never an exec of this one
+        if r.returncode == 0:
+            os.replace(tmp, so)
+            return so
+        log.append(f"[{fam}] {r.stderr[-2000:]}")
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    with open(failed, "w") as f:
+        f.write("\n".join(log) if log else "no kernel family applies to this shape\n")
+    return None
+
+
+def ensure_registered(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> bool:
+    """compile (or fetch from the cache) and register the kernels of this network; False: generic kernel"""
+    from . import _native as nat
+    path = build(layers, likelihood, verbose)
+    if path is None:
+        return False
+    nat._check(nat.lib.tbnn_register_kernel_lib(path.encode()))
+    return True
+
+
+if __name__ == "__main__":
+    from . import _native as nat
+    dims = [int(x) for x in sys.argv[1].split(",")]
+    act = {"relu": nat.ACT_RELU, "tanh": nat.ACT_TANH, "sigmoid": nat.ACT_SIGMOID}[sys.argv[2] if len(sys.argv) > 2 else "relu"]
+    layers = [(dims[i], dims[i + 1], act if i < len(dims) - 2 else nat.ACT_NONE, nat.PRIOR_CAUCHY) for i in range(len(dims) - 1)]
+    print(families(dims), build(layers, nat.LIK_GAUSSIAN, verbose=True))

@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # run-time kernel instantiation (tensorbnn_amd/jit.py) only where a test asks for it (jit=True)
+    os.environ.setdefault("TBNN_JIT", "0")
     # the C-ABI library is built in-tree (hipcc cross-compiles gfx950 without a GPU); build it if absent/stale
     try:
         from tensorbnn_amd import build as _b

@@ -1,0 +1,56 @@
+"""GPU: run-time instantiated kernels (tensorbnn_amd/jit.py + tbnn_register_kernel_lib) against the oracle."""
+import numpy as np
+import pytest
+
+import tbnn_oracle as o
+from tensorbnn_amd import jit
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # narrow family (k_fwd_bwd_fast3): every dW tile in registers
+    "narrow_tanh": dict(dims=[6, 24, 24, 1], n=900, act=o.ACT_TANH, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN, name="jit-fast3<"),
+    # narrow family, 3 outputs on the MFMA path (k_fwd_bwd_fast)
+    "narrow_out3": dict(dims=[5, 20, 3], n=500, act=o.ACT_ELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN, name="jit-fast<"),
+    # wide family, image resident in LDS
+    "wide_resident": dict(dims=[8, 80, 80, 2], n=1200, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_BERNOULLI, name="jit-wide(resident)<"),
+    # wide family, streamed weights (3 x 128-wide)
+    "wide_stream": dict(dims=[8, 128, 128, 128, 1], n=2000, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN, name="jit-wide<"),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_jit_kernel_parity(native, case):
+    c = CASES[case]
+    spec, X, Y, theta, eta = o.synth_problem(c["dims"], c["n"], c["act"], c["prior"], c["lik"])
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, kernel=native.KERNEL_FAST, jit=True)
+    assert ch.kernel_name.startswith(c["name"]), ch.kernel_name
+    ch.set_data(X, Y)
+    lp, g, st = ch.logp_grad(theta, eta)
+    lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)
+    assert abs(lp - lp64) <= 4e-6 * abs(lp64) + 1e-3
+    for l, (ow, ob) in zip(spec.layers, spec.offsets()):
+        for a, b in ((ow, ob), (ob, ob + l.out_dim)):
+            assert np.abs(g[a:b] - g64[a:b]).max() <= 1e-4 * max(np.abs(g64[a:b]).max(), 1e-3)
+    # a transition through the registered kernels
+    rng = np.random.default_rng(11)
+    p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+    ch.set_state(theta); ch.set_hypers(eta)
+    out = ch.hmc_step(1e-5, 3, p0=p0, log_u=np.log(0.5))
+    ref = o.weight_step(spec, theta, eta, X, Y, 1e-5, 3, p0, np.log(0.5), np.float64)
+    # the ratio is a difference of two fp32-path log-probs: its error scales with their magnitude
+    assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-4 * abs(ref.log_accept_ratio) + 2e-7 * abs(lp64)
+    ch.close()
+
+
+def test_jit_unsupported_shape_falls_back(native):
+    """mixed hidden activations: no fused family -> AUTO runs on the generic kernel, FAST fails loudly"""
+    layers = [(4, 8, native.ACT_RELU, native.PRIOR_CAUCHY), (8, 8, native.ACT_TANH, native.PRIOR_CAUCHY),
+              (8, 1, native.ACT_NONE, native.PRIOR_CAUCHY)]
+    assert jit.shape_of(layers, native.LIK_GAUSSIAN) is None
+    ch = native.Chain(layers, kernel=native.KERNEL_AUTO, jit=True)
+    assert ch.kernel_name == "generic"
+    ch.close()
+    with pytest.raises(native.TbnnError):
+        native.Chain(layers, kernel=native.KERNEL_FAST, jit=True)

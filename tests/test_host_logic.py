@@ -176,3 +176,19 @@ def test_two_process_gloo_gather(tmp_path):
         assert mats[0].shape == (3, 2, 2) and mats[1].shape == (3, 2, 1) and len(hyp) == 3
         for k in range(3):
             assert np.all(mats[0][k] == 10 * c + k) and np.all(hyp[k] == 100 * c + k)
+
+
+def test_jit_family_choice_and_source():
+    """host side of tensorbnn_amd/jit.py: which kernel family a shape gets and the generated translation unit"""
+    from tensorbnn_amd import jit, _native as nat
+    assert jit.families([5, 50, 50, 50, 1])[0] == "fast3"
+    assert jit.families([5, 20, 3]) == ["fast"]                    # 3 outputs: MFMA last layer
+    assert jit.families([10, 200, 200, 200, 1]) == ["wide"]
+    assert jit.families([40, 300, 3]) == []                        # fan-in 40, 300-wide: generic kernel
+    layers = [(8, 64, nat.ACT_RELU, nat.PRIOR_CAUCHY), (64, 48, nat.ACT_RELU, nat.PRIOR_CAUCHY), (48, 2, nat.ACT_SIGMOID, nat.PRIOR_CAUCHY)]
+    dims, hact, lact, bern = jit.shape_of(layers, nat.LIK_BERNOULLI)
+    assert (dims, hact, lact, bern) == ([8, 64, 48, 2], nat.ACT_RELU, nat.ACT_SIGMOID, 1)
+    src = jit.source(dims, hact, lact, bern, "wide")
+    assert "Shape<1, 3, true, 8, 64, 48, 2>" in src and "JitWide<S>::fill" in src and "tbnn_jit_ops" in src
+    mixed = [(4, 8, nat.ACT_RELU, 0), (8, 8, nat.ACT_TANH, 0), (8, 1, nat.ACT_NONE, 0)]
+    assert jit.shape_of(mixed, nat.LIK_GAUSSIAN) is None
