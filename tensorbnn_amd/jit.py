@@ -102,6 +102,9 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
     if os.path.exists(failed):
         return None
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        return None                      # no compiler on this machine: generic kernel (not remembered as a failure)
+    print(f"tensorbnn_amd: compiling MFMA kernels for network {dims} (once; cached in {d})", file=sys.stderr, flush=True)
     log = []
     for fam in families(dims):
         src = os.path.join(d, f"tbnn_{key}_{fam}.hip")
