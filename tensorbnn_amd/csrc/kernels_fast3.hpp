@@ -17,6 +17,12 @@
 #pragma once
 #include "kernels_fast.hpp"
 
+// MFMAs per LDS instruction when issue(l) is threaded through dW_{l+1} (0: separate phases, the round-1 schedule).
+// Measured on configs[1]: 54.3 us (0) -> 53.9 us (1..3).
+#ifndef TBNN_SGB
+#define TBNN_SGB 2
+#endif
+
 template <class S>
 struct F3Cfg : FastCfg<S> {
     using B = FastCfg<S>;
@@ -353,10 +359,26 @@ struct Pipe3 {
                                                 const float (&Aup)[Bwd3<S, l + 1>::MTd][4], const float (&Bup)[C::NT(l + 1)][4]) {
         float Aop[Bwd3<S, l>::MTd][4], Bop[C::NT(l)][4];
         Bwd3<S, l>::issue(dz, wl, i16, g, Aop, Bop);
+#if TBNN_SGB > 0
+        // the ~20 LDS instructions of issue(l) cost ~450 issue cycles on their own: thread them through the
+        // 48 MFMAs of dW_{l+1} (operands already in registers) -- 2 MFMAs, 1 DS, 2 MFMAs, 1 DS, ...
+        Bwd3<S, l + 1>::dw(dW, Aup, Bup);
+        {
+            constexpr int NDS = Bwd3<S, l>::MT > 0 ? 4 * Bwd3<S, l>::MT + C::NT(l) + Bwd3<S, l>::MT : 0;
+#pragma unroll
+            for (int i = 0; i < NDS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, TBNN_SGB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+            }
+        }
+        SCHED_FENCE();
+        TSTAMP(10 + 4 * l);
+#else
         SCHED_FENCE();
         TSTAMP(10 + 4 * l);
         Bwd3<S, l + 1>::dw(dW, Aup, Bup);
         SCHED_FENCE();
+#endif
         TSTAMP(11 + 4 * l);
         FringeDW<S, l>::run(FP, T, dzf, g);
         TSTAMP(12 + 4 * l);
