@@ -153,6 +153,20 @@ int tbnn_set_epoch(tbnn_handle h, uint32_t epoch);
  * chain's stream (fills fwdbwd_us); stride <= 0 turns it off */
 int tbnn_set_profiling(tbnn_handle h, int stride);
 
+/* ---- predictions and metrics over the staged rows: no host traffic but the result.
+ * network.__init__ stages the validation set next to the training set (network.py:47-51). ---- */
+int tbnn_set_validation(tbnn_handle h, const float* X, const float* Y, int64_t n);
+/* network.predict(train=True/False) (network.py:141-171): which = 0 training rows, 1 validation rows;
+ * theta NULL = current state; out: host [d_out, n] or NULL (predictions stay on the device). */
+int tbnn_predict(tbnn_handle h, int which, const float* theta, float* out);
+/* metrics.py:30-141 in one pass over the predictions: with p = f*sd+mean, r = y*sd+mean (exp() of either on
+ * request: scaleExp; SquaredError leaves the validation predictions un-exponentiated, metrics.py:44-47)
+ *   out3[0] = mean (p-r)^2            SquaredError
+ *   out3[1] = mean 100*|(p-r)/r|      PercentError
+ *   out3[2] = mean |r - round(p)|     1 - Accuracy */
+int tbnn_metrics(tbnn_handle h, int which, const float* theta, float mean, float sd, int exp_pred, int exp_real,
+                 double out3[3]);
+
 /* ---- kernels for shapes outside the ahead-of-time registries.  The shape-specialised MFMA kernels are
  * C++ templates; tensorbnn_amd/jit.py instantiates them for a given network with hipcc at run time
  * (cached .so), and this call hands the result to the library: later tbnn_create calls with

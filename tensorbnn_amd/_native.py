@@ -75,6 +75,9 @@ SYMBOLS = [
     ("tbnn_debug_draw", C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_int32, _fp, _fp]),
     ("tbnn_set_epoch", C.c_int, [_H, C.c_uint32]),
     ("tbnn_set_profiling", C.c_int, [_H, C.c_int]),
+    ("tbnn_set_validation", C.c_int, [_H, _fp, _fp, C.c_int64]),
+    ("tbnn_predict", C.c_int, [_H, C.c_int, _fp, _fp]),
+    ("tbnn_metrics", C.c_int, [_H, C.c_int, _fp, C.c_float, C.c_float, C.c_int, C.c_int, _dp]),
     ("tbnn_register_kernel_lib", C.c_int, [C.c_char_p]),
     ("tbnn_fused_kernel_available", C.c_int, [C.POINTER(NetDesc)]),
     ("tbnn_comm_unique_id", C.c_int, [C.POINTER(C.c_ubyte)]),
@@ -258,6 +261,28 @@ class Chain:
 
     def set_profiling(self, stride: int):
         _check(lib.tbnn_set_profiling(self._h, int(stride)))
+
+    def set_validation(self, X, Y):
+        X = _f32(X).reshape(-1, self.d_in)
+        Y = _f32(Y).reshape(X.shape[0], self.d_out)
+        _check(lib.tbnn_set_validation(self._h, _p(X), _p(Y), X.shape[0]))
+        self.nv = X.shape[0]
+
+    def predict(self, which: int = 0, theta=None) -> np.ndarray:
+        """[d_out, n] predictions over the staged training (0) / validation (1) rows"""
+        n = self.nv if which else self.n
+        out = np.empty((self.d_out, n), dtype=np.float32)
+        th = None if theta is None else _f32(theta).reshape(-1)
+        _check(lib.tbnn_predict(self._h, int(which), _p(th), _p(out)))
+        return out
+
+    def metrics(self, which: int = 0, theta=None, mean: float = 0.0, sd: float = 1.0, exp_pred: bool = False,
+                exp_real: bool = False):
+        """(mean squared error, mean percent error, mean |r - round(p)|) over the staged rows (metrics.py:30-141)"""
+        out = (C.c_double * 3)()
+        th = None if theta is None else _f32(theta).reshape(-1)
+        _check(lib.tbnn_metrics(self._h, int(which), _p(th), float(mean), float(sd), int(exp_pred), int(exp_real), out))
+        return float(out[0]), float(out[1]), float(out[2])
 
     def gather_samples(self, comm: "Comm", d_out_ptr: int = 0) -> np.ndarray:
         """RCCL all-gather of (theta, eta) over the communicator: returns [world, P+H]"""

@@ -6,7 +6,7 @@
 #include "common.hpp"
 #include "wide_api.hpp"
 
-#define TBNN_JIT_ABI 1
+#define TBNN_JIT_ABI 2
 enum { TBNN_FAMILY_NARROW = 1, TBNN_FAMILY_WIDE = 2 };
 
 struct FusedOps {
@@ -25,6 +25,8 @@ struct FusedOps {
     void (*plan)(long n, WidePlan* plan);
     int (*wlaunch)(const WidePlan* plan, hipStream_t st, const NetDev* nd, const float* qimg, const float* eta,
                    const float* X, const float* Y, long n, float* store, float* slabA, float* slabB, double* pstat, float* out);
+    // wide family, optional: forward only, fout[d_out][n] (null: the generic forward kernel is used)
+    int (*wforward)(hipStream_t st, const NetDev* nd, const float* qimg, const float* X, long n, float* fout);
 };
 
 static inline bool fused_ops_match(const FusedOps& o, const NetDev& nd) {

@@ -27,6 +27,6 @@ struct JitNarrow {
         o->family = TBNN_FAMILY_NARROW;
         o->img_floats = FastCfg<S>::STATIC_FLOATS;
         o->image_map = &image_map; o->grid = &grid; o->launch = &launch;
-        o->plan = nullptr; o->wlaunch = nullptr;
+        o->plan = nullptr; o->wlaunch = nullptr; o->wforward = nullptr;
     }
 };

@@ -171,3 +171,27 @@ __global__ __launch_bounds__(GEN_RB) void k_forward_generic(
         }
     }
 }
+
+// metrics.py:30-141 on the device: one pass over the predictions f[d_out][n] and the targets Y[n][d_out];
+//   p = f*sd + mean, r = y*sd + mean (metrics.py:36-42), optionally exp() of either (scaleExp; SquaredError does
+//   not exponentiate the validation predictions, :44-47 -- the caller passes the flags)
+//   part[3b+0] += (p-r)^2, part[3b+1] += 100|(p-r)/r|, part[3b+2] += |r - round(p)|   (round half to even, tf.round)
+__global__ __launch_bounds__(256) void k_metrics(const float* __restrict__ f, const float* __restrict__ Y, long n, int d_out,
+                                                  float mean, float sd, int exp_pred, int exp_real, double* __restrict__ part) {
+    __shared__ double red[8];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const long tot = n * d_out;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / d_out; const int o = (int)(e - row * d_out);
+        float p = f[(size_t)o * n + row] * sd + mean;
+        float r = Y[e] * sd + mean;
+        if (exp_pred) p = expf(p);
+        if (exp_real) r = expf(r);
+        const float d = p - r;
+        a0 += (double)(d * d);
+        a1 += (double)(fabsf(d / r) * 100.f);
+        a2 += (double)fabsf(r - rintf(p));
+    }
+    a0 = block_sum(a0, red); a1 = block_sum(a1, red); a2 = block_sum(a2, red);
+    if (threadIdx.x == 0) { part[3 * blockIdx.x] = a0; part[3 * blockIdx.x + 1] = a1; part[3 * blockIdx.x + 2] = a2; }
+}

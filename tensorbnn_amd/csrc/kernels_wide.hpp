@@ -107,6 +107,7 @@ struct WideCfg {
     static constexpr int cF(int l) { int c = 0; for (int m = 1; m < l; ++m) c += KG(in(m)); return c; }           // first chunk of F(l)
     static constexpr int cB(int l) { int c = cF(NM + 1); for (int m = NM; m > l; --m) c += KG(out(m)); return c; } // first chunk of B(l)
     static constexpr int NCH = cB(0);
+    static constexpr int NCHF = cF(NM + 1);            // chunks of the forward segments alone (forward-only kernel)
     static constexpr int chunk_gran(int c) {
         for (int l = 1; l <= NM; ++l) if (c >= cF(l) && c < cF(l) + KG(in(l))) return GF(l);
         for (int l = NM; l >= 1; --l) if (c >= cB(l) && c < cB(l) + KG(out(l))) return GB(l);
@@ -207,7 +208,7 @@ __device__ __forceinline__ float relu_mask_apply(unsigned m, int bit, float acc)
 }
 
 // top of chunk c: park the chunk fetched one step ago (c+2) in its ring slot, fetch chunk c+3.
-template <class S, int c>
+template <class S, int c, bool FWD = false>
 __device__ __forceinline__ void wide_stage(int base, f32x4 (&stgs)[WIDE_PD][WideCfg<S>::NGW], float* __restrict__ ring,
                                            const float* __restrict__ img, int wave, int lane) {
     using C = WideCfg<S>;
@@ -215,7 +216,8 @@ __device__ __forceinline__ void wide_stage(int base, f32x4 (&stgs)[WIDE_PD][Wide
     return;                                            // timing experiment: ring never refilled (results wrong)
 #endif
     if constexpr (C::RESIDENT) return;
-    constexpr int cw = (c + 2) % C::NCH, cl = (c + 2 + WIDE_PD) % C::NCH;
+    constexpr int NCHE = FWD ? C::NCHF : C::NCH;       // the forward-only kernel cycles through the F segments only
+    constexpr int cw = (c + 2) % NCHE, cl = (c + 2 + WIDE_PD) % NCHE;
     f32x4 (&stg)[C::NGW] = stgs[0];                    // oldest set: chunk c+2
     float* dst = ring + ((base + c + 2) & (WIDE_RING - 1)) * C::SLOT_FLOATS + wave * 256 + lane * 4;
 #pragma unroll
@@ -245,23 +247,27 @@ __device__ __forceinline__ void wide_stage(int base, f32x4 (&stgs)[WIDE_PD][Wide
 }
 
 // A operands of chunk c (already visible in its ring slot: parked two chunks earlier, one barrier ago)
-template <class S, int c>
+template <class S, int c, bool FWD = false>
 __device__ __forceinline__ void wide_load_A(int base, f32x4 (&A)[WideCfg<S>::MAXT], const float* __restrict__ ring, int lane) {
     using C = WideCfg<S>;
     // RESIDENT: `ring` is the LDS base and the chunk sits at its image offset
-    const float* sl = (C::RESIDENT ? ring + C::gran_off(c % C::NCH, 0) : ring + ((base + c) & (WIDE_RING - 1)) * C::SLOT_FLOATS) + lane * 4;
+    constexpr int cc = c % (FWD ? C::NCHF : C::NCH);
+    const float* sl = (C::RESIDENT ? ring + C::gran_off(cc, 0) : ring + ((base + c) & (WIDE_RING - 1)) * C::SLOT_FLOATS) + lane * 4;
 #pragma unroll
     for (int t = 0; t < C::MAXT; ++t)
-        if (t < C::chunk_tiles(c % C::NCH)) A[t] = *reinterpret_cast<const f32x4*>(sl + t * 256);
+        if (t < C::chunk_tiles(cc)) A[t] = *reinterpret_cast<const f32x4*>(sl + t * 256);
 }
 
-template <class S>
+// FWD: forward pass only (network.predict, network.py:141-171): no likelihood, no delta chain, no stores;
+// fout[d_out][n] receives the network output.  Y, eta, store, slabA, pstat are unused (null).
+template <class S, bool FWD = false>
 __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_chain_wide(
     NetDev nd, const float* __restrict__ qimg, const float* __restrict__ eta,
     const float* __restrict__ X, const float* __restrict__ Y, long n,
-    float* __restrict__ store, float* __restrict__ slabA, double* __restrict__ pstat)
+    float* __restrict__ store, float* __restrict__ slabA, double* __restrict__ pstat, float* __restrict__ fout)
 {
     using C = WideCfg<S>;
+    static_assert(!FWD || C::RESIDENT || C::NCHF >= 3, "forward-only ring priming needs >= 3 forward chunks");
     static_assert(C::LDS_FLOATS * 4 + 64 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     __shared__ double red[WIDE_WAVES];
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                     *reinterpret_cast<const f32x4*>(qimg + C::gran_off(c, 0) + (wave + j * WIDE_WAVES) * C::gran_step(c) + lane * 4);
     });
     sfor<0, WIDE_PD>(SFOR_LAMBDA(k) {
-        constexpr int k = SFOR_VAL(k), c = (2 + k) % C::NCH;
+        constexpr int k = SFOR_VAL(k), c = (2 + k) % (FWD ? C::NCHF : C::NCH);
 #pragma unroll
         for (int j = 0; j < C::NGW; ++j)
             stg[k][j] = (!C::RESIDENT && j < C::chunk_gran(c) / WIDE_WAVES)
@@ -301,10 +307,10 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     // the A operands of chunk c+1 are read at the top of chunk c (double buffer): the LDS latency sits under
     // chunk c's MFMAs and the barrier's lgkmcnt(0) finds the queue empty
     f32x4 Acur[C::MAXT];
-    wide_load_A<S, 0>(0, Acur, ring, lane);
+    wide_load_A<S, 0, FWD>(0, Acur, ring, lane);
 #endif
 
-    const float sigma = lik_sigma(nd, eta);
+    const float sigma = FWD ? 1.f : lik_sigma(nd, eta);
     const float inv_var = 1.f / (sigma * sigma);
     double stat = 0.0;
     f32x4 dW0[C::DW0_TILES];
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             xn[k] = (ok && u >= 0) ? X[row * d_in + u] : 0.f;
         }
 #pragma unroll
-        for (int o = 0; o < d_out; ++o) yn[o] = ok ? Y[row * d_out + o] : 0.f;
+        for (int o = 0; o < d_out; ++o) yn[o] = (!FWD && ok) ? Y[row * d_out + o] : 0.f;
     };
     fetch((long)blockIdx.x * WIDE_WAVES + wave);
     int base = 0;                                              // ring slot of chunk 0 of the current block
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                     constexpr int os = ones_slot(C::in(l));
                     if (t == os / 16 && g == (os % 16) / 4) v[t][os % 4] = 1.f;
                 }
-                if (tvalid) {
+                if (!FWD && tvalid) {
                     float* p = store + C::act_off(l, ntiles) + ((size_t)stile * C::TA(l)) * 256 + i16 * 16 + g * 4;
 #pragma unroll
                     for (int t = 0; t < C::TA(l); ++t) *reinterpret_cast<f32x4*>(p + t * 256) = v[t];
@@ -414,13 +420,13 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             sfor<0, C::KG(C::in(l))>(SFOR_LAMBDA(kg) {
                 constexpr int kg = SFOR_VAL(kg), c = C::cF(l) + kg;
 #ifndef WIDE_APREFETCH
-                wide_stage<S, c>(base, stg, ring, img, wave, lane);
+                wide_stage<S, c, FWD>(base, stg, ring, img, wave, lane);
                 f32x4 Acur[C::MAXT];
-                wide_load_A<S, c>(base, Acur, ring, lane);
+                wide_load_A<S, c, FWD>(base, Acur, ring, lane);
 #else
                 f32x4 Anext[C::MAXT];
-                wide_load_A<S, c + 1>(base, Anext, ring, lane);
-                wide_stage<S, c>(base, stg, ring, img, wave, lane);
+                wide_load_A<S, c + 1, FWD>(base, Anext, ring, lane);
+                wide_stage<S, c, FWD>(base, stg, ring, img, wave, lane);
 #endif
 #pragma unroll
                 for (int s = 0; s < C::ksteps(C::in(l), kg); ++s)
@@ -459,9 +465,15 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                 p += __shfl_xor(p, 16, 64);
                 p += __shfl_xor(p, 32, 64);
                 const float fi = actc_fwd<S::LACT>(p + lds[C::BL_OFF + o]);
-                dzl[o] = rvalid ? lik_delta<S>(fi, y[o], inv_var, g == 0, stat) : 0.f;
-                accbL[o] += dzl[o];
+                if constexpr (FWD) {
+                    if (rvalid && g == 0) fout[(size_t)o * n + tile * 16 + i16] = fi;      // [d_out][n]
+                    dzl[o] = 0.f;
+                } else {
+                    dzl[o] = rvalid ? lik_delta<S>(fi, y[o], inv_var, g == 0, stat) : 0.f;
+                    accbL[o] += dzl[o];
+                }
             }
+            if constexpr (FWD) { base = (base + C::NCHF) & (WIDE_RING - 1); continue; }
 #pragma unroll
             for (int t = 0; t < TP; ++t) {
                 f32x4 d = {0.f, 0.f, 0.f, 0.f};
@@ -567,6 +579,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         base = (base + C::NCH) & (WIDE_RING - 1);
     }
 
+    if constexpr (FWD) return;
     // ---- epilogue: compact slab [layer 0][last layer] of this workgroup
     const double wtot = wave_sum(stat);
     if (lane == 0) red[wave] = wtot;
@@ -860,10 +873,26 @@ static inline int wide_launch_t(const WidePlan& p, hipStream_t st, const NetDev&
     using C = WideCfg<S>;
     WideDwArgs a;
     for (int i = 0; i <= TBNN_MAX_LAYERS; ++i) a.wg_lo[i] = p.wg_lo[i];
-    hipLaunchKernelGGL(k_chain_wide<S>, dim3(p.gridA), dim3(WIDE_THREADS), 0, st, nd, qimg, eta, X, Y, n, store, slabA, pstat);
+    hipLaunchKernelGGL((k_chain_wide<S, false>), dim3(p.gridA), dim3(WIDE_THREADS), 0, st, nd, qimg, eta, X, Y, n, store, slabA, pstat,
+                       (float*)nullptr);
     hipLaunchKernelGGL(k_dw_wide<S>, dim3(p.gridB), dim3(WIDE_THREADS), 0, st, a, (const float*)store, n, slabB);
     hipLaunchKernelGGL(k_reduce_wide<S>, dim3((C::P() + 63) / 64), dim3(64, 4), 0, st, a, (const float*)slabA, p.gridA,
                        (const float*)slabB, out);
     return 0;
 }
 
+// forward only: fout[d_out][n] = network(X) for the weights in qimg; false when this shape's ring cannot be primed
+template <class S>
+static inline bool wide_forward_ok() { return WideCfg<S>::RESIDENT || WideCfg<S>::NCHF >= 3; }
+template <class S>
+static inline int wide_forward_t(hipStream_t st, const NetDev& nd, const float* qimg, const float* X, long n, float* fout) {
+    if constexpr (WideCfg<S>::RESIDENT || WideCfg<S>::NCHF >= 3) {
+        const long ntiles = (n + 15) / 16, nblk = (ntiles + WIDE_WAVES - 1) / WIDE_WAVES;
+        const int grid = (int)std::min<long>(nblk, 256);
+        hipLaunchKernelGGL((k_chain_wide<S, true>), dim3(grid), dim3(WIDE_THREADS), 0, st, nd, qimg, (const float*)nullptr, X,
+                           (const float*)nullptr, n, (float*)nullptr, (float*)nullptr, (double*)nullptr, fout);
+        return 0;
+    } else {
+        return -1;
+    }
+}

@@ -55,6 +55,9 @@ struct tbnn_ctx {
     std::string kernel_name;
     // data
     float* dX = nullptr; float* dY = nullptr; bool own_data = false; long n = 0;
+    // validation data (network.py:47-51) and the prediction buffer of tbnn_predict / tbnn_metrics
+    float* dXv = nullptr; float* dYv = nullptr; long nv = 0;
+    float* fbuf = nullptr; size_t fbuf_floats = 0; double* mpart = nullptr;
     // chain state
     float *q_cur = nullptr, *g_cur = nullptr, *q = nullptr, *p = nullptr, *g = nullptr, *eta = nullptr;
     float *p0_inj = nullptr, *logu_inj = nullptr, *tmp = nullptr;
@@ -170,7 +173,8 @@ extern "C" int tbnn_destroy(tbnn_handle h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->own_data) { hipFree(h->dX); hipFree(h->dY); }
     float* bufs[] = {h->q_cur, h->g_cur, h->q, h->p, h->g, h->eta, h->p0_inj, h->logu_inj, h->tmp,
-                     h->slabs, h->scratch, h->hyp_ws, h->wstore, h->wslabA, h->wslabB, h->grow};
+                     h->slabs, h->scratch, h->hyp_ws, h->wstore, h->wslabA, h->wslabB, h->grow, h->dXv, h->dYv, h->fbuf};
+    if (h->mpart) hipFree(h->mpart);
     for (float* b : bufs) if (b) hipFree(b);
     if (h->pstat) hipFree(h->pstat);
     if (h->pstat_red) hipFree(h->pstat_red);
@@ -618,6 +622,31 @@ extern "C" int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* et
     return 0;
 }
 
+// forward pass of the network at the weights q (device) over dX[n][d_in] -> dOut[d_out][n], on h->stream
+static int launch_forward(tbnn_ctx* h, const float* q, const float* dX, long n, float* dOut) {
+    const NetDev& nd = h->nd;
+    const bool wide_fwd = h->wide_id >= 0 && (h->jit ? h->jit->wforward != nullptr : h->wplan.fwd_ok != 0);
+    if (wide_fwd) {
+        // MFMA forward (k_chain_wide<S, FWD>): needs the padded image of q
+        hipLaunchKernelGGL(k_make_image, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, q, h->imgmap, h->qimg_cur);
+        const int rc = h->jit ? h->jit->wforward(h->stream, &h->nd, h->qimg_cur, dX, n, dOut)
+                              : wide_forward(h->wide_id, h->stream, h->nd, h->qimg_cur, dX, n, dOut);
+        if (rc) return fail(-2, "wide forward launch failed");
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    const long nblk = (n + GEN_RB - 1) / GEN_RB;
+    const int grid = (int)std::min<long>(nblk, 512);
+    const size_t per = generic_scratch_floats(nd);
+    float* scr = nullptr;
+    HIPCHK(hipMalloc(&scr, per * sizeof(float) * grid));
+    hipLaunchKernelGGL(k_forward_generic, dim3(grid), dim3(GEN_RB), 0, h->stream, nd, q, dX, n, scr, per, dOut);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(scr);
+    return 0;
+}
+
 extern "C" int tbnn_forward(tbnn_handle h, const float* theta, const float* X, int64_t n, float* out) {
     NEED(h);
     if (!X || !out || n < 1) return fail(-1, "forward: null pointer or n < 1");
@@ -625,19 +654,86 @@ extern "C" int tbnn_forward(tbnn_handle h, const float* theta, const float* X, i
     const NetDev& nd = h->nd;
     const float* dq = h->q_cur;
     if (theta) { HIPCHK(hipMemcpyAsync(h->q, theta, (size_t)nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream)); dq = h->q; h->q_img_valid = false; }
-    float *dXf = nullptr, *dOut = nullptr, *scr = nullptr;
-    const long nblk = (n + GEN_RB - 1) / GEN_RB;
-    const int grid = (int)std::min<long>(nblk, 512);
-    const size_t per = generic_scratch_floats(nd);
+    float *dXf = nullptr, *dOut = nullptr;
     HIPCHK(hipMalloc(&dXf, (size_t)n * nd.d_in * sizeof(float)));
     HIPCHK(hipMalloc(&dOut, (size_t)n * nd.d_out * sizeof(float)));
-    HIPCHK(hipMalloc(&scr, per * sizeof(float) * grid));
     HIPCHK(hipMemcpyAsync(dXf, X, (size_t)n * nd.d_in * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_forward_generic, dim3(grid), dim3(GEN_RB), 0, h->stream, nd, dq, dXf, (long)n, scr, per, dOut);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, dOut, (size_t)n * nd.d_out * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    int rc = launch_forward(h, dq, dXf, (long)n, dOut);
+    if (!rc) {
+        HIPCHK(hipMemcpyAsync(out, dOut, (size_t)n * nd.d_out * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    hipFree(dXf); hipFree(dOut);
+    return rc;
+}
+
+extern "C" int tbnn_set_validation(tbnn_handle h, const float* X, const float* Y, int64_t n) {
+    NEED(h);
+    if (!X || !Y || n < 1) return fail(-1, "set_validation: null pointer or n < 1");
+    HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    hipFree(dXf); hipFree(dOut); hipFree(scr);
+    if (h->dXv) { hipFree(h->dXv); h->dXv = nullptr; }
+    if (h->dYv) { hipFree(h->dYv); h->dYv = nullptr; }
+    HIPCHK(hipMalloc(&h->dXv, (size_t)n * h->nd.d_in * sizeof(float)));
+    HIPCHK(hipMalloc(&h->dYv, (size_t)n * h->nd.d_out * sizeof(float)));
+    HIPCHK(hipMemcpy(h->dXv, X, (size_t)n * h->nd.d_in * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->dYv, Y, (size_t)n * h->nd.d_out * sizeof(float), hipMemcpyHostToDevice));
+    h->nv = (long)n;
+    return 0;
+}
+
+// predictions over the staged training (which = 0) or validation (1) rows into h->fbuf[d_out][n]
+static int predict_resident(tbnn_ctx* h, int which, const float* theta, long* n_out) {
+    const NetDev& nd = h->nd;
+    const float* dX = which ? h->dXv : h->dX;
+    const long n = which ? h->nv : h->n;
+    if (!dX || n < 1) return fail(-1, which ? "tbnn_set_validation has not been called" : "tbnn_set_data has not been called");
+    const float* dq = h->q_cur;
+    if (theta) { HIPCHK(hipMemcpyAsync(h->q, theta, (size_t)nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream)); dq = h->q; h->q_img_valid = false; }
+    const size_t need = (size_t)n * nd.d_out;
+    if (h->fbuf_floats < need) {
+        if (h->fbuf) hipFree(h->fbuf);
+        h->fbuf = nullptr; h->fbuf_floats = 0;
+        HIPCHK(hipMalloc(&h->fbuf, need * sizeof(float))); h->fbuf_floats = need;
+    }
+    *n_out = n;
+    return launch_forward(h, dq, dX, n, h->fbuf);
+}
+
+extern "C" int tbnn_predict(tbnn_handle h, int which, const float* theta, float* out) {
+    NEED(h);
+    if (which != 0 && which != 1) return fail(-1, "which must be 0 (training rows) or 1 (validation rows)");
+    HIPCHK(hipSetDevice(h->device));
+    long n = 0;
+    int rc = predict_resident(h, which, theta, &n);
+    if (rc) return rc;
+    if (out) HIPCHK(hipMemcpyAsync(out, h->fbuf, (size_t)n * h->nd.d_out * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int tbnn_metrics(tbnn_handle h, int which, const float* theta, float mean, float sd, int exp_pred, int exp_real,
+                            double out3[3]) {
+    NEED(h);
+    if (!out3) return fail(-1, "null out3");
+    if (which != 0 && which != 1) return fail(-1, "which must be 0 (training rows) or 1 (validation rows)");
+    HIPCHK(hipSetDevice(h->device));
+    long n = 0;
+    int rc = predict_resident(h, which, theta, &n);
+    if (rc) return rc;
+    const int MB = 256;
+    if (!h->mpart) HIPCHK(hipMalloc(&h->mpart, 3 * MB * sizeof(double)));
+    const long tot = n * h->nd.d_out;
+    const int grid = (int)std::min<long>(MB, (tot + 255) / 256);
+    hipLaunchKernelGGL(k_metrics, dim3(grid), dim3(256), 0, h->stream, (const float*)h->fbuf, (const float*)(which ? h->dYv : h->dY), n,
+                       h->nd.d_out, mean, sd, exp_pred, exp_real, h->mpart);
+    HIPCHK(hipGetLastError());
+    std::vector<double> part(3 * (size_t)grid);
+    HIPCHK(hipMemcpyAsync(part.data(), h->mpart, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double a[3] = {0, 0, 0};
+    for (int b = 0; b < grid; ++b) for (int k = 0; k < 3; ++k) a[k] += part[3 * b + k];
+    for (int k = 0; k < 3; ++k) out3[k] = a[k] / (double)tot;
     return 0;
 }
 

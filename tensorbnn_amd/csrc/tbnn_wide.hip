@@ -48,7 +48,12 @@ const char* wide_name(int id) {
     }
 
 void wide_image_map_id(int id, int* map) { WIDE_DISPATCH(id, wide_image_map<S>(map)); }
-void wide_plan(int id, long n, WidePlan& plan) { plan.id = id; WIDE_DISPATCH(id, wide_plan_t<S>(n, plan)); }
+void wide_plan(int id, long n, WidePlan& plan) { plan.id = id; WIDE_DISPATCH(id, (wide_plan_t<S>(n, plan), plan.fwd_ok = wide_forward_ok<S>() ? 1 : 0)); }
+int wide_forward(int id, hipStream_t st, const NetDev& nd, const float* qimg, const float* X, long n, float* fout) {
+    int rc = -1;
+    WIDE_DISPATCH(id, rc = wide_forward_t<S>(st, nd, qimg, X, n, fout));
+    return rc;
+}
 int wide_launch(const WidePlan& plan, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
                 const float* X, const float* Y, long n, float* store, float* slabA, float* slabB, double* pstat, float* out) {
     int rc = -1;

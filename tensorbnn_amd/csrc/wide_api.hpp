@@ -13,6 +13,7 @@ struct WidePlan {
     size_t slabA_floats = 0;     // gridA x compact slab (first + last layer)
     size_t slabB_floats = 0;     // gridB x middle-layer slab
     int img_floats = 0;
+    int fwd_ok = 0;              // a forward-only instantiation exists (wide_forward)
 };
 
 int wide_lookup(const NetDev& nd);
@@ -22,3 +23,5 @@ void wide_plan(int id, long n, WidePlan& plan);
 // k_chain_wide + k_dw_wide + k_reduce_wide on `st`; out: one dense gradient row of P floats
 int wide_launch(const WidePlan& plan, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
                 const float* X, const float* Y, long n, float* store, float* slabA, float* slabB, double* pstat, float* out);
+// forward only (network.predict): fout[d_out][n]; qimg = padded image of the weights
+int wide_forward(int id, hipStream_t st, const NetDev& nd, const float* qimg, const float* X, long n, float* fout);

@@ -13,6 +13,7 @@ import time
 import numpy as np
 
 from . import _native as nat
+from .metrics import Accuracy, PercentError, SquaredError
 from .paramAdapter import paramAdapter
 
 
@@ -80,14 +81,40 @@ class network(object):
             self._chain_key = key
             y = self.trainY.reshape(len(self.trainX), -1)
             self._chain.set_data(self.trainX, y)
+            if self.validateX is not None and len(self.validateX):          # network.py:47-51: staged once
+                self._chain.set_validation(self.validateX, np.asarray(self.validateY).reshape(len(self.validateX), -1))
         return self._chain
 
     def predict(self, train, *argv):
-        """network.py:141-171: [d_out, n] prediction (native forward kernel)."""
+        """network.py:141-171: [d_out, n] prediction over the rows staged on the device (tbnn_predict)."""
         tensors = self.states if len(argv) == 0 else argv[0]
         theta = np.concatenate([np.asarray(s, dtype=np.float32).reshape(-1) for s in tensors])
-        x = self.trainX if train else self.validateX
-        return self._ensure_chain().forward(x, theta)
+        ch = self._ensure_chain()
+        if not train and not getattr(ch, "nv", 0):
+            return ch.forward(self.validateX, theta)
+        return ch.predict(0 if train else 1, theta)
+
+    def _metrics_on_device(self):
+        """The three reference metrics straight from the device (tbnn_metrics: forward + reduction, three doubles
+        back); False when the list holds anything else or no validation rows are staged -- then the predictions
+        go through `metrics` as in the reference."""
+        ch = self._ensure_chain()
+        if not getattr(ch, "nv", 0) or not all(type(m) in (SquaredError, PercentError, Accuracy) for m in self.metricList):
+            return False
+        theta = self._theta()
+        for m in self.metricList:
+            # metrics.py:44-47: SquaredError does not exponentiate the validation predictions
+            pv_exp = bool(m.scaleExp) and not isinstance(m, SquaredError)
+            tr = ch.metrics(0, theta, m.mean, m.sd, bool(m.scaleExp), bool(m.scaleExp))
+            va = ch.metrics(1, theta, m.mean, m.sd, pv_exp, bool(m.scaleExp))
+            if isinstance(m, SquaredError):
+                m.squaredErrorTrain, m.squaredErrorValidate = tr[0], va[0]
+            elif isinstance(m, PercentError):
+                m.percentErrorTrain, m.percentErrorValidate = tr[1], va[1]
+            else:
+                m.accuracyTrain, m.accuracyValidate = 1.0 - tr[2], 1.0 - va[2]
+            m.display()
+        return True
 
     def metrics(self, trainPredict, trainReal, validatePredict, validateReal):
         """network.py:60-82"""
@@ -188,7 +215,8 @@ class network(object):
                 print("leapfrog", self.leapfrog)
                 print("Main acceptance", self.mainAccept)
                 print("Hyper acceptance", self.hyperAccept)
-                self.metrics(self.predict(True), self.trainY, self.predict(False), self.validateY)
+                if not self._metrics_on_device():
+                    self.metrics(self.predict(True), self.trainY, self.predict(False), self.validateY)
             if self.adapt_enabled:                                           # :603-607
                 step, leap = self.adapt.update(self.states)
                 self.step_size, self.leapfrog = np.float32(step), np.int32(leap)

@@ -1,0 +1,53 @@
+"""GPU: predictions and metrics over the staged rows (tbnn_predict / tbnn_metrics)."""
+import numpy as np
+import pytest
+
+import tbnn_oracle as o
+from tensorbnn_amd import metrics as M
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "narrow": ([5, 50, 50, 50, 1], 2000, o.ACT_RELU, o.LIK_GAUSSIAN),          # generic forward kernel
+    "wide_resident": ([20, 100, 100, 2], 1500, o.ACT_RELU, o.LIK_BERNOULLI),   # k_chain_wide<S, FWD>, weights in LDS
+    "wide_stream": ([10, 200, 200, 200, 1], 1100, o.ACT_RELU, o.LIK_GAUSSIAN), # k_chain_wide<S, FWD>, streamed weights
+    "wide_ring_small": ([20, 32, 16, 48, 2], 700, o.ACT_SIGMOID, o.LIK_BERNOULLI),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_predict_and_metrics(native, case):
+    dims, n, act, lik = CASES[case]
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, act, o.PRIOR_CAUCHY, lik)
+    nv = n // 3 + 5
+    Xv, Yv = X[:nv] * 0.5 + 0.1, Y[:nv]
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    ch = native.Chain(layers, likelihood=spec.likelihood, kernel=native.KERNEL_AUTO)
+    ch.set_data(X, Y); ch.set_validation(Xv, Yv); ch.set_state(theta)
+    ref_t = o.forward(spec, theta, X, np.float64)
+    ref_v = o.forward(spec, theta, Xv, np.float64)
+    pt, pv = ch.predict(0), ch.predict(1)
+    np.testing.assert_allclose(pt, ref_t, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(pv, ref_v, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(ch.forward(Xv, theta), ref_v, rtol=2e-5, atol=2e-5)     # tbnn_forward takes the same kernel
+    # another theta without touching the chain state
+    th2 = (theta * 0.9).astype(np.float32)
+    np.testing.assert_allclose(ch.predict(1, th2), o.forward(spec, th2, Xv, np.float64), rtol=2e-5, atol=2e-5)
+    np.testing.assert_array_equal(ch.get_state(), theta)
+    # the three reference metrics (host NumPy restatement of metrics.py as the checker), incl. the scaleExp quirk
+    for scale_exp, mean, sd in ((False, 0.0, 1.0), (True, 0.3, 0.7)):
+        for cls, idx in ((M.SquaredError, 0), (M.PercentError, 1), (M.Accuracy, 2)):
+            m = cls(scaleExp=scale_exp, mean=mean, sd=sd)
+            m.calculate(pt, pv, Y, Yv)
+            pv_exp = scale_exp and cls is not M.SquaredError
+            tr = ch.metrics(0, None, mean, sd, scale_exp, scale_exp)[idx]
+            va = ch.metrics(1, None, mean, sd, pv_exp, scale_exp)[idx]
+            want_t, want_v = {0: (m.squaredErrorTrain, m.squaredErrorValidate) if idx == 0 else None,
+                              1: (m.percentErrorTrain, m.percentErrorValidate) if idx == 1 else None,
+                              2: (1 - m.accuracyTrain, 1 - m.accuracyValidate) if idx == 2 else None}[idx]
+            for got, want in ((tr, want_t), (va, want_v)):
+                if np.isfinite(want):
+                    assert abs(got - want) <= 2e-4 * abs(want) + 1e-6, (cls.__name__, scale_exp, got, want)
+                else:                       # percent error against zero targets: inf (or nan) on both sides
+                    assert not np.isfinite(got), (cls.__name__, scale_exp, got, want)
+    ch.close()

@@ -24,6 +24,7 @@ class FakeChain:
         self.calls = []
 
     def set_data(self, X, Y): pass
+    def set_validation(self, X, Y): pass       # nv stays 0: train() takes the host metrics path
     def set_state(self, t): self.theta = self.base = np.array(t, np.float32); self.k = 0
     def set_hypers(self, e): self.eta = self.ebase = np.array(e, np.float32); self.ke = 0
     def get_state(self): return self.theta.copy()
