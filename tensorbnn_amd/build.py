@@ -6,6 +6,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "tbnn_api.hip"), os.path.join(HERE, "csrc", "tbnn_wide.hip"),
        os.path.join(HERE, "csrc", "adapter.cpp")]
+# narrow kernels: the chain MFMAs write ArchVGPRs (their results feed the VALU), dW accumulators are pinned to
+# AccVGPRs by hand (kernels_fast.hpp, mfma16_acc)
+NARROW_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+PER_SOURCE_FLAGS = {"tbnn_api.hip": NARROW_FLAGS}
 OBJ_DIR = os.path.join(HERE, "_obj")
 OUT = os.path.join(HERE, "libtbnn.so")
 
@@ -29,7 +33,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs, objs = [], []
     for src in SRC:
         obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + PER_SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -149,6 +149,32 @@ __device__ unsigned long long g_tile_stamps[64];
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// dW accumulation with the accumulator pinned to AccVGPRs.  With -mllvm -amdgpu-mfma-vgpr-form (build.py, jit.py) the
+// compiler's own MFMAs -- the forward / delta chain, whose results the VALU consumes -- write ArchVGPRs directly (no
+// v_accvgpr_read per result register; on gfx950 every VALU instruction costs ~9 cycles of tile time because the f32
+// MFMA and the VALU share the issue slot, tools_ubench/coexec.hip), and the dW tiles, which only MFMAs touch inside
+// the row loop, must then not compete for the 256 ArchVGPRs.  No software wait states are inserted around inline asm:
+// FAR says the same accumulator is revisited only after at least one other MFMA (>= 32 cycles, beyond the MFMA->MFMA
+// SrcC requirement); otherwise the builtin is used.  Operands come from LDS loads; the kernels drain the pipe
+// (mfma_drain) before the epilogue reads the accumulators.  TBNN_ACC_AGPR=0: builtin everywhere.
+#ifndef TBNN_ACC_AGPR
+#define TBNN_ACC_AGPR 1
+#endif
+template <bool FAR>
+__device__ __forceinline__ void mfma16_acc(f32x4& c, float a, float b) {
+#if TBNN_ACC_AGPR
+    if constexpr (FAR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else c = mfma16(a, b, c);
+#else
+    c = mfma16(a, b, c);
+#endif
+}
+__device__ __forceinline__ void mfma_drain() {
+#if TBNN_ACC_AGPR
+    asm volatile("s_nop 15\n\ts_nop 15");
+#endif
+}
+
 // the NS (1..4) k-step operands of one k-group: 4, 8 or 16 bytes from LDS
 // (ns is a constant after unrolling: the branches fold)
 __device__ __forceinline__ f32x4 load_ks(const float* p, int ns) {
@@ -293,7 +319,7 @@ struct BwdOps {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    dW[C::dwoff(l) + mt * NT + nt] = mfma16(Aop[mt][s], Bop[nt][s], dW[C::dwoff(l) + mt * NT + nt]);
+                    mfma16_acc<(MT * NT > 1)>(dW[C::dwoff(l) + mt * NT + nt], Aop[mt][s], Bop[nt][s]);
     }
     // delta_{l-1} = (W_l^T dz) * act'(a_{l-1}); A operands from the transposed image, one k-group ahead
     static __device__ __forceinline__ void da(const TileRegs<S>& T, const float* __restrict__ lds, int i16, int g,
@@ -634,6 +660,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         if (first) { TB_STAMP(2); first = false; }
     }
     TB_STAMP(3);
+    mfma_drain();
     if (stamps && blockIdx.x == 0 && lane == 0) stamps[12 + wave] = wall_clock64();
 
     // ---- epilogue: every wave stages its dW tiles [wave][tile][lane] (16 B per lane), wave t%4 sums the

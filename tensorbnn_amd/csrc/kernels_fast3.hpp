@@ -22,6 +22,43 @@
 #ifndef TBNN_SGB
 #define TBNN_SGB 2
 #endif
+// 1: fringe dW rows in the B-operand layout (fewer registers: the f32 VALU shares the MFMA's issue slot, every
+// spill copy costs ~9 cycles of tile time); 0: per-lane sums in the D layout (the first fast3 version)
+#ifndef TBNN_F3_FB
+#define TBNN_F3_FB 1
+#endif
+// 1: thread the LDS instructions of issue(l) through the (asm) dW MFMAs of layer l+1 by hand
+#ifndef TBNN_F3_THREAD
+#define TBNN_F3_THREAD 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Packed f32 FMA as an opaque instruction.  The compiler's pre-emit peephole splits a v_pk_fma_f32 that follows an
+// MFMA into two v_fma_f32 on the assumption that they run in the MFMA's shadow; on gfx950 an f32 MFMA and the f32
+// VALU share the issue slot (tools_ubench/coexec.hip: +8.6 cycles per VALU instruction either way), so the split
+// doubles the cost.  Operands of these helpers are never raw MFMA results (no software wait states are inserted
+// for inline asm): callers pass activation outputs, LDS loads or VALU results only.
+__device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// a * (b[H], b[H]) + c
+template <int H>
+__device__ __forceinline__ f32x2 pkfma_bc(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    if constexpr (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// a * (b[H], b[H])
+template <int H>
+__device__ __forceinline__ f32x2 pkmul_bc(f32x2 a, f32x2 b) {
+    f32x2 d;
+    if constexpr (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 template <class S>
 struct F3Cfg : FastCfg<S> {
@@ -37,7 +74,11 @@ struct F3Cfg : FastCfg<S> {
     static constexpr int DW3_TILES = dwoff3(B::NL);
     // per-lane k-slots of layer l's input: natural x for layer 0, else 4 registers of every tile of a_{l-1}
     static constexpr int KIN(int l) { return l == 0 ? B::KS0 : 4 * B::MT(l - 1); }
-    static constexpr int fpoff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += NF(m) * (KIN(m) + 1); return o; }
+    // fringe rows of dW: layers with an MFMA dW part accumulate them in the *B-operand* layout (the a_{l-1} image
+    // registers that feed dW_l anyway): 2 registers per N tile instead of NF*(KIN+1) per-lane sums in the D layout.
+    static constexpr bool FB(int l) { return TBNN_F3_FB && NF(l) > 0 && MTF(l) > 0; }
+    static constexpr int fpn(int l) { return NF(l) == 0 ? 0 : (FB(l) ? 2 * B::NT(l) : NF(l) * (KIN(l) + 1)); }
+    static constexpr int fpoff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += fpn(m); return o; }
     static constexpr int FP_REGS = fpoff(B::NL);
     static constexpr int maxNF() { int m = 0; for (int l = 0; l < B::NL; ++l) m = NF(l) > m ? NF(l) : m; return m; }
     static constexpr int EP3_WANT = DW3_TILES * FAST_WAVES * 256 <= 39936 ? DW3_TILES : (DW3_TILES < 16 ? DW3_TILES : 16);
@@ -47,7 +88,8 @@ struct F3Cfg : FastCfg<S> {
     static constexpr int PR = 20;
     static constexpr int aoff3(int l) { int o = 0; for (int m = 0; m < l && m < NLM3; ++m) o += 16 * B::NT(m) * PR; return o; }
     static constexpr int doff3 = aoff3(NLM3);
-    static constexpr int WAVE3_FLOATS = doff3 + 16 * B::maxMT() * PR;
+    static constexpr int fdoff3 = doff3 + 16 * B::maxMT() * PR;   // fringe deltas [lane group copy][row][NF]: 4 x 32 floats
+    static constexpr int WAVE3_FLOATS = fdoff3 + 128;
     static constexpr int MIN3 = B::STATIC_FLOATS + FAST_WAVES * WAVE3_FLOATS;
     static constexpr int LDS3_A = MIN3 > EP3_WANT * FAST_WAVES * 256 ? MIN3 : EP3_WANT * FAST_WAVES * 256;
     static constexpr int LDS3_FLOATS = LDS3_A > FAST_WAVES * (FP_REGS > 0 ? FP_REGS : 1) * 64 ? LDS3_A : FAST_WAVES * FP_REGS * 64;
@@ -73,18 +115,64 @@ __device__ __forceinline__ float gsum(float p) {
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
-// sum_k w[k-slot] * v[k-slot] over this lane's k-slots of a K dimension living in D-layout tiles
+// TBNN_F3_M4 (default): the fringe dot products on the 16-block v_mfma_f32_4x4x1_f32 instead of VALU FMAs.
+// Block b = lane/4 = (lane group g, row quad i16/4) multiplies A[m = i16&3] = W[fringe unit m][k-slot of group g] by
+// B[n = i16&3] = a[k-slot][row i16] -- the D-layout activation register as it stands -- so after one instruction per
+// k-slot register, accumulator register m of every lane holds exactly the per-lane partial sum that dot_slots computes
+// for fringe unit m (2 passes = 8 cycles per instruction against ~12 cycles per dependent packed FMA).  The sum over
+// the 4 lane groups is ONE 16x16x4 MFMA with A = 1 (B[k = g][n = i16] is the register of partials as it stands, C
+// carries the bias): every register of every lane of the result holds the finished pre-activation of row i16.
+#ifndef TBNN_F3_M4
+#define TBNN_F3_M4 1
+#endif
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+// prow: this lane's A-operand row (image row 16*MTF + 4*(i16&3), + 4g); tiles: the K dimension in D-layout registers
 template <class S, int K>
+__device__ __forceinline__ f32x4 fringe_partials(const float* __restrict__ prow, const f32x4* tiles) {
+    using C = F3Cfg<S>;
+    // one accumulator per k-group: independent chains (a dependent 4x4x1 waits for the previous result), summed at the end
+    constexpr int KG = C::cdiv(K, 16);
+    f32x4 acc[KG];
+#pragma unroll
+    for (int kt = 0; kt < KG; ++kt) {
+        acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 w = load_ks(prow + 16 * kt, C::ksteps(K, kt));
+#pragma unroll
+        for (int s = 0; s < C::ksteps(K, kt); ++s) acc[kt] = mfma4(w[s], tiles[kt][s], acc[kt]);
+    }
+#pragma unroll
+    for (int st = 1; st < KG; st *= 2)
+#pragma unroll
+        for (int kt = 0; kt + st < KG; kt += 2 * st) acc[kt] += acc[kt + st];
+    return acc[0];
+}
+// sum over the 4 lane groups + c, broadcast to every lane (row i16)
+__device__ __forceinline__ float gsum_mfma(float p, float c) {
+    return mfma16(1.f, p, f32x4{c, c, c, c})[0];
+}
+
+// sum_k w[k-slot] * v[k-slot] over this lane's k-slots of a K dimension living in D-layout tiles
+// PK: `tiles` hold VALU results (activation outputs / masked deltas), so the opaque packed FMA may read them
+template <class S, int K, bool PK>
 __device__ __forceinline__ float dot_slots(const float* __restrict__ row, const f32x4* tiles, int g) {
     using C = F3Cfg<S>;
+    // pairs of k-slots on v_pk_fma_f32 (two partial sums), the odd one out on a plain FMA
+    f32x2 p2 = {0.f, 0.f};
     float p = 0.f;
 #pragma unroll
     for (int kt = 0; kt < C::cdiv(K, 16); ++kt) {
         const f32x4 w = load_ks(row + 16 * kt + 4 * g, C::ksteps(K, kt));
+        const int ns = C::ksteps(K, kt);
 #pragma unroll
-        for (int s = 0; s < C::ksteps(K, kt); ++s) p = fmaf(w[s], tiles[kt][s], p);
+        for (int s = 0; s + 1 < ns; s += 2) {
+            if constexpr (PK) p2 = pkfma(f32x2{w[s], w[s + 1]}, f32x2{tiles[kt][s], tiles[kt][s + 1]}, p2);
+            else p2 = f32x2{w[s], w[s + 1]} * f32x2{tiles[kt][s], tiles[kt][s + 1]} + p2;
+        }
+        if (ns & 1) p = fmaf(w[ns - 1], tiles[kt][ns - 1], p);
     }
-    return p;
+    return (p2[0] + p2[1]) + p;
 }
 
 template <class S, int l>
@@ -117,15 +205,25 @@ struct Fwd3 {
         f32x4 Anext[MTN], Bnext[MTN];
         // ---- fringe units on the VALU (issued first: their two lane shuffles land under the MFMAs below)
         float pf[NF > 0 ? NF : 1];
+        f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (NF > 0 && TBNN_F3_M4) {
+            const float* prow = lds + C::woff(l) + (16 * MT + 4 * (i16 & 3)) * C::LDW(l);
+            if constexpr (l == 0) {
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
+                for (int t = 0; t < C::KS0; ++t) pacc = mfma4(prow[4 * t + g], T.x0[t], pacc);
+            } else {
+                pacc = fringe_partials<S, C::in(l)>(prow + 4 * g, &T.a[C::aroff(l - 1)]);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < (TBNN_F3_M4 ? 0 : NF); ++f) {
             const float* row = lds + C::woff(l) + C::fslot(l, f) * C::LDW(l);
             float p = 0.f;
             if constexpr (l == 0) {
 #pragma unroll
                 for (int t = 0; t < C::KS0; ++t) p = fmaf(row[4 * t + g], T.x0[t], p);
             } else {
-                p = dot_slots<S, C::in(l)>(row, &T.a[C::aroff(l - 1)], g);
+                p = dot_slots<S, C::in(l), S::act(l - 1) != TBNN_ACT_NONE>(row, &T.a[C::aroff(l - 1)], g);
             }
             pf[f] = p;
         }
@@ -177,7 +275,9 @@ struct Fwd3 {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const float z = gsum(pf[f]) + lds[C::boff(l) + C::fslot(l, f)];
+                float z;
+                if constexpr (TBNN_F3_M4) z = gsum_mfma(pacc[f], lds[C::boff(l) + C::fslot(l, f)]);
+                else z = gsum(pf[f]) + lds[C::boff(l) + C::fslot(l, f)];
                 T.af[l][f] = actc_fwd<S::act(l)>(z);
                 if (g == f) v[0] = T.af[l][f];
             }
@@ -211,13 +311,23 @@ struct FringeDW {
     using C = F3Cfg<S>;
     static __device__ __forceinline__ void run(float (&FP)[C::FP_REGS > 0 ? C::FP_REGS : 1], const Tile3<S>& T,
                                                 const float (&dzf)[C::maxNF() > 0 ? C::maxNF() : 1], int g) {
-        constexpr int NF = C::NF(l), KIN = C::KIN(l);
+        constexpr int NF = C::FB(l) ? 0 : C::NF(l), KIN = C::KIN(l);
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             float* fp = FP + C::fpoff(l) + f * (KIN + 1);
             if constexpr (l == 0) {
 #pragma unroll
                 for (int t = 0; t < C::KS0; ++t) fp[t] = fmaf(dzf[f], T.x0[t], fp[t]);
+            } else if constexpr (S::act(l - 1) != TBNN_ACT_NONE) {
+                const f32x2 d2 = {dzf[f], dzf[f]};
+#pragma unroll
+                for (int kt = 0; kt < C::MT(l - 1); ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 v = pkfma_bc<0>(f32x2{T.a[C::aroff(l - 1) + kt][r], T.a[C::aroff(l - 1) + kt][r + 1]}, d2,
+                                                    f32x2{fp[4 * kt + r], fp[4 * kt + r + 1]});
+                        fp[4 * kt + r] = v[0]; fp[4 * kt + r + 1] = v[1];
+                    }
             } else {
 #pragma unroll
                 for (int kt = 0; kt < C::MT(l - 1); ++kt)
@@ -237,11 +347,17 @@ struct Bwd3 {
     static constexpr int MTd = MT > 0 ? MT : 1, NFd = C::maxNF() > 0 ? C::maxNF() : 1;
 
     // W(D_l) R(op_l): only when the layer has an MFMA dW part
-    static __device__ __forceinline__ void issue(const f32x4 (&dz)[C::MT(l)], float* wl, int i16, int g,
-                                                  float (&Aop)[MTd][4], float (&Bop)[NT][4]) {
+    static __device__ __forceinline__ void issue(const f32x4 (&dz)[C::MT(l)], const float (&dzf)[NFd], float* wl, int i16, int g,
+                                                  float (&Aop)[MTd][4], float (&Bop)[NT][4], float (&Fop)[8]) {
         if constexpr (MT > 0) {
             float* dimg = wl + C::doff3;
             const float* aimg = wl + C::aoff3(l);
+            if constexpr (C::FB(l)) {
+                // fringe deltas of rows 4g..4g+3 for every lane: each lane group keeps its own copy [row][NF]
+                float* fd = wl + C::fdoff3 + 32 * g;
+                if constexpr (NF == 2) *reinterpret_cast<f32x2*>(fd + 2 * i16) = f32x2{dzf[0], dzf[1]};
+                else fd[i16] = dzf[0];
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -258,6 +374,87 @@ struct Bwd3 {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) Aop[mt][s] = a[s];
             }
+            if constexpr (C::FB(l)) {
+                const float* fd = wl + C::fdoff3 + 32 * g;
+                if constexpr (NF == 2) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(fd + 8 * g), v = *reinterpret_cast<const f32x4*>(fd + 8 * g + 4);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { Fop[s] = u[s]; Fop[4 + s] = v[s]; }
+                } else {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(fd + 4 * g);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) Fop[s] = u[s];
+                }
+            }
+        }
+    }
+    // issue() one LDS instruction (pair) at a time, so that Pipe3 can thread it through the dW MFMAs of the layer above
+    // (an asm-volatile MFMA pins the memory operations around it, the order written here is the order issued)
+    static constexpr int NWR = MT > 0 ? 2 * MT + (C::FB(l) ? 1 : 0) : 0;
+    static constexpr int NRD = MT > 0 ? NT + MT + (C::FB(l) ? (NF == 2 ? 2 : 1) : 0) : 0;
+    static constexpr int NLDS = NWR + NRD;
+    static __device__ __forceinline__ void issue_step(int i, const f32x4 (&dz)[C::MT(l)], const float (&dzf)[NFd], float* wl, int i16, int g,
+                                                       float (&Aop)[MTd][4], float (&Bop)[NT][4], float (&Fop)[8]) {
+        if constexpr (MT > 0) {
+            float* dimg = wl + C::doff3;
+            const float* aimg = wl + C::aoff3(l);
+            float* fd = wl + C::fdoff3 + 32 * g;
+            if (i < 2 * MT) {
+                const int mt = i >> 1, r = 2 * (i & 1);
+                dimg[(16 * mt + 4 * g + r) * C::PR + i16] = dz[mt][r];
+                dimg[(16 * mt + 4 * g + r + 1) * C::PR + i16] = dz[mt][r + 1];
+            } else if (C::FB(l) && i == 2 * MT) {
+                if constexpr (NF == 2) *reinterpret_cast<f32x2*>(fd + 2 * i16) = f32x2{dzf[0], dzf[1]};
+                else fd[i16] = dzf[0];
+            } else {
+                const int j = i - NWR;
+                if (j < NT) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(aimg + (16 * j + i16) * C::PR + 4 * g);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) Bop[j][s] = b[s];
+                } else if (j < NT + MT) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(dimg + (16 * (j - NT) + i16) * C::PR + 4 * g);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) Aop[j - NT][s] = a[s];
+                } else {
+                    const int h = j - NT - MT;
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(fd + (NF == 2 ? 8 : 4) * g + 4 * h);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) Fop[4 * h + s] = u[s];
+                }
+            }
+        }
+    }
+    static constexpr int NMF = MT > 0 ? 4 * MT * NT : 0;
+    static __device__ __forceinline__ void dw_step(int j, f32x4 (&dW)[C::DW3_TILES > 0 ? C::DW3_TILES : 1], const float (&Aop)[MTd][4],
+                                                    const float (&Bop)[NT][4]) {
+        if constexpr (MT > 0) {
+            const int s = j / (MT * NT), mt = (j / NT) % MT, nt = j % NT;
+            mfma16_acc<(MT * NT > 1)>(dW[C::dwoff3(l) + mt * NT + nt], Aop[mt][s], Bop[nt][s]);
+        }
+    }
+    // fringe rows of dW_l in the B-operand layout: lane (i16, g) sums delta_f[row 4g+s] * a_{l-1}[slot 16nt+i16][row 4g+s]
+    // over its 4 rows; the epilogue adds the 4 lane groups.  NF == 2: one v_pk_fma per (nt, s) for both units;
+    // NF == 1: pairs of rows.
+    static __device__ __forceinline__ void fdw(float (&FP)[C::FP_REGS > 0 ? C::FP_REGS : 1], const float (&Fop)[8],
+                                                const float (&Bop)[NT][4]) {
+        if constexpr (C::FB(l)) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x2 acc = {FP[C::fpoff(l) + 2 * nt], FP[C::fpoff(l) + 2 * nt + 1]};
+                const f32x2 b01 = {Bop[nt][0], Bop[nt][1]}, b23 = {Bop[nt][2], Bop[nt][3]};
+                if constexpr (NF == 2) {
+                    acc = pkfma_bc<0>(f32x2{Fop[0], Fop[1]}, b01, acc);
+                    acc = pkfma_bc<1>(f32x2{Fop[2], Fop[3]}, b01, acc);
+                    acc = pkfma_bc<0>(f32x2{Fop[4], Fop[5]}, b23, acc);
+                    acc = pkfma_bc<1>(f32x2{Fop[6], Fop[7]}, b23, acc);
+                } else {
+                    acc = pkfma(f32x2{Fop[0], Fop[1]}, b01, acc);
+                    acc = pkfma(f32x2{Fop[2], Fop[3]}, b23, acc);
+                }
+                FP[C::fpoff(l) + 2 * nt] = acc[0];
+                FP[C::fpoff(l) + 2 * nt + 1] = acc[1];
+            }
         }
     }
     static __device__ __forceinline__ void dw(f32x4 (&dW)[C::DW3_TILES > 0 ? C::DW3_TILES : 1], const float (&Aop)[MTd][4],
@@ -269,7 +466,7 @@ struct Bwd3 {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        dW[C::dwoff3(l) + mt * NT + nt] = mfma16(Aop[mt][s], Bop[nt][s], dW[C::dwoff3(l) + mt * NT + nt]);
+                        mfma16_acc<(MT * NT > 1)>(dW[C::dwoff3(l) + mt * NT + nt], Aop[mt][s], Bop[nt][s]);
         }
     }
     // delta_{l-1} (full tiles + fringe) from delta_l
@@ -280,10 +477,13 @@ struct Bwd3 {
             constexpr int MTP = C::MTF(l - 1), NFP = C::NF(l - 1), K = C::out(l);
             // fringe units of layer l-1 first (their shuffles land under the MFMAs)
             float pf[NFP > 0 ? NFP : 1];
-            if constexpr (MT > 0) {
+            f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (MT > 0 && NFP > 0 && TBNN_F3_M4)
+                pacc = fringe_partials<S, K>(lds + C::toff(l) + (16 * MTP + 4 * (i16 & 3)) * C::LDT(l) + 4 * g, dz);
+            if constexpr (MT > 0 && !TBNN_F3_M4) {
 #pragma unroll
                 for (int f = 0; f < NFP; ++f)
-                    pf[f] = dot_slots<S, K>(lds + C::toff(l) + C::fslot(l - 1, f) * C::LDT(l), dz, g);
+                    pf[f] = dot_slots<S, K, S::act(l) != TBNN_ACT_NONE>(lds + C::toff(l) + C::fslot(l - 1, f) * C::LDT(l), dz, g);
             }
             if constexpr (MT > 0) {
                 constexpr int KG = C::cdiv(K, 16);
@@ -313,18 +513,21 @@ struct Bwd3 {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dzp[m][r] = actc_bwd_mul<S::act(l - 1)>(acc[m][r], T.a[C::aroff(l - 1) + m][r]);
 #pragma unroll
-                for (int f = 0; f < NFP; ++f) dzpf[f] = actc_bwd_mul<S::act(l - 1)>(gsum(pf[f]), T.af[l - 1][f]);
+                for (int f = 0; f < NFP; ++f)
+                    dzpf[f] = actc_bwd_mul<S::act(l - 1)>(TBNN_F3_M4 ? gsum_mfma(pacc[f], 0.f) : gsum(pf[f]), T.af[l - 1][f]);
             } else {
                 // all-fringe layer (the VALU last layer): K = NF fringe deltas, weights W_l[o][slot] read per lane
 #pragma unroll
                 for (int m = 0; m < MTP; ++m) {
-                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                    f32x2 d01, d23;
 #pragma unroll
                     for (int o = 0; o < NF; ++o) {
                         const f32x4 w = *reinterpret_cast<const f32x4*>(lds + C::woff(l) + C::fslot(l, o) * C::LDW(l) + 16 * m + 4 * g);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) d[r] = fmaf(w[r], dzf[o], d[r]);
+                        const f32x2 dd = {dzf[o], dzf[o]};
+                        if (o == 0) { d01 = pkmul_bc<0>(f32x2{w[0], w[1]}, dd); d23 = pkmul_bc<0>(f32x2{w[2], w[3]}, dd); }
+                        else { d01 = pkfma_bc<0>(f32x2{w[0], w[1]}, dd, d01); d23 = pkfma_bc<0>(f32x2{w[2], w[3]}, dd, d23); }
                     }
+                    const float d[4] = {d01[0], d01[1], d23[0], d23[1]};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dzp[m][r] = actc_bwd_mul<S::act(l - 1)>(d[r], T.a[C::aroff(l - 1) + m][r]);
                 }
@@ -356,10 +559,13 @@ struct Pipe3 {
     static __device__ __forceinline__ void run(f32x4 (&dW)[C::DW3_TILES > 0 ? C::DW3_TILES : 1], float (&FP)[C::FP_REGS > 0 ? C::FP_REGS : 1],
                                                 const Tile3<S>& T, const float* __restrict__ lds, float* wl, int i16, int g,
                                                 const f32x4 (&dz)[C::MT(l)], const float (&dzf)[NFd],
-                                                const float (&Aup)[Bwd3<S, l + 1>::MTd][4], const float (&Bup)[C::NT(l + 1)][4]) {
-        float Aop[Bwd3<S, l>::MTd][4], Bop[C::NT(l)][4];
-        Bwd3<S, l>::issue(dz, wl, i16, g, Aop, Bop);
-#if TBNN_SGB > 0
+                                                const float (&Aup)[Bwd3<S, l + 1>::MTd][4], const float (&Bup)[C::NT(l + 1)][4],
+                                                const float (&Fup)[8]) {
+        float Aop[Bwd3<S, l>::MTd][4], Bop[C::NT(l)][4], Fop[8];
+#if !(TBNN_ACC_AGPR && TBNN_F3_THREAD)
+        Bwd3<S, l>::issue(dz, dzf, wl, i16, g, Aop, Bop, Fop);
+#endif
+#if TBNN_SGB > 0 && !TBNN_ACC_AGPR
         // the ~20 LDS instructions of issue(l) cost ~450 issue cycles on their own: thread them through the
         // 48 MFMAs of dW_{l+1} (operands already in registers) -- 2 MFMAs, 1 DS, 2 MFMAs, 1 DS, ...
         Bwd3<S, l + 1>::dw(dW, Aup, Bup);
@@ -373,6 +579,19 @@ struct Pipe3 {
         }
         SCHED_FENCE();
         TSTAMP(10 + 4 * l);
+#elif TBNN_ACC_AGPR && TBNN_F3_THREAD
+        {
+            constexpr int NM = Bwd3<S, l + 1>::NMF, NL = Bwd3<S, l>::NLDS;
+            static_assert(NM > 0, "the layer above has an MFMA dW part");
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+                Bwd3<S, l + 1>::dw_step(j, dW, Aup, Bup);
+#pragma unroll
+                for (int k = (j * NL) / NM; k < ((j + 1) * NL) / NM; ++k) Bwd3<S, l>::issue_step(k, dz, dzf, wl, i16, g, Aop, Bop, Fop);
+            }
+        }
+        SCHED_FENCE();
+        TSTAMP(10 + 4 * l);
 #else
         SCHED_FENCE();
         TSTAMP(10 + 4 * l);
@@ -380,6 +599,7 @@ struct Pipe3 {
         SCHED_FENCE();
 #endif
         TSTAMP(11 + 4 * l);
+        Bwd3<S, l + 1>::fdw(FP, Fup, Bup);
         FringeDW<S, l>::run(FP, T, dzf, g);
         TSTAMP(12 + 4 * l);
         if constexpr (l > 0) {
@@ -388,9 +608,10 @@ struct Pipe3 {
             Bwd3<S, l>::da(T, lds, i16, g, dz, dzf, dzp, dzpf);
             SCHED_FENCE();
             TSTAMP(13 + 4 * l);
-            Pipe3<S, l - 1>::run(dW, FP, T, lds, wl, i16, g, dzp, dzpf, Aop, Bop);
+            Pipe3<S, l - 1>::run(dW, FP, T, lds, wl, i16, g, dzp, dzpf, Aop, Bop, Fop);
         } else {
             Bwd3<S, 0>::dw(dW, Aop, Bop);
+            Bwd3<S, 0>::fdw(FP, Fop, Bop);
             TSTAMP(13);
         }
     }
@@ -430,11 +651,34 @@ struct SlabOut3 {
 template <class S, int l>
 struct FringeOut {
     using C = F3Cfg<S>;
-    // thread (item = (f, kslot, g), wave): item count per layer = NF * (KIN+1) * 4 lane groups
+    // staging: lb[(wave * FP_REGS + reg) * 64 + lane]
     static __device__ __forceinline__ void run(const float* lb, float* __restrict__ slab, int tid) {
         constexpr int NF = C::NF(l), KIN = C::KIN(l), in = C::in(l), out = C::out(l);
-        constexpr int NI = NF * (KIN + 1) * 4;
+        if constexpr (C::FB(l)) {
+            // B-operand layout: item = (f, nt, i16): sum over the 4 waves x 4 lane groups (x 2 row pairs when NF == 1)
+            constexpr int NT = C::NT(l), NI = NF * NT * 16;
+            for (int it = tid; it < NI; it += FAST_THREADS) {
+                const int i16 = it & 15, nt = (it >> 4) % NT, f = it / (16 * NT);
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < FAST_WAVES; ++w) {
+                    float vw = 0.f;
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        if constexpr (NF == 2) vw += lb[(size_t)(w * C::FP_REGS + C::fpoff(l) + 2 * nt + f) * 64 + 16 * gg + i16];
+                        else vw += lb[(size_t)(w * C::FP_REGS + C::fpoff(l) + 2 * nt) * 64 + 16 * gg + i16] +
+                                   lb[(size_t)(w * C::FP_REGS + C::fpoff(l) + 2 * nt + 1) * 64 + 16 * gg + i16];
+                    }
+                    v += vw;
+                }
+                const int cs = 16 * nt + i16, u = C::funit(l, f);
+                const int col = l == 0 ? (cs <= in ? cs : -1) : unit_of(in, cs, true);
+                if (col >= 0) slab[C::offW(l) + (col < in ? u * in + col : in * out + u)] = v;
+            }
+        } else
+        // D layout: thread (item = (f, kslot, g), wave): item count per layer = NF * (KIN+1) * 4 lane groups
         if constexpr (NF > 0) {
+            constexpr int NI = NF * (KIN + 1) * 4;
             for (int base = 0; base < NI * FAST_WAVES; base += FAST_THREADS) {
                 const int t = base + tid;
                 const int it = t >> 2, w = t & 3;
@@ -565,8 +809,8 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         TSTAMP(31);
         {
             constexpr int LM = L - 1;
-            float Aop[Bwd3<S, LM>::MTd][4], Bop[C::NT(LM)][4];
-            Bwd3<S, LM>::issue(dzp, wl, i16, g, Aop, Bop);
+            float Aop[Bwd3<S, LM>::MTd][4], Bop[C::NT(LM)][4], Fop[8];
+            Bwd3<S, LM>::issue(dzp, dzpf, wl, i16, g, Aop, Bop, Fop);
             TSTAMP(32);
             FringeDW<S, LM>::run(FP, T, dzpf, g);
             TSTAMP(33);
@@ -576,14 +820,16 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                 Bwd3<S, LM>::da(T, lds, i16, g, dzp, dzpf, dzq, dzqf);
                 SCHED_FENCE();
                 TSTAMP(34);
-                Pipe3<S, LM - 1>::run(dW, FP, T, lds, wl, i16, g, dzq, dzqf, Aop, Bop);
+                Pipe3<S, LM - 1>::run(dW, FP, T, lds, wl, i16, g, dzq, dzqf, Aop, Bop, Fop);
             } else {
                 Bwd3<S, 0>::dw(dW, Aop, Bop);
+                Bwd3<S, 0>::fdw(FP, Fop, Bop);
             }
         }
         if (first) { TB_STAMP(2); first = false; }
     }
     TB_STAMP(3);
+    mfma_drain();
 
     // ---- epilogue
     const double wtot = wave_sum(stat);

@@ -17,7 +17,15 @@
 #include "kernels_hmc.hpp"
 #include "kernels_hyper.hpp"
 #include "kernels_fast.hpp"
+// kernels_fast2.hpp (two waves per SIMD, a measured negative result) is only built on request: it needs the
+// AGPR-form build (no -amdgpu-mfma-vgpr-form, -DTBNN_ACC_AGPR=0) to fit its 256-register budget
+#ifdef TBNN_WITH_FAST2
 #include "kernels_fast2.hpp"
+#else
+static inline bool fast2_available(int) { return false; }
+template <class... A> static inline int fast2_launch(A...) { return -1; }
+__device__ unsigned long long g_ring_wait_cycles[2];
+#endif
 #include "kernels_fast3.hpp"
 #include "wide_api.hpp"
 #include "fused_ops.hpp"

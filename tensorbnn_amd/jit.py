@@ -22,6 +22,8 @@ import subprocess
 import sys
 from typing import Optional, Sequence
 
+NARROW_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]      # keep in step with build.py
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 NARROW_TILES = 40
@@ -111,7 +113,10 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
         with open(src, "w") as f:
             f.write(source(dims, hact, lact, bern, fam))
         tmp = so + f".{os.getpid()}.tmp"
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", tmp, src]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
+        if fam != "wide":
+            cmd += NARROW_FLAGS          # as build.py compiles the narrow kernels (VGPR-form chain MFMAs)
+        cmd += ["-o", tmp, src]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)      # a child process: never an exec of this one
