@@ -159,6 +159,12 @@ int tbnn_set_validation(tbnn_handle h, const float* X, const float* Y, int64_t n
 /* network.predict(train=True/False) (network.py:141-171): which = 0 training rows, 1 validation rows;
  * theta NULL = current state; out: host [d_out, n] or NULL (predictions stay on the device). */
 int tbnn_predict(tbnn_handle h, int which, const float* theta, float* out);
+/* Ensemble prediction, predictor.predict (predictor.py:132-155): the forward pass of m saved
+ * networks, theta_i = thetas + i * theta_stride (theta_stride >= P floats), over the same rows.  X NULL: the staged
+ * rows selected by `which` (0 training, 1 validation); else n host rows [n, d_in].  out: host [m][d_out][n].
+ * Narrow shapes run one batched launch of the forward-only MFMA kernel (grid.y = network). */
+int tbnn_forward_many(tbnn_handle h, const float* thetas, int32_t m, int64_t theta_stride, int which, const float* X,
+                      int64_t n, float* out);
 /* metrics.py:30-141 in one pass over the predictions: with p = f*sd+mean, r = y*sd+mean (exp() of either on
  * request: scaleExp; SquaredError leaves the validation predictions un-exponentiated, metrics.py:44-47)
  *   out3[0] = mean (p-r)^2            SquaredError

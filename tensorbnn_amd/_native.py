@@ -77,6 +77,7 @@ SYMBOLS = [
     ("tbnn_set_profiling", C.c_int, [_H, C.c_int]),
     ("tbnn_set_validation", C.c_int, [_H, _fp, _fp, C.c_int64]),
     ("tbnn_predict", C.c_int, [_H, C.c_int, _fp, _fp]),
+    ("tbnn_forward_many", C.c_int, [_H, _fp, C.c_int32, C.c_int64, C.c_int, _fp, C.c_int64, _fp]),
     ("tbnn_metrics", C.c_int, [_H, C.c_int, _fp, C.c_float, C.c_float, C.c_int, C.c_int, _dp]),
     ("tbnn_register_kernel_lib", C.c_int, [C.c_char_p]),
     ("tbnn_fused_kernel_available", C.c_int, [C.POINTER(NetDesc)]),
@@ -274,6 +275,20 @@ class Chain:
         out = np.empty((self.d_out, n), dtype=np.float32)
         th = None if theta is None else _f32(theta).reshape(-1)
         _check(lib.tbnn_predict(self._h, int(which), _p(th), _p(out)))
+        return out
+
+    def forward_many(self, thetas, X=None, which: int = 1) -> np.ndarray:
+        """predictions of an ensemble: thetas [m, P] -> [m, d_out, rows]; X None: the staged rows (0 train, 1 validation)"""
+        th = np.ascontiguousarray(thetas, dtype=np.float32)
+        if th.ndim != 2 or th.shape[1] != self.P:
+            raise ValueError(f"thetas must be [m, {self.P}]")
+        if X is None:
+            n, xp = (self.nv if which else self.n), None
+        else:
+            xp = _f32(X).reshape(-1, self.d_in)
+            n = xp.shape[0]
+        out = np.empty((th.shape[0], self.d_out, n), dtype=np.float32)
+        _check(lib.tbnn_forward_many(self._h, _p(th), th.shape[0], th.shape[1], int(which), _p(xp), n, _p(out)))
         return out
 
     def metrics(self, which: int = 0, theta=None, mean: float = 0.0, sd: float = 1.0, exp_pred: bool = False,

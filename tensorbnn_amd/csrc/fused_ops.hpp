@@ -6,7 +6,7 @@
 #include "common.hpp"
 #include "wide_api.hpp"
 
-#define TBNN_JIT_ABI 2
+#define TBNN_JIT_ABI 3
 enum { TBNN_FAMILY_NARROW = 1, TBNN_FAMILY_WIDE = 2 };
 
 struct FusedOps {
@@ -21,6 +21,9 @@ struct FusedOps {
     int (*grid)(long n);
     int (*launch)(int grid, hipStream_t st, const NetDev* nd, const float* qimg, const float* eta, const float* X,
                   const float* Y, long n, float* slabs, int pitch, double* pstat);
+    // narrow family, optional: forward only for `nets` networks (images img_stride floats apart), fout[net][d_out][n]
+    int (*nforward)(int gx, int nets, hipStream_t st, const float* qimgs, long img_stride, const float* X, long n, float* fouts,
+                    long out_stride);
     // wide family: k_chain_wide + k_dw_wide + k_reduce_wide
     void (*plan)(long n, WidePlan* plan);
     int (*wlaunch)(const WidePlan* plan, hipStream_t st, const NetDev* nd, const float* qimg, const float* eta,

@@ -21,12 +21,22 @@ struct JitNarrow {
                                (unsigned long long*)nullptr);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
+    static int nforward(int gx, int nets, hipStream_t st, const float* qimgs, long img_stride, const float* X, long n, float* fouts,
+                        long out_stride) {
+        if constexpr (F3) {
+            hipLaunchKernelGGL(k_forward_fast3<S>, dim3(gx, nets), dim3(FAST_THREADS), 0, st, qimgs, img_stride, X, n, fouts, out_stride);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        } else {
+            return -1;
+        }
+    }
     static void image_map(int* map) { ImageMap<S, 0>::run(map); }
     static void fill(FusedOps* o) {
         fused_ops_shape<S>(o, F3 ? "jit-fast3" : "jit-fast");
         o->family = TBNN_FAMILY_NARROW;
         o->img_floats = FastCfg<S>::STATIC_FLOATS;
         o->image_map = &image_map; o->grid = &grid; o->launch = &launch;
+        o->nforward = F3 ? &nforward : nullptr;
         o->plan = nullptr; o->wlaunch = nullptr; o->wforward = nullptr;
     }
 };

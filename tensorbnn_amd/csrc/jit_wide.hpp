@@ -23,5 +23,6 @@ struct JitWide {
         o->image_map = &image_map; o->grid = nullptr; o->launch = nullptr;
         o->plan = &plan; o->wlaunch = &wlaunch;
         o->wforward = wide_forward_ok<S>() ? &wforward : nullptr;
+        o->nforward = nullptr;
     }
 };

@@ -175,7 +175,8 @@ __device__ __forceinline__ float dot_slots(const float* __restrict__ row, const 
     return (p2[0] + p2[1]) + p;
 }
 
-template <class S, int l>
+// IMG: write the transposed activation images the dW MFMAs read (off in the forward-only kernel)
+template <class S, int l, bool IMG = true>
 struct Fwd3 {
     using C = F3Cfg<S>;
     static __device__ __forceinline__ void preload(f32x4 (&An)[C::MTF(l) > 0 ? C::MTF(l) : 1], f32x4 (&Bn)[C::MTF(l) > 0 ? C::MTF(l) : 1],
@@ -284,7 +285,7 @@ struct Fwd3 {
             T.a[C::aroff(l) + MT] = v;
         }
         if constexpr (more) {
-            if constexpr (C::MTF(l + 1) > 0) {
+            if constexpr (IMG && C::MTF(l + 1) > 0) {
                 // transposed image of a_{l+1}'s input (= this layer's output) for the MFMA part of dW_{l+1}
                 constexpr int u1 = C::in(l + 1);
                 float* aimg = wl + C::aoff3(l + 1);
@@ -300,7 +301,7 @@ struct Fwd3 {
                 }
             }
             TSTAMP(1 + l);
-            Fwd3<S, l + 1>::run(T, lds, wl, i16, g, Anext, Bnext);
+            Fwd3<S, l + 1, IMG>::run(T, lds, wl, i16, g, Anext, Bnext);
         } else { TSTAMP(1 + l); }
     }
 };
@@ -864,6 +865,51 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #undef TB_STAMP
 }
 
+
+// Forward pass only (predictions): the same register-chained MFMA layers, no images, no likelihood, no backward.
+// blockIdx.y selects the network of an ensemble: weight image qimgs + y * img_stride, output fout + y * out_stride,
+// fout[d_out][n] per network (predictor.py:132-155 evaluates every saved network on the same rows).
+template <class S>
+__global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_forward_fast3(
+    const float* __restrict__ qimgs, long img_stride, const float* __restrict__ X, long n, float* __restrict__ fouts, long out_stride)
+{
+    using C = F3Cfg<S>;
+    static_assert(C::VL && C::NF(C::NL - 1) == C::out(C::NL - 1) && C::MTF(C::NL - 1) == 0, "fast3: last layer must be all-fringe");
+    __shared__ __attribute__((aligned(16))) float lds[C::WB_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, g = lane >> 4;
+    const float* qimg = qimgs + (size_t)blockIdx.y * img_stride;
+    float* fout = fouts + (size_t)blockIdx.y * out_stride;
+    {
+        constexpr int N4 = C::WB_FLOATS / 4;
+        static_assert(C::WB_FLOATS % 4 == 0, "image sections are 16-B multiples");
+        const float4* src = reinterpret_cast<const float4*>(qimg);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int e = tid; e < N4; e += FAST_THREADS) dst[e] = src[e];
+    }
+    __syncthreads();
+    constexpr int d_in = C::in(0), d_out = C::out(C::NL - 1), L = C::NL - 1;
+    const long ntiles = (n + 15) / 16;
+    const long W = (long)gridDim.x * FAST_WAVES;
+    f32x4 A0[C::MTF(0) > 0 ? C::MTF(0) : 1], B0[C::MTF(0) > 0 ? C::MTF(0) : 1];
+    Fwd3<S, 0, false>::preload(A0, B0, lds, i16, g);
+    for (long tile = (long)blockIdx.x * FAST_WAVES + wave; tile < ntiles; tile += W) {
+        Tile3<S> T;
+        const long row = tile * 16 + i16;
+        const bool ok = row < n;
+#pragma unroll
+        for (int t = 0; t < C::KS0; ++t) {
+            const int u = 4 * t + g;
+            T.x0[t] = (ok && u < d_in) ? X[row * d_in + u] : 0.f;
+        }
+        Fwd3<S, 0, false>::run(T, lds, nullptr, i16, g, A0, B0);
+        if (ok && g == 0) {
+#pragma unroll
+            for (int o = 0; o < d_out; ++o) fout[(size_t)o * n + row] = T.af[L][o];
+        }
+    }
+}
+
 #ifndef TBNN_NO_FAST_REGISTRY
 static inline bool fast3_available(int id) { return id == 0 || id == 1 || id == 2; }
 static inline int fast3_launch(int id, int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
@@ -873,6 +919,17 @@ static inline int fast3_launch(int id, int grid, hipStream_t st, const NetDev& n
         case 0: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeC2>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
         case 1: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeC1>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
         case 2: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeTR>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        default: return -1;
+    }
+    return 0;
+}
+// forward-only launch: `nets` networks (grid.y), gx workgroups each
+static inline int fast3_forward(int id, int gx, int nets, hipStream_t st, const float* qimgs, long img_stride, const float* X, long n,
+                                float* fouts, long out_stride) {
+    switch (id) {
+        case 0: hipLaunchKernelGGL(k_forward_fast3<ShapeC2>, dim3(gx, nets), dim3(FAST_THREADS), 0, st, qimgs, img_stride, X, n, fouts, out_stride); break;
+        case 1: hipLaunchKernelGGL(k_forward_fast3<ShapeC1>, dim3(gx, nets), dim3(FAST_THREADS), 0, st, qimgs, img_stride, X, n, fouts, out_stride); break;
+        case 2: hipLaunchKernelGGL(k_forward_fast3<ShapeTR>, dim3(gx, nets), dim3(FAST_THREADS), 0, st, qimgs, img_stride, X, n, fouts, out_stride); break;
         default: return -1;
     }
     return 0;

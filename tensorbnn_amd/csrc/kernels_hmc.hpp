@@ -146,8 +146,11 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
 }
 
 // scatter a flat theta into the padded weight image (bootstrap / tbnn_logp_grad)
+// blockIdx.y: network of an ensemble (q + y * q_stride -> qimg + y * img_stride; both strides 0 for a single one)
 __global__ __launch_bounds__(256) void k_make_image(int P, const float* __restrict__ q,
-                                                    const int* __restrict__ imgmap, float* __restrict__ qimg) {
+                                                    const int* __restrict__ imgmap, float* __restrict__ qimg,
+                                                    long q_stride = 0, long img_stride = 0) {
+    q += (size_t)blockIdx.y * q_stride; qimg += (size_t)blockIdx.y * img_stride;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < P) { const float v = q[j]; qimg[imgmap[j]] = v; const int m1 = imgmap[P + j]; if (m1 >= 0) qimg[m1] = v; }
 }

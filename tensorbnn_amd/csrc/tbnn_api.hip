@@ -630,6 +630,21 @@ extern "C" int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* et
     return 0;
 }
 
+// the narrow family's forward-only kernel exists for fast3 shapes (registry or run-time compiled)
+static inline bool narrow_fwd_ok(const tbnn_ctx* h) {
+    if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0) return false;
+    return h->jit ? h->jit->nforward != nullptr : h->fast_ver == 3;
+}
+// `nets` networks whose images lie img_stride floats apart -> outputs out_stride floats apart
+static int narrow_forward(tbnn_ctx* h, int nets, const float* imgs, long img_stride, const float* dX, long n, float* dOut, long out_stride) {
+    const long ntiles = (n + 15) / 16, wgs = (ntiles + FAST_WAVES - 1) / FAST_WAVES;
+    // one network: fill the chip; an ensemble: the networks (grid.y) do that, fewer workgroups each re-use the image more
+    const long cap = nets >= 64 ? 16 : (nets >= 8 ? 64 : 256);
+    const int gx = (int)std::max<long>(1, std::min<long>(wgs, cap));
+    return h->jit ? h->jit->nforward(gx, nets, h->stream, imgs, img_stride, dX, n, dOut, out_stride)
+                  : fast3_forward(h->fast_id, gx, nets, h->stream, imgs, img_stride, dX, n, dOut, out_stride);
+}
+
 // forward pass of the network at the weights q (device) over dX[n][d_in] -> dOut[d_out][n], on h->stream
 static int launch_forward(tbnn_ctx* h, const float* q, const float* dX, long n, float* dOut) {
     const NetDev& nd = h->nd;
@@ -640,6 +655,13 @@ static int launch_forward(tbnn_ctx* h, const float* q, const float* dX, long n, 
         const int rc = h->jit ? h->jit->wforward(h->stream, &h->nd, h->qimg_cur, dX, n, dOut)
                               : wide_forward(h->wide_id, h->stream, h->nd, h->qimg_cur, dX, n, dOut);
         if (rc) return fail(-2, "wide forward launch failed");
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (narrow_fwd_ok(h)) {
+        // MFMA forward of the narrow family (k_forward_fast3): image of q, one network
+        hipLaunchKernelGGL(k_make_image, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, q, h->imgmap, h->qimg_cur, 0L, 0L);
+        if (narrow_forward(h, 1, h->qimg_cur, 0, dX, n, dOut, 0)) return fail(-2, "fast3 forward launch failed");
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -718,6 +740,66 @@ extern "C" int tbnn_predict(tbnn_handle h, int which, const float* theta, float*
     if (out) HIPCHK(hipMemcpyAsync(out, h->fbuf, (size_t)n * h->nd.d_out * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
+}
+
+// Ensemble prediction (predictor.py:132-155): m networks, theta_i = thetas + i * theta_stride, over the same rows.
+// X == null: the staged rows selected by `which` (0 training, 1 validation); else n host rows.  out[m][d_out][n].
+extern "C" int tbnn_forward_many(tbnn_handle h, const float* thetas, int32_t m, int64_t theta_stride, int which, const float* X,
+                                 int64_t n, float* out) {
+    NEED(h);
+    const NetDev& nd = h->nd;
+    if (!thetas || !out || m < 1 || theta_stride < nd.P) return fail(-1, "forward_many: null pointer, m < 1 or theta_stride < P");
+    HIPCHK(hipSetDevice(h->device));
+    const float* dX = nullptr;
+    float* dXown = nullptr;
+    long rows = 0;
+    if (X) {
+        if (n < 1) return fail(-1, "forward_many: n < 1");
+        rows = (long)n;
+        HIPCHK(hipMalloc(&dXown, (size_t)rows * nd.d_in * sizeof(float)));
+        HIPCHK(hipMemcpyAsync(dXown, X, (size_t)rows * nd.d_in * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        dX = dXown;
+    } else {
+        if (which != 0 && which != 1) return fail(-1, "which must be 0 (training rows) or 1 (validation rows)");
+        dX = which ? h->dXv : h->dX; rows = which ? h->nv : h->n;
+        if (!dX || rows < 1) return fail(-1, which ? "tbnn_set_validation has not been called" : "tbnn_set_data has not been called");
+    }
+    const size_t per_net = (size_t)rows * nd.d_out;
+    // networks per pass: the output chunk stays below 1 GiB
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)m, ((size_t)1 << 28) / std::max<size_t>(per_net, 1)));
+    float *dTh = nullptr, *dOut = nullptr, *dImg = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() { if (dTh) hipFree(dTh); if (dOut) hipFree(dOut); if (dImg) hipFree(dImg); if (dXown) hipFree(dXown); };
+#define FM_CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(-2, hipGetErrorString(e_)); } } while (0)
+    FM_CHK(hipMalloc(&dTh, (size_t)chunk * nd.P * sizeof(float)));
+    FM_CHK(hipMalloc(&dOut, (size_t)chunk * per_net * sizeof(float)));
+    const bool batched = narrow_fwd_ok(h);
+    if (batched) {
+        FM_CHK(hipMalloc(&dImg, (size_t)chunk * h->img_floats * sizeof(float)));
+        FM_CHK(hipMemsetAsync(dImg, 0, (size_t)chunk * h->img_floats * sizeof(float), h->stream));
+    }
+    for (int i0 = 0; i0 < m && !rc; i0 += chunk) {
+        const int c = std::min(chunk, m - i0);
+        FM_CHK(hipMemcpy2DAsync(dTh, (size_t)nd.P * sizeof(float), thetas + (size_t)i0 * theta_stride, (size_t)theta_stride * sizeof(float),
+                                (size_t)nd.P * sizeof(float), (size_t)c, hipMemcpyHostToDevice, h->stream));
+        if (batched) {
+            hipLaunchKernelGGL(k_make_image, dim3((nd.P + 255) / 256, c), dim3(256), 0, h->stream, nd.P, (const float*)dTh, h->imgmap, dImg,
+                               (long)nd.P, (long)h->img_floats);
+            rc = narrow_forward(h, c, dImg, h->img_floats, dX, rows, dOut, (long)per_net);
+            if (rc) rc = fail(-2, "fast3 ensemble forward launch failed");
+        } else {
+            for (int i = 0; i < c && !rc; ++i) rc = launch_forward(h, dTh + (size_t)i * nd.P, dX, rows, dOut + (size_t)i * per_net);
+        }
+        if (!rc) {
+            FM_CHK(hipGetLastError());
+            FM_CHK(hipMemcpyAsync(out + (size_t)i0 * per_net, dOut, (size_t)c * per_net * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+            FM_CHK(hipStreamSynchronize(h->stream));
+        }
+    }
+#undef FM_CHK
+    hipStreamSynchronize(h->stream);
+    cleanup();
+    return rc;
 }
 
 extern "C" int tbnn_metrics(tbnn_handle h, int which, const float* theta, float mean, float sd, int exp_pred, int exp_real,

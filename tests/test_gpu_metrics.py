@@ -8,7 +8,8 @@ from tensorbnn_amd import metrics as M
 pytestmark = pytest.mark.gpu
 
 CASES = {
-    "narrow": ([5, 50, 50, 50, 1], 2000, o.ACT_RELU, o.LIK_GAUSSIAN),          # generic forward kernel
+    "narrow": ([5, 50, 50, 50, 1], 2000, o.ACT_RELU, o.LIK_GAUSSIAN),          # k_forward_fast3 (forward-only MFMA kernel)
+    "generic": ([3, 7, 5, 2], 900, o.ACT_TANH, o.LIK_GAUSSIAN),                  # k_forward_generic
     "wide_resident": ([20, 100, 100, 2], 1500, o.ACT_RELU, o.LIK_BERNOULLI),   # k_chain_wide<S, FWD>, weights in LDS
     "wide_stream": ([10, 200, 200, 200, 1], 1100, o.ACT_RELU, o.LIK_GAUSSIAN), # k_chain_wide<S, FWD>, streamed weights
     "wide_ring_small": ([20, 32, 16, 48, 2], 700, o.ACT_SIGMOID, o.LIK_BERNOULLI),
@@ -50,4 +51,35 @@ def test_predict_and_metrics(native, case):
                     assert abs(got - want) <= 2e-4 * abs(want) + 1e-6, (cls.__name__, scale_exp, got, want)
                 else:                       # percent error against zero targets: inf (or nan) on both sides
                     assert not np.isfinite(got), (cls.__name__, scale_exp, got, want)
+    ch.close()
+
+
+ENSEMBLE = {
+    "narrow_batched": ([5, 50, 50, 50, 1], 1777, o.ACT_RELU, o.LIK_GAUSSIAN, 37),     # one launch, grid.y = network
+    "narrow_tanh": ([1, 10, 10, 10, 1], 333, o.ACT_TANH, o.LIK_GAUSSIAN, 5),
+    "wide": ([20, 100, 100, 2], 900, o.ACT_RELU, o.LIK_BERNOULLI, 4),                 # per-network k_chain_wide<S, FWD>
+    "generic": ([3, 7, 5, 2], 500, o.ACT_SIGMOID, o.LIK_GAUSSIAN, 6),
+}
+
+
+@pytest.mark.parametrize("case", list(ENSEMBLE))
+def test_forward_many(native, case):
+    """tbnn_forward_many (predictor.predict, predictor.py:132-155): every network of an ensemble against the oracle,
+    over host rows and over the staged validation rows; the chain state stays untouched"""
+    dims, n, act, lik, m = ENSEMBLE[case]
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, act, o.PRIOR_CAUCHY, lik)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    ch = native.Chain(layers, likelihood=spec.likelihood, kernel=native.KERNEL_AUTO)
+    ch.set_data(X, Y); ch.set_state(theta)
+    rng = np.random.default_rng(5)
+    thetas = (theta[None, :] * (1.0 + 0.3 * rng.standard_normal((m, theta.size)))).astype(np.float32)
+    Xq = (X[: n // 2 + 3] * 0.7 - 0.05).astype(np.float32)
+    got = ch.forward_many(thetas, X=Xq)
+    assert got.shape == (m, dims[-1], Xq.shape[0])
+    for i in range(m):
+        np.testing.assert_allclose(got[i], o.forward(spec, thetas[i], Xq, np.float64), rtol=2e-5, atol=2e-5)
+    ch.set_validation(Xq, Y[: Xq.shape[0]])
+    np.testing.assert_array_equal(ch.forward_many(thetas, which=1), got)       # staged rows: same kernel, same numbers
+    np.testing.assert_allclose(ch.forward_many(thetas[:2], which=0)[1], o.forward(spec, thetas[1], X, np.float64), rtol=2e-5, atol=2e-5)
+    np.testing.assert_array_equal(ch.get_state(), theta)
     ch.close()

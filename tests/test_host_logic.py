@@ -165,7 +165,10 @@ def test_two_process_gloo_gather(tmp_path):
     per-chain reference-format folders rank 0 writes."""
     script = tmp_path / "worker.py"
     script.write_text(GLOO_WORKER)
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:                      # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script), ROOT, str(tmp_path / "out")]
     env = dict(os.environ, OMP_NUM_THREADS="1")
