@@ -3,8 +3,16 @@
 Reads the reference's on-disk sample format (summary.txt, <n>.<k>.txt,
 hypers<k>.txt, architecture.txt; writer network.py:545-663) and runs the
 forward pass of every saved network through the native forward kernel.
-Re-weighting / autocorrelation (predictor.py:157-312, needs ``emcee``) are out
-of this build's scope.
+``trainProbs`` / ``reweight`` (predictor.py:157-273) follow the reference where the
+reference runs (likelihood=None: the per-network sum of ``calculateHyperProbs``) and its
+intent where it cannot: with a likelihood the reference raises (GaussianLikelihood reads a
+``sd`` keyword nobody passes, likelihood.py:116-119; the Fixed-Gaussian one transposes the
+rows twice, predictor.py:174 + :141, and never reduces over them) -- here the data term is
+the summed log-likelihood of the training rows under each saved network, computed from one
+``tbnn_forward_many`` call.  ``autocorrelation`` / ``autoCorrelationLength``
+(predictor.py:275-312) use ``emcee.autocorr`` in the reference (un-vendored, emcee 3.x):
+``function_1d`` and ``integrated_time`` are restated below from its published algorithm
+(FFT autocorrelation; Sokal's automatic window with c = 5).
 """
 import math
 
@@ -28,6 +36,8 @@ class predictor(object):
         self.loadArchitecture()
         self.likelihood = likelihood if likelihood is not None else GaussianLikelihood(sd=0.1)
         self._chain = None
+        self.weightsTrain = []                                                  # predictor.py:40
+        self.weights = []
 
     def loadNetworks(self):
         """predictor.py:43-113"""
@@ -93,3 +103,120 @@ class predictor(object):
         out = self._chain.forward_many(picked, X=x)
         assert out.shape[0] == math.ceil(self.numNetworks / n)
         return [out[i] for i in range(out.shape[0])]
+
+    # ---- re-weighting (predictor.py:157-273) ----
+    def _data_logprob(self, likelihood, trainX, trainY, n):
+        """summed log-likelihood of the training rows under every n-th network (see the module docstring)"""
+        from .layer import _multivariate_log_prob
+        from .likelihood import BernoulliLikelihood, FixedGaussianLikelihood
+        preds = self.predict(trainX, n)
+        y = np.asarray(trainY, dtype=np.float32)
+        out = []
+        for i, f in enumerate(preds):
+            cur = np.asarray(f, dtype=np.float32).T                             # [rows, d_out]
+            real = y.reshape(cur.shape)
+            if isinstance(likelihood, BernoulliLikelihood):
+                out.append(np.float32(0))                                       # likelihood.py:239-243
+                continue
+            if isinstance(likelihood, FixedGaussianLikelihood):
+                sd = np.float32(likelihood.sd)                                  # likelihood.py:195 (not squared)
+            else:
+                m = i * n
+                sd = np.float32(self.hypers[m][-1]) if len(self.hypers) else np.float32(0.1)   # likelihood.py:116-117
+            out.append(np.float32(np.sum(_multivariate_log_prob(np.ones_like(cur) * sd, cur, real))))
+        return out
+
+    def _hyper_probs(self, weights, n):
+        """predictor.py:188-206 / :248-266: minus the data term, minus every layer's calculateHyperProbs"""
+        for m in range(0, self.numNetworks, n):
+            matrixIndex = hyperIndex = 0
+            current = -weights[m // n]
+            for layer in self.layers:
+                tensors = [self.matrices[matrixIndex + x][m, :, :] for x in range(layer.numTensors)]
+                hypers = [self.hypers[m][hyperIndex + x] for x in range(layer.numHyperTensors)]
+                hyperIndex += layer.numHyperTensors
+                matrixIndex += layer.numTensors
+                if layer.numHyperTensors > 0:
+                    current = current - np.float32(layer.calculateHyperProbs(hypers, tensors))
+            weights[m // n] = current
+        return np.array(weights)
+
+    def trainProbs(self, trainX, trainY, n, likelihood):
+        """predictor.py:157-207: negative log posterior weight of every n-th network under the training priors"""
+        if likelihood is not None:
+            weights = self._data_logprob(self.likelihood, trainX, trainY, n)
+        else:
+            weights = [np.float32(0) for _ in range(0, self.numNetworks, n)]
+        self.weightsTrain = self._hyper_probs(weights, n)
+
+    def reweight(self, architecture, trainX=None, trainY=None, n=1, likelihood=None):
+        """predictor.py:209-273: importance weights p(theta | new priors) / p(theta | training priors), normalised"""
+        if len(self.weightsTrain) == 0:
+            self.trainProbs(trainX, trainY, n, likelihood)
+        self.loadArchitecture(architecture=architecture)
+        if likelihood is not None:
+            weights = self._data_logprob(likelihood, trainX, trainY, n)
+        else:
+            weights = [np.float32(0) for _ in range(0, self.numNetworks, n)]
+        self.weights = self._hyper_probs(weights, n)
+        weighting = np.exp(self.weightsTrain - self.weights)
+        weighting = weighting / np.sum(weighting)
+        self.loadArchitecture()
+        return weighting
+
+    # ---- autocorrelation (predictor.py:275-312) ----
+    def autocorrelation(self, inputData, nMax):
+        output = np.squeeze(np.array(self.predict(inputData, n=1))).T
+        valFunc, accepted = 0, 0
+        for x in range(len(output)):
+            temp = integrated_time(output[x], tol=5, quiet=True)
+            if not np.isnan(temp).any():
+                valFunc = valFunc + np.array(function_1d(output[x]))
+                accepted += 1
+        valFunc = valFunc / accepted
+        return valFunc[:nMax] if nMax < len(valFunc) else valFunc
+
+    def autoCorrelationLength(self, inputData, nMax):
+        output = np.squeeze(np.array(self.predict(inputData, n=1))).T
+        val, accepted = 0, 0
+        for x in range(len(output)):
+            temp = integrated_time(output[x], tol=5, quiet=True)
+            if not np.isnan(temp).any():
+                val = val + temp
+                accepted += 1
+        val = val / accepted
+        if val[0] > nMax:
+            print("Correlation time is greater than maximum accepted value.")
+        return val[0]
+
+    def extractParameters(self):
+        """predictor.py:314-319: the parameter matrices, first axis = network"""
+        return self.matrices
+
+
+def function_1d(x):
+    """emcee.autocorr.function_1d: normalised autocorrelation function of a 1-D series (FFT, zero-padded)"""
+    x = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    if x.ndim != 1:
+        raise ValueError("invalid dimensions for 1D autocorrelation function")
+    n = 1
+    while n < len(x):
+        n <<= 1
+    f = np.fft.fft(x - np.mean(x), n=2 * n)
+    acf = np.fft.ifft(f * np.conjugate(f))[: len(x)].real
+    acf /= acf[0]
+    return acf
+
+
+def integrated_time(x, c=5, tol=50, quiet=False):
+    """emcee.autocorr.integrated_time for one chain: tau = 2 * cumsum(acf) - 1 at Sokal's window (first M >= c * tau);
+    returns an array of one element, NaN-free unless the series is constant"""
+    x = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    f = function_1d(x)
+    taus = 2.0 * np.cumsum(f) - 1.0
+    m = np.arange(len(taus)) < c * taus
+    window = int(np.argmin(m)) if np.any(m) else len(taus) - 1
+    tau_est = np.array([taus[window]])
+    if not quiet and np.any(tol * tau_est > len(x)):
+        raise ValueError("The chain is shorter than {0} times the integrated autocorrelation time".format(tol))
+    return tau_est

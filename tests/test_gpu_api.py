@@ -48,6 +48,23 @@ def test_train_regression_script_flow(tmp_path, monkeypatch, native):
     spec = o.make_spec([1, 10, 10, 10, 1], o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_FIXED_GAUSSIAN)
     ref = o.forward(spec, p.vectors[0], valIn.reshape(-1, 1).astype(np.float32), np.float64)
     np.testing.assert_allclose(preds[0], ref, rtol=2e-5, atol=2e-5)
+    # re-weighting with the data term (predictor.py:157-273; see predictor.py's docstring for the reference's defects):
+    # same architecture + same likelihood => uniform weights; the data term is the training log-likelihood
+    from tensorbnn_amd.layer import _multivariate_log_prob
+    p2 = predictor(str(tmp_path / "TrigRegression") + "/", likelihood=FixedGaussianLikelihood(sd=0.1))
+    wts = p2.reweight(str(tmp_path / "TrigRegression" / "architecture.txt"), trainX=trainIn.reshape(-1, 1), trainY=trainOut,
+                      n=1, likelihood=FixedGaussianLikelihood(sd=0.1))
+    np.testing.assert_allclose(wts, np.full(4, 0.25), rtol=1e-5)
+    f0 = o.forward(spec, p.vectors[0], trainIn.reshape(-1, 1).astype(np.float32), np.float64).T
+    ll0 = float(np.sum(_multivariate_log_prob(np.full(f0.shape, 0.1, np.float32), f0.astype(np.float32),
+                                              trainOut.reshape(f0.shape).astype(np.float32))))
+    hp0 = sum(float(GaussianDenseLayer(1, 1).calculateHyperProbs(p.hypers[0][4 * j:4 * j + 4], [p.matrices[2 * j][0], p.matrices[2 * j + 1][0]]))
+              for j in range(4))
+    assert abs(float(p2.weightsTrain[0]) + ll0 + hp0) <= 2e-4 * abs(ll0 + hp0) + 1e-3
+    # autocorrelation over the ensemble's predictions (predictor.py:275-312)
+    ac = p.autocorrelation(valIn.reshape(-1, 1), 3)
+    assert ac.shape == (3,) and abs(ac[0] - 1.0) < 1e-6
+    assert np.isfinite(p.autoCorrelationLength(valIn.reshape(-1, 1), 100))
 
 
 def test_accept_ratio_parity_with_oracle_chain(native):

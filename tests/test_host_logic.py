@@ -196,3 +196,57 @@ def test_jit_family_choice_and_source():
     assert "Shape<1, 3, true, 8, 64, 48, 2>" in src and "JitWide<S>::fill" in src and "tbnn_jit_ops" in src
     mixed = [(4, 8, nat.ACT_RELU, 0), (8, 8, nat.ACT_TANH, 0), (8, 1, nat.ACT_NONE, 0)]
     assert jit.shape_of(mixed, nat.LIK_GAUSSIAN) is None
+
+
+def test_predictor_reweight_without_likelihood(tmp_path):
+    """predictor.reweight / trainProbs, the path the reference can run (likelihood=None, predictor.py:157-273):
+    weights = exp(sum_layers hyperprobs_new - hyperprobs_train), normalised -- checked against a direct evaluation"""
+    from tensorbnn_amd.predictor import predictor
+    from tensorbnn_amd.layer import CauchyDenseLayer, GaussianDenseLayer
+    rng = np.random.default_rng(11)
+    shapes = [(4, 3), (4, 1), (2, 4), (2, 1)]
+    names = ["dense", "relu", "dense"]
+    w = o.SampleWriter(str(tmp_path / "run"), shapes, names, 9, 1, 1, 2)
+    nets = []
+    for it in range(1, 7):
+        sts = [(0.5 * rng.standard_normal(sh)).astype(np.float32) for sh in shapes]
+        # near the Gaussian hyper-priors' modes: the un-normalised exp() of the reference (predictor.py:267) stays finite
+        hyp = [np.float32(v + 0.02 * rng.standard_normal(1)) for v in ([0.02, 1.0, -0.02, 0.99] * 2 + [0.3])]
+        nets.append((sts, hyp))
+        w.after_epoch(it, sts, hyp)
+    w.close()
+    p = predictor(str(tmp_path / "run") + "/")
+    assert p.numNetworks >= 4 and p.extractParameters()[0].shape[1:] == (4, 3)
+    (tmp_path / "arch2.txt").write_text("denseGaussian\nrelu\ndenseGaussian\n")
+    wts = p.reweight(str(tmp_path / "arch2.txt"), n=1, likelihood=None)
+    assert wts.shape == (p.numNetworks,) and abs(wts.sum() - 1) < 1e-5 and np.all(wts >= 0)
+    # direct evaluation
+    lw = []
+    for k in range(p.numNetworks):
+        t = [m[k] for m in p.matrices]
+        h = p.hypers[k]
+        old = sum(float(CauchyDenseLayer(1, 1).calculateHyperProbs(h[4 * j:4 * j + 4], t[2 * j:2 * j + 2])) for j in range(2))
+        new = sum(float(GaussianDenseLayer(1, 1).calculateHyperProbs(h[4 * j:4 * j + 4], t[2 * j:2 * j + 2])) for j in range(2))
+        lw.append(new - old)
+    ref = np.exp(np.array(lw) - max(lw)); ref /= ref.sum()
+    np.testing.assert_allclose(wts, ref, rtol=2e-4, atol=1e-7)
+    # the architecture is restored afterwards (predictor.py:271)
+    assert [l.name for l in p.layers] == names
+
+
+def test_autocorr_restatement():
+    """function_1d / integrated_time (emcee.autocorr, used at predictor.py:275-312) on an AR(1) series:
+    acf(k) = rho^k, tau = (1 + rho) / (1 - rho)"""
+    from tensorbnn_amd.predictor import function_1d, integrated_time
+    rng = np.random.default_rng(0)
+    rho, n = 0.8, 200000
+    e = rng.standard_normal(n)
+    x = np.empty(n); x[0] = e[0]
+    for i in range(1, n):
+        x[i] = rho * x[i - 1] + e[i]
+    f = function_1d(x)
+    assert f[0] == 1.0 and np.allclose(f[1:6], rho ** np.arange(1, 6), atol=0.02)
+    tau = integrated_time(x, tol=5, quiet=True)
+    assert tau.shape == (1,) and abs(tau[0] - (1 + rho) / (1 - rho)) < 0.6
+    with pytest.raises(ValueError):
+        integrated_time(x[:50], tol=50)
