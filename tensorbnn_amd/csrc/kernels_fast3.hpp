@@ -51,6 +51,51 @@ __device__ __forceinline__ f32x2 pkfma_bc(f32x2 a, f32x2 b, f32x2 c) {
     else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// Relu derivative of a pair of activation outputs as {0, 1} floats in ONE packed instruction: clamp(a * FLT_MAX) to
+// [0, 1].  a >= 0 always; every normal a > 0 gives 1, a == 0 gives 0 (a positive denormal below 2.9e-39 would give a
+// fraction: a pre-activation in that interval does not occur in fp32 arithmetic of this size).  The mask is applied
+// with v_mul_legacy_f32 (0 * x = 0 for every x, inf and NaN included), so a masked-out element is an exact zero
+// like the select it replaces: 1.5 VALU instructions per element instead of v_cmp + v_cndmask.
+#ifndef TBNN_F3_RELU_PK
+#define TBNN_F3_RELU_PK 1
+#endif
+__device__ __forceinline__ f32x2 relu_step2(f32x2 a, f32x2 big) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(big));
+    return d;
+}
+__device__ __forceinline__ float mul_legacy(float s, float x) {
+    float d;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(d) : "v"(s), "v"(x));
+    return d;
+}
+// The opaque instructions above read MFMA results, and no software wait states are inserted for inline asm: settle()
+// stands between the MFMAs that produced `acc` and the first opaque reader (11 wait states cover the 8-pass
+// v_mfma_f32_16x16x4_f32 -> VALU read requirement of 10).
+template <int N>
+__device__ __forceinline__ void mfma_settle(f32x4 (&acc)[N]) {
+    static_assert(N >= 1 && N <= 4, "one asm statement ties up to 4 tiles");
+    if constexpr (N == 1) asm volatile("s_nop 10" : "+v"(acc[0]));
+    if constexpr (N == 2) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]));
+    if constexpr (N == 3) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+    if constexpr (N == 4) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+}
+// acc * act'(a) for the 4 registers of a tile; SETTLED: the caller has called mfma_settle on acc (or acc is a VALU result)
+template <int ACT, bool SETTLED>
+__device__ __forceinline__ f32x4 actc_bwd_mul4(f32x4 acc, f32x4 a) {
+    f32x4 r;
+    if constexpr (ACT == TBNN_ACT_RELU && TBNN_F3_RELU_PK && SETTLED) {
+        const f32x2 big = {3.402823466e38f, 3.402823466e38f};
+        const f32x2 s01 = relu_step2(f32x2{a[0], a[1]}, big), s23 = relu_step2(f32x2{a[2], a[3]}, big);
+        r[0] = mul_legacy(s01[0], acc[0]); r[1] = mul_legacy(s01[1], acc[1]);
+        r[2] = mul_legacy(s23[0], acc[2]); r[3] = mul_legacy(s23[1], acc[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = actc_bwd_mul<ACT>(acc[i], a[i]);
+    }
+    return r;
+}
+
 // a * (b[H], b[H])
 template <int H>
 __device__ __forceinline__ f32x2 pkmul_bc(f32x2 a, f32x2 b) {
@@ -120,8 +165,8 @@ __device__ __forceinline__ float gsum(float p) {
 // B[n = i16&3] = a[k-slot][row i16] -- the D-layout activation register as it stands -- so after one instruction per
 // k-slot register, accumulator register m of every lane holds exactly the per-lane partial sum that dot_slots computes
 // for fringe unit m (2 passes = 8 cycles per instruction against ~12 cycles per dependent packed FMA).  The sum over
-// the 4 lane groups is ONE 16x16x4 MFMA with A = 1 (B[k = g][n = i16] is the register of partials as it stands, C
-// carries the bias): every register of every lane of the result holds the finished pre-activation of row i16.
+// the 4 lane groups is ONE 16x16x4 MFMA with A = 1 (B[k = g][n = i16] is the register of partials as it stands):
+// every register of every lane of the result holds the finished pre-activation of row i16.
 #ifndef TBNN_F3_M4
 #define TBNN_F3_M4 1
 #endif
@@ -148,9 +193,10 @@ __device__ __forceinline__ f32x4 fringe_partials(const float* __restrict__ prow,
         for (int kt = 0; kt + st < KG; kt += 2 * st) acc[kt] += acc[kt + st];
     return acc[0];
 }
-// sum over the 4 lane groups + c, broadcast to every lane (row i16)
-__device__ __forceinline__ float gsum_mfma(float p, float c) {
-    return mfma16(1.f, p, f32x4{c, c, c, c})[0];
+// sum over the 4 lane groups, broadcast to every lane (row i16); C is the inline constant 0 (a bias travelling in C
+// would cost four v_mov to splat it, one v_add afterwards is cheaper)
+__device__ __forceinline__ float gsum_mfma(float p) {
+    return mfma16(1.f, p, f32x4{0.f, 0.f, 0.f, 0.f})[0];
 }
 
 // sum_k w[k-slot] * v[k-slot] over this lane's k-slots of a K dimension living in D-layout tiles
@@ -277,7 +323,7 @@ struct Fwd3 {
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 float z;
-                if constexpr (TBNN_F3_M4) z = gsum_mfma(pacc[f], lds[C::boff(l) + C::fslot(l, f)]);
+                if constexpr (TBNN_F3_M4) z = gsum_mfma(pacc[f]) + lds[C::boff(l) + C::fslot(l, f)];
                 else z = gsum(pf[f]) + lds[C::boff(l) + C::fslot(l, f)];
                 T.af[l][f] = actc_fwd<S::act(l)>(z);
                 if (g == f) v[0] = T.af[l][f];
@@ -509,13 +555,13 @@ struct Bwd3 {
 #pragma unroll
                         for (int m = 0; m < MTP; ++m) acc[m] = mfma16(A4[m][s], dz[kt][s], acc[m]);
                 }
+                if constexpr (S::act(l - 1) == TBNN_ACT_RELU && TBNN_F3_RELU_PK && MTP >= 1 && MTP <= 4) mfma_settle(acc);
 #pragma unroll
                 for (int m = 0; m < MTP; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dzp[m][r] = actc_bwd_mul<S::act(l - 1)>(acc[m][r], T.a[C::aroff(l - 1) + m][r]);
+                    dzp[m] = actc_bwd_mul4<S::act(l - 1), (MTP >= 1 && MTP <= 4)>(acc[m], T.a[C::aroff(l - 1) + m]);
 #pragma unroll
                 for (int f = 0; f < NFP; ++f)
-                    dzpf[f] = actc_bwd_mul<S::act(l - 1)>(TBNN_F3_M4 ? gsum_mfma(pacc[f], 0.f) : gsum(pf[f]), T.af[l - 1][f]);
+                    dzpf[f] = actc_bwd_mul<S::act(l - 1)>(TBNN_F3_M4 ? gsum_mfma(pacc[f]) : gsum(pf[f]), T.af[l - 1][f]);
             } else {
                 // all-fringe layer (the VALU last layer): K = NF fringe deltas, weights W_l[o][slot] read per lane
 #pragma unroll
@@ -528,9 +574,7 @@ struct Bwd3 {
                         if (o == 0) { d01 = pkmul_bc<0>(f32x2{w[0], w[1]}, dd); d23 = pkmul_bc<0>(f32x2{w[2], w[3]}, dd); }
                         else { d01 = pkfma_bc<0>(f32x2{w[0], w[1]}, dd, d01); d23 = pkfma_bc<0>(f32x2{w[2], w[3]}, dd, d23); }
                     }
-                    const float d[4] = {d01[0], d01[1], d23[0], d23[1]};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dzp[m][r] = actc_bwd_mul<S::act(l - 1)>(d[r], T.a[C::aroff(l - 1) + m][r]);
+                    dzp[m] = actc_bwd_mul4<S::act(l - 1), true>(f32x4{d01[0], d01[1], d23[0], d23[1]}, T.a[C::aroff(l - 1) + m]);
                 }
 #pragma unroll
                 for (int f = 0; f < NFP; ++f) {
