@@ -167,6 +167,14 @@ struct WideCfg {
     static constexpr int slabB_off(int l) { int o = 0; for (int m = 1; m < l; ++m) o += r4(in(m) * out(m) + out(m)); return o; }   // within one WG's slab
     static constexpr int SB_FLOATS = slabB_off(NM + 1);
     static constexpr long dw_cost(int l) { return (long)DWT(l); }
+    // k_dw_wide workgroups per CU: a wave that owns few accumulator tiles (configs[4]: 13 tiles, 52 MFMAs between two
+    // barriers) leaves the MFMA pipe idle at every barrier / LDS round trip; a second resident workgroup fills it when
+    // two rings fit in LDS and two waves fit in a SIMD's registers
+#ifndef WIDE_DW_OCC_MAX
+#define WIDE_DW_OCC_MAX 2
+#endif
+    static constexpr int DW_OCC = (WIDE_DW_OCC_MAX >= 2 && 2 * WIDE_RING * DW_SLOT_FLOATS * 4 <= 150 * 1024 &&
+                                   4 * maxDWT() + 4 * DW_NGW * WIDE_DW_PD + 48 <= 232) ? 2 : 1;
 };
 
 // y = sum over the 16 lanes of a lane group (same lane >> 4)
@@ -757,7 +765,7 @@ __device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, l
 }
 
 template <class S>
-__global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dw_wide(
+__global__ __launch_bounds__(WIDE_THREADS, WideCfg<S>::DW_OCC) void k_dw_wide(
     WideDwArgs args, const float* __restrict__ store, long n, float* __restrict__ slabB)
 {
     using C = WideCfg<S>;
@@ -849,10 +857,10 @@ static inline void wide_plan_t(long n, WidePlan& p) {
     using C = WideCfg<S>;
     const long ntiles = (n + 15) / 16, nblk = (ntiles + WIDE_WAVES - 1) / WIDE_WAVES;
     p.gridA = (int)std::min<long>(nblk, 256);
-    // 256 dW workgroups shared out over the middle layers in proportion to their MFMA count
+    // 256 (x DW_OCC) dW workgroups shared out over the middle layers in proportion to their MFMA count
     long tot = 0;
     for (int l = 1; l <= C::NM; ++l) tot += C::dw_cost(l);
-    int budget = (int)std::min<long>(256, std::max<long>(ntiles, C::NM)), used = 0;
+    int budget = (int)std::min<long>(256 * C::DW_OCC, std::max<long>(ntiles, C::NM)), used = 0;
     p.wg_lo[0] = 0;
     for (int l = 1; l <= C::NM; ++l) {
         int w = l == C::NM ? budget - used : (int)std::max<long>(1, (budget * C::dw_cost(l)) / tot);
