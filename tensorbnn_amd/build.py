@@ -6,11 +6,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "tbnn_api.hip"), os.path.join(HERE, "csrc", "tbnn_wide.hip"),
        os.path.join(HERE, "csrc", "adapter.cpp")]
-# narrow kernels: the chain MFMAs write ArchVGPRs (their results feed the VALU), dW accumulators are pinned to
+# both kernel families: the chain MFMAs write ArchVGPRs (their results feed the VALU), dW accumulators are pinned to
 # AccVGPRs by hand (kernels_fast.hpp, mfma16_acc)
 NARROW_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 PER_SOURCE_FLAGS = {"tbnn_api.hip": NARROW_FLAGS,
-                    "tbnn_wide.hip": os.environ.get("TBNN_WIDE_FLAGS", "").split()}     # experiments
+                    "tbnn_wide.hip": NARROW_FLAGS + os.environ.get("TBNN_WIDE_FLAGS", "").split()}     # + experiments
 OBJ_DIR = os.path.join(HERE, "_obj")
 OUT = os.path.join(HERE, "libtbnn.so")
 

@@ -51,6 +51,10 @@ __device__ unsigned long long g_wide_stamps[256];
 #define WIDE_THREADS 256
 #define WIDE_RING 4
 #ifndef WIDE_DW_PD
+// dW_0 accumulators pinned to AccVGPRs (kernels_fast.hpp, mfma16_acc) next to VGPR-form chain MFMAs (build.py): -1.5 % at configs[4]
+#ifndef WIDE_DW0_AGPR
+#define WIDE_DW0_AGPR 1
+#endif
 #define WIDE_DW_PD 1   // k_dw_wide: row tiles in flight from HBM beyond the two parked in LDS (measured: 1 = 2 = 4)
 #endif
 #ifndef WIDE_PD
@@ -580,7 +584,11 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                     for (int t = b0; t < b0 + C::DZB && t < C::MT0; ++t)
 #pragma unroll
                         for (int nt = 0; nt < C::NT0; ++nt)
+#if WIDE_DW0_AGPR
+                            mfma16_acc<(C::NT0 * (C::DZB < C::MT0 ? C::DZB : C::MT0) > 1)>(dW0[t * C::NT0 + nt], Aop[t - b0][s], Bop[nt][s]);
+#else
                             dW0[t * C::NT0 + nt] = mfma16(Aop[t - b0][s], Bop[nt][s], dW0[t * C::NT0 + nt]);
+#endif
             }
         }
         WSTAMP(5);
@@ -588,6 +596,9 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     }
 
     if constexpr (FWD) return;
+#if WIDE_DW0_AGPR
+    mfma_drain();
+#endif
     // ---- epilogue: compact slab [layer 0][last layer] of this workgroup
     const double wtot = wave_sum(stat);
     if (lane == 0) red[wave] = wtot;

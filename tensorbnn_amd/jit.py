@@ -114,8 +114,7 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
             f.write(source(dims, hact, lact, bern, fam))
         tmp = so + f".{os.getpid()}.tmp"
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
-        if fam != "wide":
-            cmd += NARROW_FLAGS          # as build.py compiles the narrow kernels (VGPR-form chain MFMAs)
+        cmd += NARROW_FLAGS              # as build.py compiles the kernels (VGPR-form chain MFMAs)
         cmd += ["-o", tmp, src]
         if verbose:
             print(" ".join(cmd), flush=True)
