@@ -41,12 +41,22 @@ struct Shape {
     static constexpr int act(int l) { return l == NL - 1 ? LACT_ : HACT_; }
 };
 
+#ifndef TBNN_FAST_ACT
+#define TBNN_FAST_ACT 1
+#endif
 template <int ACT>
 __device__ __forceinline__ float actc_fwd(float z) {
     // relu as ONE integer max on the bit pattern (negative floats are negative ints; no NaN canonicalisation op)
     if constexpr (ACT == TBNN_ACT_RELU) return __int_as_float(max(__float_as_int(z), 0));
+#if TBNN_FAST_ACT
+    // hardware exp2 / reciprocal (about 2 ulp) instead of the library tanhf / expf + IEEE division: in the fused kernels
+    // every VALU instruction costs MFMA time
+    else if constexpr (ACT == TBNN_ACT_TANH) return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * z));
+    else if constexpr (ACT == TBNN_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-z));
+#else
     else if constexpr (ACT == TBNN_ACT_TANH) return tanhf(z);
     else if constexpr (ACT == TBNN_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
+#endif
     else if constexpr (ACT == TBNN_ACT_EXP) return expf(z);
     else if constexpr (ACT == TBNN_ACT_ELU) return z > 0.f ? z : expm1f(z);
     else return z;
@@ -396,16 +406,29 @@ struct LastRegs {
 };
 
 // likelihood for one output value: statistic (counted when `count`), returns dL/df * act'
+#ifndef TBNN_FAST_BERN
+#define TBNN_FAST_BERN 1
+#endif
 template <class S>
 __device__ __forceinline__ float lik_delta(float fi, float yy, float inv_var, bool count, double& stat) {
     float da;
     if constexpr (S::BERN) {
         const float p = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);
         const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
+#if TBNN_FAST_BERN
+        // hardware log2 / reciprocal (1 ulp) instead of the library logf / log1pf / IEEE division sequences: the fused
+        // kernels are VALU-bound next to the f32 MFMA (every instruction ~9 cycles), the likelihood is ~100 of them
+        const float q = 1.f - p;
+        const float t1 = (yy == 0.f) ? 0.f : yy * __logf(p);
+        const float t2 = (1.f - yy == 0.f) ? 0.f : (1.f - yy) * __logf(q);
+        if (count) stat += (double)(t1 + t2);
+        da = inside ? (yy * __builtin_amdgcn_rcpf(p) - (1.f - yy) * __builtin_amdgcn_rcpf(q)) : 0.f;
+#else
         const float t1 = (yy == 0.f) ? 0.f : yy * logf(p);
         const float t2 = (1.f - yy == 0.f) ? 0.f : (1.f - yy) * log1pf(-p);
         if (count) stat += (double)(t1 + t2);
         da = inside ? (yy / p - (1.f - yy) / (1.f - p)) : 0.f;
+#endif
     } else {
         const float res = yy - fi;
         if (count) stat += (double)res * (double)res;
