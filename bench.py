@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = 157.3
-HYPER_EPS = 2e-5       # configs[4] hyper transition (L_h = 100): scan 3e-5 -> 0.85..0.13, 1e-5 -> 0.99 (tools_hyperprobe.py)
+HYPER_EPS = 2e-5       # configs[4] hyper transition (L_h = 100): scan 3e-5 -> 0.85..0.13, 1e-5 -> 0.99 (tools/hyperprobe.py)
 # --workload: c2 = BASELINE configs[1] (the metric's config, default); c4 / c5 = configs[3] / configs[4]
 # (extra lines for the wide-layer path, same JSON contract)
 WORKLOADS = {

@@ -162,7 +162,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // dW accumulation with the accumulator pinned to AccVGPRs.  With -mllvm -amdgpu-mfma-vgpr-form (build.py, jit.py) the
 // compiler's own MFMAs -- the forward / delta chain, whose results the VALU consumes -- write ArchVGPRs directly (no
 // v_accvgpr_read per result register; on gfx950 every VALU instruction costs ~9 cycles of tile time because the f32
-// MFMA and the VALU share the issue slot, tools_ubench/coexec.hip), and the dW tiles, which only MFMAs touch inside
+// MFMA and the VALU share the issue slot, tools/ubench/coexec.hip), and the dW tiles, which only MFMAs touch inside
 // the row loop, must then not compete for the 256 ArchVGPRs.  No software wait states are inserted around inline asm:
 // FAR says the same accumulator is revisited only after at least one other MFMA (>= 32 cycles, beyond the MFMA->MFMA
 // SrcC requirement); otherwise the builtin is used.  Operands come from LDS loads; the kernels drain the pipe

@@ -35,7 +35,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Packed f32 FMA as an opaque instruction.  The compiler's pre-emit peephole splits a v_pk_fma_f32 that follows an
 // MFMA into two v_fma_f32 on the assumption that they run in the MFMA's shadow; on gfx950 an f32 MFMA and the f32
-// VALU share the issue slot (tools_ubench/coexec.hip: +8.6 cycles per VALU instruction either way), so the split
+// VALU share the issue slot (tools/ubench/coexec.hip: +8.6 cycles per VALU instruction either way), so the split
 // doubles the cost.  Operands of these helpers are never raw MFMA results (no software wait states are inserted
 // for inline asm): callers pass activation outputs, LDS loads or VALU results only.
 __device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) {

@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C, os, sys, numpy as np
 import tensorbnn_amd._native as nat
 from tensorbnn_amd.workloads import synth_problem

@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev: A/B the wide kernels under different TBNN_WIDE_FLAGS: tools_ab_wide.sh <c4|c5> "<flags A>" "<flags B>" ...
+# dev: A/B the wide kernels under different TBNN_WIDE_FLAGS: tools/ab_wide.sh <c4|c5> "<flags A>" "<flags B>" ...
 wl=$1; shift
 for fl in "$@"; do
   TBNN_WIDE_FLAGS="$fl" python3 -c "from tensorbnn_amd import build as b; b.build(force=True, verbose=False)" 2>&1 | grep -E "error" | head -3

@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev: A/B of C2 kernel build variants: ./tools_c2_variants.sh "<flags1>" "<flags2>" ...
+# dev: A/B of C2 kernel build variants: ./tools/c2_variants.sh "<flags1>" "<flags2>" ...
 for V in "$@"; do
   echo "=== variant: [$V]"
   TBNN_EXTRA_FLAGS="$V" python3 -m tensorbnn_amd.build --force > /dev/null 2>&1 || echo BUILD FAILED

@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 """dev: time tbnn_forward_many (ensemble prediction) for the configs[1] shape: m networks x n rows"""
 import sys, time
 import numpy as np

@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys, numpy as np
 sys.path.insert(0, "oracle")
 import tbnn_oracle as o

@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 """dev: step-size scan for the C4 / C5 bench workloads (accept-prob window [0.6, 0.9] after warm-up)"""
 import sys, json, numpy as np
 from tensorbnn_amd import _native as nat

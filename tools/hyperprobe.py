@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tensorbnn_amd import _native as nat
 from tensorbnn_amd.workloads import synth_problem

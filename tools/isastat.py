@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 s=open('build/asm/c2.s').read().split('\n')
 idx=[i for i,l in enumerate(s) if 'v_mfma' in l]
 F,L=idx[0],idx[-1]

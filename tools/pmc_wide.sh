@@ -6,7 +6,7 @@ mkdir -p $OUT
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $SET --output-format csv -d $OUT/${CASE}_p$i -- python3 tools_widetime.py $CASE 2 > $OUT/${CASE}_p$i.log 2>&1 || echo "pass $i ($SET) failed/timed out"
+  timeout 150 rocprofv3 --pmc $SET --output-format csv -d $OUT/${CASE}_p$i -- python3 tools/widetime.py $CASE 2 > $OUT/${CASE}_p$i.log 2>&1 || echo "pass $i ($SET) failed/timed out"
 done
 python3 - <<PY
 import csv, glob, collections, os, json

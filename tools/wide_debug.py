@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 """dev: wide path vs generic kernel vs oracle on a small problem"""
 import sys, os
 import numpy as np

@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 """dev: per-chunk shader-clock stamps of k_chain_wide (build with TBNN_EXTRA_FLAGS=-DWIDE_STAMPS)"""
 import ctypes as C, numpy as np, sys
 import tensorbnn_amd._native as nat

@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 """dev: time the wide path at full size (C4 / C5) -- uses workloads.synth_problem (no oracle), rocprof friendly"""
 import sys, time
 import numpy as np
