@@ -1,19 +1,22 @@
-// k_fwd_bwd_fast3: k_fwd_bwd_fast with the *fringe* units of every layer on the VALU.
+// k_fwd_bwd_fast3: k_fwd_bwd_fast with the *fringe* units of every layer off the 16x16x4 MFMA tiles.
 //
-// On gfx950 the f32 MFMA and the f32 VALU share one ALU (kernels_fast.hpp header), so
-// the cost of the tile body is its MFMA count.  A 50-unit layer fills 3 full 16-unit MFMA tiles
-// plus a 4th tile that carries 2 units: a quarter of the forward / delta-chain MFMAs and 7 of the
-// 16 dW tiles of a layer exist for 2 units.  Here a layer with out % 16 in {1, 2} keeps
-// MTF = out/16 full tiles on the MFMA path and computes its NF fringe units with plain FMAs:
-//   forward   z_u = b_u + sum_k W[u][k] a[k]        each lane sums its own 16 k-slots, the four
-//             lane groups are combined with two lane shuffles; the result (all lanes) is dropped
-//             into register 0 of the fringe tile (lane group f) so that it feeds the next layer's
-//             last k-step exactly like an MFMA result would;
-//   delta     d_u = act'(a_u) sum_i W[i][u] delta[i]   same shape, W^T image;
-//   dW rows   dW[u][k] += d_u a_{l-1}[k]               per-lane partial sums (2 x 16 registers per
-//             layer), reduced once per launch in the epilogue.
-// The last layer (<= 2 outputs) is simply the all-fringe case (MTF = 0).  C2: 270 MFMAs per
-// 16-row tile instead of 360, +~250 VALU ops.
+// A 50-unit layer fills 3 full 16-unit MFMA tiles plus a 4th tile that carries 2 units: a quarter of the
+// forward / delta-chain MFMAs and 4 of the 16 dW tiles of a layer exist for 2 units.  Here a layer with
+// out % 16 in {1, 2} keeps MTF = out/16 full tiles on the 16x16x4 path and computes its NF fringe units apart:
+//   forward   z_u = b_u + sum_k W[u][k] a[k]: per-lane partial sums over the lane's own k-slots on the 16-block
+//             v_mfma_f32_4x4x1 (fringe_partials), summed over the 4 lane groups by ONE 16x16x4 MFMA with A = 1
+//             (gsum_mfma); the result (all lanes) is dropped into register 0 of the fringe tile (lane group f) so
+//             that it feeds the next layer's last k-step exactly like an MFMA result would;
+//   delta     d_u = act'(a_u) sum_i W[i][u] delta[i]: same shape, W^T image;
+//   dW rows   dW[u][k] += d_u a_{l-1}[k]: in the B-operand layout of the a_{l-1} image registers that feed the MFMA
+//             part of dW_l anyway (fdw: one v_pk_fma per N tile and data row), 2 registers per N tile, reduced over
+//             the lane groups and waves once per launch in the epilogue (FringeOut).
+// The last layer (<= 2 outputs) is the all-fringe case (MTF = 0) and keeps per-lane sums in the D layout.
+// On gfx950 the f32 MFMA and the f32 VALU share one issue slot (tools/ubench/coexec.hip: every VALU instruction
+// adds ~9 cycles to the MFMA stream), so the tile body is shaped by instruction count: AccVGPR-pinned dW
+// accumulators next to VGPR-form chain MFMAs (kernels_fast.hpp, mfma16_acc), LDS traffic threaded by hand through
+// the dW MFMAs (Pipe3), packed instructions kept packed (pkfma*), a 1.5-instruction relu derivative (actc_bwd_mul4).
+// C2: 270 + 67 (4x4x1) + 11 MFMAs, 227 VALU and 148 LDS instructions per 16-row tile.  DESIGN.md section 4.
 #pragma once
 #include "kernels_fast.hpp"
 

@@ -10,6 +10,11 @@ pytestmark = pytest.mark.gpu
 CASES = {
     # narrow family (k_fwd_bwd_fast3): every dW tile in registers
     "narrow_tanh": dict(dims=[6, 24, 24, 1], n=900, act=o.ACT_TANH, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN, name="jit-fast3<"),
+    # fast3 with ONE fringe unit per hidden layer (17 = 16 + 1, 33 = 32 + 1: the row-pair form of the B-layout fringe dW)
+    # and a 2-output all-fringe last layer; Relu: the packed derivative mask
+    "narrow_fringe1": dict(dims=[7, 17, 33, 2], n=700, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN, name="jit-fast3<"),
+    # fast3, two fringe units, sigmoid hidden layers (the generic derivative path, hardware exp2/reciprocal epilogue)
+    "narrow_fringe2_sigmoid": dict(dims=[3, 34, 18, 1], n=600, act=o.ACT_SIGMOID, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN, name="jit-fast3<"),
     # narrow family, 3 outputs on the MFMA path (k_fwd_bwd_fast)
     "narrow_out3": dict(dims=[5, 20, 3], n=500, act=o.ACT_ELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN, name="jit-fast<"),
     # wide family, image resident in LDS
