@@ -72,6 +72,12 @@ __device__ __forceinline__ float act_bwd(float a, int act) {
     }
 }
 
+// diagnostic build only (-DTBNN_TILE_STAMPS): shader-clock stamps (per translation unit; tbnn_debug_tile_stamps reads
+// the copy of tbnn_api.hip)
+#ifdef TBNN_TILE_STAMPS
+static __device__ unsigned long long g_tile_stamps[64];
+#endif
+
 // wave (64-lane) and block reductions
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -150,7 +150,6 @@ struct FastCfg {
 
 // diagnostic build only (-DTBNN_TILE_STAMPS): shader-clock stamps at the phase boundaries of a tile step
 #ifdef TBNN_TILE_STAMPS
-__device__ unsigned long long g_tile_stamps[64];
 #define TSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0) g_tile_stamps[k] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define TSTAMP(k) do { } while (0)
