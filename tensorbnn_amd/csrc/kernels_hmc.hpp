@@ -145,6 +145,12 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
     if (y == 0 && j < P) out[j] = (part[0][x] + part[1][x]) + (part[2][x] + part[3][x]);
 }
 
+// plain copy (tbnn_get_state: theta into device-mapped pinned host memory)
+__global__ __launch_bounds__(256) void k_copy_f32(int n, const float* __restrict__ src, float* __restrict__ dst) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) dst[j] = src[j];
+}
+
 // scatter a flat theta into the padded weight image (bootstrap / tbnn_logp_grad)
 // blockIdx.y: network of an ensemble (q + y * q_stride -> qimg + y * img_stride; both strides 0 for a single one)
 __global__ __launch_bounds__(256) void k_make_image(int P, const float* __restrict__ q,

@@ -81,6 +81,9 @@ struct tbnn_ctx {
     tbnn_comm* shard = nullptr; long n_total = 0; float* grow = nullptr; double* pstat_red = nullptr;
     int* imgmap = nullptr; float* qimg = nullptr; float* qimg_cur = nullptr; int img_floats = 0;   // fast kernel: padded weight images
     size_t scratchPerWG = 0;
+    float* pin_dev = nullptr;              // device-side address of pin
+    float* pin = nullptr;                  // pinned staging for the per-epoch state read-back (P + H floats): a 22-KB D2H copy
+                                           // into pageable memory costs ~180 us, through pinned memory ~15 us
     Scal* sc = nullptr; Scal* sc_host = nullptr; Scal* sc_out = nullptr;   // sc_out: device copy for host
     double* trace = nullptr; int trace_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -193,6 +196,7 @@ extern "C" int tbnn_destroy(tbnn_handle h) {
     if (h->sc_out) hipFree(h->sc_out);
     if (h->trace) hipFree(h->trace);
     if (h->sc_host) hipHostFree(h->sc_host);
+    if (h->pin) hipHostFree(h->pin);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     for (auto e : h->pev) hipEventDestroy(e);
@@ -235,6 +239,8 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
     HIPB(hipMalloc(&h->logu_inj, sizeof(float)));
     HIPB(hipMalloc(&h->sc, sizeof(Scal))); HIPB(hipMalloc(&h->sc_out, sizeof(Scal)));
     HIPB(hipHostMalloc(&h->sc_host, sizeof(Scal)));
+    HIPB(hipHostMalloc(&h->pin, ((size_t)nd.P + nd.H) * sizeof(float), hipHostMallocMapped));
+    HIPB(hipHostGetDevicePointer((void**)&h->pin_dev, h->pin, 0));
     HIPB(hipMemset(h->sc, 0, sizeof(Scal)));
     HIPB(hipMemset(h->q_cur, 0, PB));
     HIPB(hipEventCreate(&h->ev0)); HIPB(hipEventCreate(&h->ev1));
@@ -388,8 +394,12 @@ extern "C" int tbnn_set_state(tbnn_handle h, const float* theta) {
 extern "C" int tbnn_get_state(tbnn_handle h, float* theta) {
     NEED(h); if (!theta) return fail(-1, "null theta");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpyAsync(theta, h->q_cur, (size_t)h->nd.P * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    // a kernel writes theta straight into the (device-mapped) pinned buffer: a D2H copy engine transfer of this size
+    // has ~160 us of latency, the zero-copy store a few us
+    hipLaunchKernelGGL(k_copy_f32, dim3((h->nd.P + 255) / 256), dim3(256), 0, h->stream, h->nd.P, (const float*)h->q_cur, h->pin_dev);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(theta, h->pin, (size_t)h->nd.P * sizeof(float));
     return 0;
 }
 extern "C" int tbnn_set_hypers(tbnn_handle h, const float* eta) {
@@ -403,8 +413,9 @@ extern "C" int tbnn_set_hypers(tbnn_handle h, const float* eta) {
 extern "C" int tbnn_get_hypers(tbnn_handle h, float* eta) {
     NEED(h); if (!eta) return fail(-1, "null eta");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpyAsync(eta, h->eta, (size_t)h->nd.H * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->pin + h->nd.P, h->eta, (size_t)h->nd.H * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(eta, h->pin + h->nd.P, (size_t)h->nd.H * sizeof(float));
     return 0;
 }
 
