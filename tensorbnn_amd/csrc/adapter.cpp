@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <random>
 #include <string>
+#include <thread>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/tbnn.h"
@@ -73,16 +75,43 @@ struct Adapter {
         const float var = calck({e, L}, {e, L}) - quad;
         return mean + var * (float)p * rootbeta;
     }
-    // :158-196 -- e fastest, then L; keeps the first strictly greater ucb; init -1e9
-    void gridSearch() {
+    // :158-196 -- e fastest, then L; keeps the first strictly greater ucb; init -1e9.
+    // The grid (trainRegression.py: 100 x 991 points x a 50 x 50 quadratic form = 2.5e8 FMAs, 30-80 ms on one core
+    // every averagingSteps epochs -- as much as ten configs[1] epochs on the GPU) is scanned by a few host threads:
+    // every thread takes a contiguous block of L rows and keeps the first strictly greater value of its block, the
+    // blocks are merged in order with the same strict comparison -- the sequential scan's result, bit for bit.
+    struct Best { float u, e, L; };
+    Best scanRows(size_t l0, size_t l1) const {
         std::vector<float> kv(previousGamma.size());
-        float best = -1e9f, be = el, bL = Ll;
-        for (size_t li = 0; li < lGrid.size(); ++li)
+        Best b{-1e9f, el, Ll};
+        for (size_t li = l0; li < l1; ++li)
             for (int ei = 0; ei < eNumber; ++ei) {
                 const float u = ucb(eGrid[ei], lGrid[li], kv);
-                if (u > best) { best = u; be = eGrid[ei]; bL = lGrid[li]; }
+                if (u > b.u) { b.u = u; b.e = eGrid[ei]; b.L = lGrid[li]; }
             }
-        currentE = be; currentL = bL;
+        return b;
+    }
+    void gridSearch() {
+        const size_t rows = lGrid.size();
+        const size_t work = rows * (size_t)eNumber * previousGamma.size() * previousGamma.size();
+        unsigned nt = 1;
+        if (work > (1u << 22)) {
+            nt = std::thread::hardware_concurrency();
+            if (const char* e = std::getenv("TBNN_ADAPTER_THREADS")) nt = (unsigned)std::max(1, std::atoi(e));
+            else nt = std::min(nt == 0 ? 1u : nt, 16u);             // 8 ranks per node share the host
+            nt = (unsigned)std::min<size_t>(nt, rows);
+        }
+        std::vector<Best> part(nt);
+        if (nt <= 1) part[0] = scanRows(0, rows);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t)
+                th.emplace_back([&, t]() { part[t] = scanRows(rows * t / nt, rows * (t + 1) / nt); });
+            for (auto& x : th) x.join();
+        }
+        Best b{-1e9f, el, Ll};
+        for (unsigned t = 0; t < nt; ++t) if (part[t].u > b.u) b = part[t];
+        currentE = b.e; currentL = b.L;
     }
     // (K + sn2 I)^-1 ; returns false when singular
     bool invert(float sn2, float extra) {
