@@ -130,3 +130,40 @@ def test_bench_multi_rank_control_flow(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["chains"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["value"] > 0 and d["roofline"]["frac"] > 0.05
+
+
+def test_classification_flow(tmp_path, monkeypatch, native):
+    """the classification use (docs/ClassificationExample.md:103-173 with the activations this build supports): Relu hidden
+    layers, Sigmoid output, BernoulliLikelihood (no hyper of its own), Accuracy metric, samples on disk, predictor"""
+    from tensorbnn_amd.activationFunctions import Relu, Sigmoid
+    from tensorbnn_amd.layer import DenseLayer
+    from tensorbnn_amd.likelihood import BernoulliLikelihood
+    from tensorbnn_amd.metrics import Accuracy
+    from tensorbnn_amd.network import network
+    from tensorbnn_amd.predictor import predictor
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((600, 4)).astype(np.float32)
+    lab = (X[:, 0] + 0.5 * X[:, 1] * X[:, 2] > 0).astype(np.float32)
+    Y = np.stack([lab, 1 - lab], axis=1)                      # two outputs, one-hot
+    net = network(np.float32, 4, X[:500], Y[:500], X[500:], Y[500:])
+    net.add(DenseLayer(4, 12, seed=1000)); net.add(Relu())
+    net.add(DenseLayer(12, 12, seed=2000)); net.add(Relu())
+    net.add(DenseLayer(12, 2, seed=3000)); net.add(Sigmoid())
+    net.setupMCMC(stepSizeStart=2e-3, stepSizeMin=5e-4, stepSizeMax=5e-3, stepSizeOptions=10, leapfrogStart=20, leapfogMin=10,
+                  leapFrogMax=40, leapfrogIncrement=5, hyperStepSize=1e-4, hyperLeapfrog=10, burnin=20, averagingSteps=5)
+    acc = Accuracy()
+    rec = net.train(60, 5, BernoulliLikelihood(), metricList=[acc], adjustHypers=True, folderName="cls", networksPerFile=2,
+                    displaySkip=30, verbose=True)           # files rotate every 10 epochs after burn-in (network.py:609-646)
+    assert len(rec) == 60 and net._chain.H == 12                # 3 dense layers x 4 hypers, none from the likelihood
+    assert np.mean([r["main"]["accept_prob"] for r in rec]) > 0.3
+    p = predictor(str(tmp_path / "cls") + "/", likelihood=BernoulliLikelihood())
+    assert p.numNetworks == 6 and p.hypers[0].shape == (12,)      # the summary of the rotation at iter 51: iters 25..50
+    preds = np.array(p.predict(X[500:]))                       # [networks, 2, rows]
+    assert preds.shape[1:] == (2, 100) and np.all((preds >= 0) & (preds <= 1))
+    # the posterior-mean classifier beats chance on the held-out rows
+    mean_p = preds.mean(axis=0)
+    assert np.mean((mean_p[0] > mean_p[1]) == (lab[500:] > 0.5)) > 0.7
+    # same forward as the oracle for a saved network
+    spec = o.make_spec([4, 12, 12, 2], o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI, final_act=o.ACT_SIGMOID)
+    np.testing.assert_allclose(preds[0], o.forward(spec, p.vectors[0], X[500:], np.float64), rtol=2e-5, atol=2e-5)
