@@ -250,3 +250,23 @@ def test_autocorr_restatement():
     assert tau.shape == (1,) and abs(tau[0] - (1 + rho) / (1 - rho)) < 0.6
     with pytest.raises(ValueError):
         integrated_time(x[:50], tol=50)
+
+
+def test_adapter_grid_search_threads_agree(monkeypatch):
+    """the threaded UCB grid scan (adapter.cpp gridSearch, paramAdapter.py:158-196) returns the sequential scan's (eps, L):
+    a grid large enough to be split (100 x 496 points x history), one thread against the default thread count"""
+    from tensorbnn_amd.paramAdapter import paramAdapter
+    def run(threads):
+        if threads is None: monkeypatch.delenv("TBNN_ADAPTER_THREADS", raising=False)
+        else: monkeypatch.setenv("TBNN_ADAPTER_THREADS", str(threads))
+        ad = paramAdapter(1e-3, 1000, 1e-4, 1e-2, 100, 100, 10000, 20, 2, 50, a=4, delta=0.1, randomSteps=3, seed=5)
+        rng = np.random.default_rng(3)
+        st = rng.standard_normal(300).astype(np.float32)
+        out = []
+        for i in range(80):
+            st = st + (0.02 + 0.01 * np.sin(i)) * rng.standard_normal(300).astype(np.float32)
+            out.append(tuple(map(float, ad.update(st))))
+        return out
+    a, b, c = run(1), run(None), run(3)
+    assert a == b == c
+    assert len(set(a[10:])) > 3          # the search did move (eps, L) around
