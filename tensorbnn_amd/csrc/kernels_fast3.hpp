@@ -773,20 +773,21 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     __shared__ double red[FAST_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
+    float* wl = lds + C::STATIC_FLOATS + wave * C::WAVE3_FLOATS;
     {
+        // all image loads in flight first, the zero fill of the per-wave images under their latency, then the LDS stores
         constexpr int N4 = C::STATIC_FLOATS / 4, IT = (N4 + FAST_THREADS - 1) / FAST_THREADS;
         const float4* src = reinterpret_cast<const float4*>(qimg);
         float4* dst = reinterpret_cast<float4*>(lds);
         float4 v[IT];
 #pragma unroll
         for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; v[k] = e < N4 ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
-    }
-    float* wl = lds + C::STATIC_FLOATS + wave * C::WAVE3_FLOATS;
-    {
+        __builtin_amdgcn_sched_barrier(0);
         float4* z = reinterpret_cast<float4*>(wl);
         for (int e = lane; e < C::WAVE3_FLOATS / 4; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
     }
     __syncthreads();
     TB_STAMP(1);
