@@ -884,25 +884,42 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     const double wtot = wave_sum(stat);
     if (lane == 0) red[wave] = wtot;
     float* slab = slabs + (size_t)blockIdx.x * pitch;
-    if constexpr (C::DW3_TILES > 0) {
-#pragma unroll
-        for (int t0 = 0; t0 < C::DW3_TILES; t0 += C::EP3_TILES) {
-            __syncthreads();
-            f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::EP3_TILES * 64);
-#pragma unroll
-            for (int t = t0; t < t0 + C::EP3_TILES && t < C::DW3_TILES; ++t) mine[(t - t0) * 64 + lane] = dW[t];
-            __syncthreads();
-            const int cnt = (C::DW3_TILES - t0) < C::EP3_TILES ? (C::DW3_TILES - t0) : C::EP3_TILES;
-            SlabOut3<S, 0>::run(lds, slab, wave, lane, t0, cnt);
-        }
-    }
-    {   // fringe partials: [wave][reg][g][i16]
+    // one staging pass for the dW tiles AND the fringe partials when both fit (configs[1]: 108 + 35 KB): two barriers
+    // instead of four
+    constexpr bool ONE_PASS = C::DW3_TILES > 0 && C::EP3_TILES == C::DW3_TILES &&
+                              (size_t)FAST_WAVES * (C::DW3_TILES * 256 + C::FP_REGS * 64) <= (size_t)C::LDS3_FLOATS;
+    if constexpr (ONE_PASS) {
+        float* lb = lds + FAST_WAVES * C::DW3_TILES * 256;
         __syncthreads();
-        float* lb = lds;
+        f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::DW3_TILES * 64);
+#pragma unroll
+        for (int t = 0; t < C::DW3_TILES; ++t) mine[t * 64 + lane] = dW[t];
 #pragma unroll
         for (int r = 0; r < C::FP_REGS; ++r) lb[((size_t)(wave * C::FP_REGS + r) * 4 + g) * 16 + i16] = FP[r];
         __syncthreads();
+        SlabOut3<S, 0>::run(lds, slab, wave, lane, 0, C::DW3_TILES);
         FringeOut<S, 0>::run(lb, slab, tid);
+    } else {
+        if constexpr (C::DW3_TILES > 0) {
+#pragma unroll
+            for (int t0 = 0; t0 < C::DW3_TILES; t0 += C::EP3_TILES) {
+                __syncthreads();
+                f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::EP3_TILES * 64);
+#pragma unroll
+                for (int t = t0; t < t0 + C::EP3_TILES && t < C::DW3_TILES; ++t) mine[(t - t0) * 64 + lane] = dW[t];
+                __syncthreads();
+                const int cnt = (C::DW3_TILES - t0) < C::EP3_TILES ? (C::DW3_TILES - t0) : C::EP3_TILES;
+                SlabOut3<S, 0>::run(lds, slab, wave, lane, t0, cnt);
+            }
+        }
+        {   // fringe partials: [wave][reg][g][i16]
+            __syncthreads();
+            float* lb = lds;
+#pragma unroll
+            for (int r = 0; r < C::FP_REGS; ++r) lb[((size_t)(wave * C::FP_REGS + r) * 4 + g) * 16 + i16] = FP[r];
+            __syncthreads();
+            FringeOut<S, 0>::run(lb, slab, tid);
+        }
     }
     if (tid == 0) {
         double t = 0.0;
