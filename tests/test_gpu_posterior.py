@@ -1,0 +1,118 @@
+"""GPU: the sampler against a posterior known in closed form -- independent of the oracle.
+
+A single GaussianDenseLayer (no activation) under FixedGaussianLikelihood is Bayesian linear regression: with the
+reference's densities (multivariateLogProb, BNN_functions.py:7-34: prior N(mu, sigma = g^2) per element -- the Q2
+normaliser quirk only shifts a constant -- and likelihood N(f, sd), likelihood.py:143-169) the posterior of
+theta = (W, b) is Gaussian with precision A^T A / sd^2 + I / sigma^2 and mean Sigma (A^T y / sd^2 + mu / sigma^2),
+A = [X, 1].  The whole transition (momentum draw from Philox, leapfrog, Metropolis, state hand-over between epochs)
+must reproduce its mean and covariance within Monte-Carlo error.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kernel", ["auto", "generic"])
+def test_linear_gaussian_posterior(native, kernel):
+    rng = np.random.default_rng(21)
+    n, d = 160, 3
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    w_true = np.array([0.7, -1.2, 0.4], np.float32)
+    sd = 0.5
+    Y = (X @ w_true + 0.3 + sd * rng.standard_normal(n)).astype(np.float32).reshape(n, 1)
+    mu_w, g_w, mu_b, g_b = 0.1, 0.9, -0.2, 1.1          # prior: N(mu_w, (g_w^2)^2) on W, N(mu_b, (g_b^2)^2) on b
+    layers = [(d, 1, native.ACT_NONE, native.PRIOR_GAUSSIAN)]
+    ch = native.Chain(layers, likelihood=native.LIK_FIXED_GAUSSIAN, fixed_sd=sd, seed=11, chain_id=3,
+                      kernel=native.KERNEL_AUTO if kernel == "auto" else native.KERNEL_GENERIC)
+    ch.set_data(X, Y)
+    ch.set_hypers(np.array([mu_w, g_w, mu_b, g_b], np.float32))
+    ch.set_state(np.zeros(d + 1, np.float32))
+    # closed form
+    A = np.concatenate([X.astype(np.float64), np.ones((n, 1))], axis=1)
+    prec0 = np.diag([1 / g_w ** 4] * d + [1 / g_b ** 4])
+    m0 = np.array([mu_w] * d + [mu_b])
+    prec = A.T @ A / sd ** 2 + prec0
+    cov = np.linalg.inv(prec)
+    mean = cov @ (A.T @ Y.astype(np.float64).ravel() / sd ** 2 + prec0 @ m0)
+    # sample: eps ~ half the smallest posterior scale, trajectory length ~ a quarter period of the stiffest direction
+    s_min = np.sqrt(np.linalg.eigvalsh(cov).min())
+    eps, L = 0.35 * s_min, 7
+    ch.hmc_run(eps, L, 300)                                     # burn-in
+    accs = []
+    # every transition's state is wanted: one epoch per call
+    T = 4000
+    samples = np.empty((T, d + 1))
+    for t in range(T):
+        out = ch.hmc_step(eps, L)
+        accs.append(out["accept_prob"])
+        samples[t] = ch.get_state()
+    assert 0.6 < np.mean(accs) <= 1.0, np.mean(accs)
+    m_hat = samples.mean(axis=0)
+    c_hat = np.cov(samples.T)
+    # integrated autocorrelation time of each coordinate (Sokal window) -> effective sample size
+    from tensorbnn_amd.predictor import integrated_time
+    tau = np.array([integrated_time(samples[:, j], tol=0, quiet=True)[0] for j in range(d + 1)])
+    ess = T / np.maximum(tau, 1.0)
+    se = np.sqrt(np.diag(cov) / ess)
+    assert np.all(np.abs(m_hat - mean) < 5 * se), (m_hat, mean, se)
+    # variances: relative Monte-Carlo error of a variance estimate ~ sqrt(2 / ESS)
+    rel = np.abs(np.diag(c_hat) / np.diag(cov) - 1)
+    assert np.all(rel < 6 * np.sqrt(2 / ess)), (rel, ess)
+    # correlations
+    sdv = np.sqrt(np.diag(cov)); sdh = np.sqrt(np.diag(c_hat))
+    assert np.max(np.abs(c_hat / np.outer(sdh, sdh) - cov / np.outer(sdv, sdv))) < 0.12
+    ch.close()
+
+
+def _batch_se(x, nb=40):
+    """standard error of the mean of a correlated series from batch means; x: [T, k]"""
+    T = (x.shape[0] // nb) * nb
+    bm = x[:T].reshape(nb, T // nb, -1).mean(axis=1)
+    return bm.std(axis=0, ddof=1) / np.sqrt(nb)
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh"])
+def test_score_identities_on_the_mfma_path(native, act):
+    """For any proper density that is continuous and piecewise smooth, E[grad log p] = 0 and
+    E[theta_i * d_i log p] = -1 (integration by parts).  Samples drawn by the fused MFMA kernels (configs[0] shape with
+    Relu, the trainRegression.py shape with Tanh; Gaussian priors so that the posterior is proper -- the reference's
+    Cauchy sign quirk Q1 makes that prior improper) must satisfy both within Monte-Carlo error: a statement about the
+    stationary distribution of the whole transition that needs no oracle.  Trajectories are long (L = 200) so that the
+    chain mixes over the prior-dominated directions; with L = 12 it is still drifting after 6000 epochs and the batch-means
+    errors are not valid (tools/scorediag.py)."""
+    import tbnn_oracle as o
+    a_kind, dims = (o.ACT_RELU, [1, 10, 10, 1]) if act == "relu" else (o.ACT_TANH, [1, 10, 10, 10, 1])
+    spec, X, Y, theta, eta = o.synth_problem(dims, 256, a_kind, o.PRIOR_GAUSSIAN, o.LIK_FIXED_GAUSSIAN)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=0.3, seed=5, chain_id=1)
+    assert ch.kernel_name.startswith("fast3<"), ch.kernel_name
+    ch.set_data(X, Y)
+    eta = np.tile(np.array([0.0, 1.0, 0.0, 1.0], np.float32), len(layers))       # N(0, 1) on every weight and bias
+    ch.set_hypers(eta)
+    ch.set_state((0.3 * theta).astype(np.float32))
+    L = 200
+    eps = 1e-3
+    ch.hmc_run(eps, L, 200)                                     # into the typical set first
+    for _ in range(30):                                         # then a step size with acceptance in [0.65, 0.9]
+        acc = np.mean([o_["accept_prob"] for o_ in ch.hmc_run(eps, L, 60)])
+        if acc < 0.65: eps *= 0.8
+        elif acc > 0.9: eps *= 1.2
+        else: break
+    ch.hmc_run(eps, L, 200)
+    T = 1500
+    P = ch.P
+    G = np.empty((T, P)); TH = np.empty((T, P)); acc = []
+    for t in range(T):
+        acc.append(ch.hmc_step(eps, L)["accept_prob"])
+        th = ch.get_state()
+        _, g, _ = ch.logp_grad(th, eta)
+        TH[t] = th; G[t] = g
+    assert 0.5 < np.mean(acc) <= 1.0, (np.mean(acc), eps)
+    z1 = G.mean(axis=0) / _batch_se(G)
+    v = TH * G
+    z2 = (v.mean(axis=0) + 1.0) / _batch_se(v)
+    for z in (z1, z2):
+        assert np.max(np.abs(z)) < 5.5, np.max(np.abs(z))      # P z-scores of unit variance: the maximum is ~3
+        assert np.mean(z * z) < 1.8, np.mean(z * z)
+    ch.close()
