@@ -116,3 +116,41 @@ def test_score_identities_on_the_mfma_path(native, act):
         assert np.max(np.abs(z)) < 5.5, np.max(np.abs(z))      # P z-scores of unit variance: the maximum is ~3
         assert np.mean(z * z) < 1.8, np.mean(z * z)
     ch.close()
+
+
+def test_score_identities_of_the_hyper_transition(native):
+    """the same two identities for the hyper-parameter transition (k_hyper, network.py:414-456) at fixed weights:
+    GaussianDenseLayer hyper target (proper in (mu, g); the Cauchy one is not, Q1) + the Gaussian likelihood's sd"""
+    import tbnn_oracle as o
+    spec, X, Y, theta, eta = o.synth_problem([5, 50, 50, 50, 1], 512, o.ACT_RELU, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    ch = native.Chain(layers, likelihood=spec.likelihood, seed=9, chain_id=2)
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    ch.logp_grad()                                              # the cached data statistic S of the weight state
+    L, eps = 25, 2e-3
+    ep = [0]
+    def step():
+        ep[0] += 1
+        ch.set_epoch(ep[0])                                     # the Philox stream is keyed by the epoch (one hyper step per epoch)
+        return ch.hyper_step(eps, L)["accept_prob"]
+    for _ in range(40):
+        acc = np.mean([step() for _ in range(40)])
+        if acc < 0.65: eps *= 0.8
+        elif acc > 0.92: eps *= 1.2
+        else: break
+    for _ in range(300): step()
+    T, H = 4000, ch.H
+    G = np.empty((T, H)); E = np.empty((T, H)); acc = []
+    for t in range(T):
+        acc.append(step())
+        E[t] = ch.get_hypers()
+        _, g = ch.hyper_logp_grad()
+        G[t] = g
+    assert 0.5 < np.mean(acc) <= 1.0, (np.mean(acc), eps)
+    z1 = G.mean(axis=0) / _batch_se(G)
+    v = E * G
+    z2 = (v.mean(axis=0) + 1.0) / _batch_se(v)
+    for z in (z1, z2):
+        assert np.max(np.abs(z)) < 5.0, (z, eps)
+        assert np.mean(z * z) < 2.5, np.mean(z * z)
+    ch.close()
