@@ -173,6 +173,9 @@ __device__ __forceinline__ float gsum(float p) {
 #ifndef TBNN_F3_M4
 #define TBNN_F3_M4 1
 #endif
+#ifndef TBNN_F3_M4ACC
+#define TBNN_F3_M4ACC 4
+#endif
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
@@ -180,20 +183,22 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 template <class S, int K>
 __device__ __forceinline__ f32x4 fringe_partials(const float* __restrict__ prow, const f32x4* tiles) {
     using C = F3Cfg<S>;
-    // one accumulator per k-group: independent chains (a dependent 4x4x1 waits for the previous result), summed at the end
-    constexpr int KG = C::cdiv(K, 16);
-    f32x4 acc[KG];
+    // TBNN_F3_M4ACC accumulators, k-groups dealt round-robin, summed at the end (dependent 4x4x1 MFMAs issue back to back
+    // at full rate, tools/ubench/chain.hip; more accumulators only shorten the chain the gsum MFMA waits for)
+    constexpr int KG = C::cdiv(K, 16), NA = KG < TBNN_F3_M4ACC ? KG : TBNN_F3_M4ACC;
+    f32x4 acc[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < KG; ++kt) {
-        acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 w = load_ks(prow + 16 * kt, C::ksteps(K, kt));
 #pragma unroll
-        for (int s = 0; s < C::ksteps(K, kt); ++s) acc[kt] = mfma4(w[s], tiles[kt][s], acc[kt]);
+        for (int s = 0; s < C::ksteps(K, kt); ++s) acc[kt % NA] = mfma4(w[s], tiles[kt][s], acc[kt % NA]);
     }
 #pragma unroll
-    for (int st = 1; st < KG; st *= 2)
+    for (int st = 1; st < NA; st *= 2)
 #pragma unroll
-        for (int kt = 0; kt + st < KG; kt += 2 * st) acc[kt] += acc[kt + st];
+        for (int a = 0; a + st < NA; a += 2 * st) acc[a] += acc[a + st];
     return acc[0];
 }
 // sum over the 4 lane groups, broadcast to every lane (row i16); C is the inline constant 0 (a bias travelling in C
