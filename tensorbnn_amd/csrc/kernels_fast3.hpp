@@ -34,80 +34,6 @@
 #ifndef TBNN_F3_THREAD
 #define TBNN_F3_THREAD 1
 #endif
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Packed f32 FMA as an opaque instruction.  The compiler's pre-emit peephole splits a v_pk_fma_f32 that follows an
-// MFMA into two v_fma_f32 on the assumption that they run in the MFMA's shadow; on gfx950 an f32 MFMA and the f32
-// VALU share the issue slot (tools/ubench/coexec.hip: +8.6 cycles per VALU instruction either way), so the split
-// doubles the cost.  Operands of these helpers are never raw MFMA results (no software wait states are inserted
-// for inline asm): callers pass activation outputs, LDS loads or VALU results only.
-__device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-// a * (b[H], b[H]) + c
-template <int H>
-__device__ __forceinline__ f32x2 pkfma_bc(f32x2 a, f32x2 b, f32x2 c) {
-    f32x2 d;
-    if constexpr (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-// Relu derivative of a pair of activation outputs as {0, 1} floats in ONE packed instruction: clamp(a * FLT_MAX) to
-// [0, 1].  a >= 0 always; every normal a > 0 gives 1, a == 0 gives 0 (a positive denormal below 2.9e-39 would give a
-// fraction: a pre-activation in that interval does not occur in fp32 arithmetic of this size).  The mask is applied
-// with v_mul_legacy_f32 (0 * x = 0 for every x, inf and NaN included), so a masked-out element is an exact zero
-// like the select it replaces: 1.5 VALU instructions per element instead of v_cmp + v_cndmask.
-#ifndef TBNN_F3_RELU_PK
-#define TBNN_F3_RELU_PK 1
-#endif
-__device__ __forceinline__ f32x2 relu_step2(f32x2 a, f32x2 big) {
-    f32x2 d;
-    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(big));
-    return d;
-}
-__device__ __forceinline__ float mul_legacy(float s, float x) {
-    float d;
-    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(d) : "v"(s), "v"(x));
-    return d;
-}
-// The opaque instructions above read MFMA results, and no software wait states are inserted for inline asm: settle()
-// stands between the MFMAs that produced `acc` and the first opaque reader (11 wait states cover the 8-pass
-// v_mfma_f32_16x16x4_f32 -> VALU read requirement of 10).
-template <int N>
-__device__ __forceinline__ void mfma_settle(f32x4 (&acc)[N]) {
-    static_assert(N >= 1 && N <= 4, "one asm statement ties up to 4 tiles");
-    if constexpr (N == 1) asm volatile("s_nop 10" : "+v"(acc[0]));
-    if constexpr (N == 2) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]));
-    if constexpr (N == 3) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
-    if constexpr (N == 4) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-}
-// acc * act'(a) for the 4 registers of a tile; SETTLED: the caller has called mfma_settle on acc (or acc is a VALU result)
-template <int ACT, bool SETTLED>
-__device__ __forceinline__ f32x4 actc_bwd_mul4(f32x4 acc, f32x4 a) {
-    f32x4 r;
-    if constexpr (ACT == TBNN_ACT_RELU && TBNN_F3_RELU_PK && SETTLED) {
-        const f32x2 big = {3.402823466e38f, 3.402823466e38f};
-        const f32x2 s01 = relu_step2(f32x2{a[0], a[1]}, big), s23 = relu_step2(f32x2{a[2], a[3]}, big);
-        r[0] = mul_legacy(s01[0], acc[0]); r[1] = mul_legacy(s01[1], acc[1]);
-        r[2] = mul_legacy(s23[0], acc[2]); r[3] = mul_legacy(s23[1], acc[3]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = actc_bwd_mul<ACT>(acc[i], a[i]);
-    }
-    return r;
-}
-
-// a * (b[H], b[H])
-template <int H>
-__device__ __forceinline__ f32x2 pkmul_bc(f32x2 a, f32x2 b) {
-    f32x2 d;
-    if constexpr (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-
 template <class S>
 struct F3Cfg : FastCfg<S> {
     using B = FastCfg<S>;
@@ -176,9 +102,6 @@ __device__ __forceinline__ float gsum(float p) {
 #ifndef TBNN_F3_M4ACC
 #define TBNN_F3_M4ACC 4
 #endif
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
-}
 // prow: this lane's A-operand row (image row 16*MTF + 4*(i16&3), + 4g); tiles: the K dimension in D-layout registers
 template <class S, int K>
 __device__ __forceinline__ f32x4 fringe_partials(const float* __restrict__ prow, const f32x4* tiles) {
@@ -201,12 +124,6 @@ __device__ __forceinline__ f32x4 fringe_partials(const float* __restrict__ prow,
         for (int a = 0; a + st < NA; a += 2 * st) acc[a] += acc[a + st];
     return acc[0];
 }
-// sum over the 4 lane groups, broadcast to every lane (row i16); C is the inline constant 0 (a bias travelling in C
-// would cost four v_mov to splat it, one v_add afterwards is cheaper)
-__device__ __forceinline__ float gsum_mfma(float p) {
-    return mfma16(1.f, p, f32x4{0.f, 0.f, 0.f, 0.f})[0];
-}
-
 // sum_k w[k-slot] * v[k-slot] over this lane's k-slots of a K dimension living in D-layout tiles
 // PK: `tiles` hold VALU results (activation outputs / masked deltas), so the opaque packed FMA may read them
 template <class S, int K, bool PK>
