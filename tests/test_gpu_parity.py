@@ -119,6 +119,30 @@ def test_fast_vs_generic_full_size(native):
     assert np.abs(g_f - g_g).max() <= 2e-5 * np.abs(g_g).max()
 
 
+def test_transition_full_size_vs_c_restatement(native):
+    """one whole transition at BASELINE configs[1]'s full size (n = 1e5, L = 10, injected momentum and uniform) against the
+    C restatement of the reference's fp32 path (oracle/c): per-step log-prob trace, log accept ratio, decision, new state"""
+    import c_oracle
+    spec, X, Y, theta, eta = o.synth_problem([5, 50, 50, 50, 1], 100000)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    ch = native.Chain(layers, likelihood=spec.likelihood)
+    assert ch.kernel_name.startswith("fast3<")
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    rng = np.random.default_rng(77)
+    p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+    eps, L, lu = 2e-5, 10, float(np.log(0.3))
+    out = ch.hmc_step(eps, L, p0=p0, log_u=lu, trace=True)
+    co = c_oracle.COracle(spec, X, Y)
+    th_c, acc_c, lar_c, lp_old, lp_new = co.hmc_step(theta, eta, eps, L, p0, lu)
+    assert abs(out["logp_old"] - lp_old) <= 4e-6 * abs(lp_old)
+    assert abs(out["logp_new"] - lp_new) <= 4e-6 * abs(lp_new)
+    assert abs(out["log_accept_ratio"] - lar_c) <= 2e-2 + 1e-4 * abs(lar_c)
+    assert bool(out["accepted"]) == acc_c
+    if acc_c:
+        np.testing.assert_allclose(ch.get_state(), th_c, rtol=0, atol=2e-6 * np.abs(th_c).max() + 1e-7)
+    ch.close()
+
+
 @pytest.mark.parametrize("case", list(CASES))
 def test_forward(native, case):
     spec, X, Y, theta, eta = problem(case)
