@@ -1,26 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- leapfrog steps/s of the HMC hot path on BASELINE configs[1].
+"""bench.py -- leapfrog steps/s of the HMC hot path on BASELINE configs[1] (+ the other configs as `secondary`).
 
   python bench.py --gpus N --steps K --warmup W
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one HMC transition (epoch) = L=50 leapfrog steps of the
-5->50->50->50->1 Relu BNN over the 100k-row synthetic regression matrix
-(SURVEY.md section 8(d)); X and Y are resident in HBM
-before the timed region.  One independent chain per GPU (chain_id = rank), no
-data-path collective; an RCCL all-gather of the sampled state (theta, eta)
-runs every --sampling-step epochs inside the timed region when N > 1
-(checkpoint-time gather, the path's only exchange).  value = leapfrog steps of
-all ranks / max-over-ranks wall time.
+A "step" is one HMC transition (epoch) = L=50 leapfrog steps of the 5->50->50->50->1 Relu BNN over the 100k-row
+synthetic regression matrix; X and Y are resident in HBM before the
+timed region.  The chain starts from the committed burned-in state tests/golden/c2_burned.npz (tools/make_burned.py)
+with the step size recorded there, so the accept ratio is in [0.6, 0.9] whatever --steps / --warmup are.  One
+independent chain per GPU (chain_id = rank), no data-path collective; the RCCL all-gather of the sampled state
+(theta, eta) -- tbnn_gather_samples, the path's only exchange -- runs every --sampling-step epochs inside the timed
+region when N > 1.  value = leapfrog steps of all ranks / max-over-ranks wall time.
 
-roofline: dominant kernel = k_fwd_bwd_fast.  achieved = algorithmic matmul
-FLOP of one launch (2n(3S - in1*out1)) / its mean duration,
-measured with hipEvent pairs on the chain's own stream around every 10th
-launch inside the timed region.  peak = 157.3 TFLOP/s (FP32 MFMA, dense,
-MI355X_MICROARCH.md).  traffic = HBM bytes per launch from the committed
-rocprofv3 PMC pass (profiles/), or null.
-cpu_baseline: the oracle's C restatement (oracle/c, kind "port") timed on the
-host cores on a bounded sample of the same workload (rank 0, N=1 only).
+At N = 1 the same invocation also measures BASELINE configs[3], configs[4] (weight transition + hyper transition with
+the reference's dual averaging per epoch) and configs[0], each with its own roofline and cpu_baseline, under
+"secondary" (--workload X measures X alone; --no-secondary skips them).
+
+roofline: dominant kernel = the fused forward+backward pass (k_fwd_bwd_fast3; k_chain_wide + k_dw_wide for the wide
+configs).  achieved = algorithmic matmul FLOP of one pass (2n(3S - in1*out1)) / its mean duration,
+measured with hipEvent pairs on the chain's own stream around every 10th pass inside the timed region.  peak = 157.3
+TFLOP/s (FP32 MFMA, dense, MI355X_MICROARCH.md).  traffic = HBM bytes per pass from the committed rocprofv3 PMC pass
+(profiles/), or null.
+cpu_baseline: the oracle's C restatement (oracle/c, kind "port") timed on the host cores on a bounded sample of the
+same workload from the same state (rank 0, N = 1 only, outside the timed GPU region): best thread count of a short
+scan, a 1-thread figure, and a PyTorch-CPU value+grad cross-check (oracle/torch_ref.py).
 """
 import argparse
 import json
@@ -32,20 +35,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = 157.3
-HYPER_EPS = 2e-5       # configs[4] hyper transition (L_h = 100): scan 3e-5 -> 0.85..0.13, 1e-5 -> 0.99 (tools/hyperprobe.py)
-# --workload: c2 = BASELINE configs[1] (the metric's config, default); c4 / c5 = configs[3] / configs[4]
-# (extra lines for the wide-layer path, same JSON contract)
-WORKLOADS = {
-    "c2": dict(dims=[5, 50, 50, 50, 1], n=100_000, L=50, lik="gaussian", steps=200, warmup=20, cpu_epochs=4, cpu_L=50,
-               text="BASELINE configs[1]: 5->50->50->50->1 Relu BNN (Cauchy DenseLayer, GaussianLikelihood sd=0.1), "
-                    "100k-row fp32 synthetic regression, L=50 leapfrog, 1 chain per GPU"),
-    "c4": dict(dims=[10, 200, 200, 200, 1], n=1_000_000, L=100, lik="gaussian", steps=20, warmup=20, cpu_epochs=1, cpu_L=3,
-               text="BASELINE configs[3]: 10->200->200->200->1 Relu BNN (Cauchy DenseLayer, GaussianLikelihood sd=0.1), "
-                    "1M-row fp32 synthetic regression, L=100 leapfrog, 1 chain per GPU"),
-    "c5": dict(dims=[20, 100, 100, 2], n=500_000, L=50, lik="bernoulli", steps=60, warmup=20, cpu_epochs=1, cpu_L=20,
-               text="BASELINE configs[4]: 20->100->100->2 Relu/Sigmoid BNN (Cauchy DenseLayer, BernoulliLikelihood), "
-                    "500k-row fp32 synthetic classification, L=50 leapfrog + hyper-HMC (L_h=100) per epoch, 1 chain per GPU"),
-}
+CONFIG_KEY = {"c1": "configs[0]", "c2": "configs[1]", "c4": "configs[3]", "c5": "configs[4]"}
+# CPU sample per workload: (max epochs, leapfrog steps per epoch, wall cap in s) for the all-threads run
+CPU_SAMPLE = {"c1": (20, 100, 10.0), "c2": (20, 50, 30.0), "c4": (1, 3, 30.0), "c5": (1, 20, 30.0)}
 
 
 def algorithmic_flops(dims, n):
@@ -53,64 +45,124 @@ def algorithmic_flops(dims, n):
     return 2.0 * n * (3 * S - dims[0] * dims[1])
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--eps", type=float, default=None, help="leapfrog step size (default: fixture value)")
-    ap.add_argument("--sampling-step", type=int, default=10)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-epochs", type=int, default=None)
-    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fast"])
-    args = ap.parse_args()
-    wl = WORKLOADS[args.workload]
-    DIMS, N_ROWS, L = wl["dims"], wl["n"], wl["L"]
-    if args.steps is None:
-        args.steps = wl["steps"]
-    if args.warmup is None:
-        args.warmup = wl["warmup"]
-    if args.cpu_epochs is None:
-        args.cpu_epochs = wl["cpu_epochs"]
+def host_cpus():
+    """(logical CPUs this process may run on, physical cores among them)"""
+    aff = sorted(os.sched_getaffinity(0))
+    cores = set()
+    try:
+        for c in aff:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            cores.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+    except OSError:
+        cores = set(aff)
+    return len(aff), len(cores)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+def cpu_baseline(name, wl, X, Y, theta, eta, eps, P):
+    """the C restatement (and the torch cross-check) timed on the host; returns the cpu_baseline object"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    import tbnn_oracle as o
+    from tensorbnn_amd import _native as nat
+    bern = wl["lik"] == nat.LIK_BERNOULLI
+    spec = o.make_spec(wl["dims"], likelihood=o.LIK_BERNOULLI if bern else o.LIK_GAUSSIAN,
+                       final_act=o.ACT_SIGMOID if bern else o.ACT_NONE)
+    co = c_oracle.COracle(spec, X, Y)
+    logical, physical = host_cpus()
+    max_thr = co.threads
+    flop_row = algorithmic_flops(wl["dims"], 1)
+    # thread-count scan (the box may hand this process fewer CPUs than it shows) on a row block sized to ~2e10 FLOP
+    n_scan = int(min(wl["n"], max(4096, 2e10 / flop_row)))
+    cs = c_oracle.COracle(spec, X[:n_scan], Y[:n_scan])
+    scan = {}
+    for t in sorted({t for t in (8, 16, 32, 64, physical, logical, max_thr) if 1 <= t <= max_thr} or {1}):
+        cs.set_threads(t)
+        cs.logp_grad(theta, eta)                      # warm the pool
+        t0 = time.perf_counter()
+        for _ in range(2):
+            cs.logp_grad(theta, eta)
+        scan[t] = 2 / (time.perf_counter() - t0) * n_scan / wl["n"]       # full-size gradient evaluations per second
+    best = max(scan, key=scan.get)
+    max_ep, cL, cap = CPU_SAMPLE[name]
+    rng = np.random.default_rng(0)
+
+    def timed(orc, threads, epochs, L, cap_s):
+        orc.set_threads(threads)
+        th = theta.copy()
+        acc, done = [], 0
+        t0 = time.perf_counter()
+        while done < epochs and (done == 0 or time.perf_counter() - t0 < cap_s):
+            p0 = rng.standard_normal(P).astype(np.float32)
+            th, a, lar, _, _ = orc.hmc_step(th, eta, eps, L, p0, float(np.log(rng.random())))
+            acc.append(min(1.0, float(np.exp(min(lar, 0.0)))))
+            done += 1
+        dt = time.perf_counter() - t0
+        return done * L / dt, done, float(np.mean(acc)), dt
+
+    v, ep, acc, dt = timed(co, best, max_ep, cL, cap)
+    lp_c = co.logp_grad(theta, eta)[0]                 # (still at `best` threads) reference value for the torch cross-check
+    # one thread: the same arithmetic on a row block sized to ~2.5e10 FLOP per gradient, scaled to the full row count
+    n_one = int(min(wl["n"], max(1024, 2.5e10 / flop_row)))
+    c1t = c_oracle.COracle(spec, X[:n_one], Y[:n_one])
+    L1 = cL if name == "c1" else 5
+    v1, ep1, _, dt1 = timed(c1t, 1, 1, L1, cap)
+    v1 *= n_one / wl["n"]
+    out = {"value": round(v, 3), "unit": "leapfrog steps/s", "cores": int(best), "kind": "port",
+           "sample": f"{ep} epochs x L={cL} (+1 bootstrap gradient per epoch, as the reference pays, Q10) of the same "
+                     f"{wl['n']}-row workload from the same chain state at the timed eps, OpenMP C restatement oracle/c, "
+                     f"{dt:.1f} s",
+           "accept_ratio": round(acc, 4), "logical_cpus": logical, "physical_cores": physical,
+           "thread_scan_grad_evals_per_s": {str(k): round(val, 3) for k, val in scan.items()},
+           "one_thread": {"value": round(v1, 4), "unit": "leapfrog steps/s", "cores": 1,
+                          "sample": f"{ep1} epoch x L={L1} on the first {n_one} rows, scaled by rows to {wl['n']}; {dt1:.1f} s"}}
+    try:                                               # PyTorch-CPU value+grad (BASELINE.md section 4, secondary cross-check)
+        import torch_ref
+        tt = torch_ref.TorchTarget(spec, X, Y)
+        tt.value_and_grad(theta, eta)
+        n_ev, t0 = 0, time.perf_counter()
+        while n_ev < 20 and (n_ev == 0 or time.perf_counter() - t0 < 10.0):
+            lp_t, _ = tt.value_and_grad(theta, eta)
+            n_ev += 1
+        dt_t = time.perf_counter() - t0
+        out["torch_cpu"] = {"value": round(n_ev / dt_t, 3), "unit": "value+grad evaluations/s (= leapfrog steps/s)",
+                            "cores": tt.threads, "kind": "port", "sample": f"{n_ev} evaluations, torch {tt.threads} threads, fp32 autograd",
+                            "logp_rel_diff_vs_c_port": abs(lp_t - lp_c) / abs(lp_c)}
+    except Exception as e:                             # the cross-check is optional; the C port is the baseline
+        out["torch_cpu"] = {"error": repr(e)[:200]}
+    return out
+
+
+def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
+    """one workload on this rank's GPU; returns the result dict (rank 0) or None"""
     import numpy as np
     import torch
     import torch.distributed as dist
-
-    if not os.path.exists(os.path.join(ROOT, "tensorbnn_amd", "libtbnn.so")) and rank == 0:
-        from tensorbnn_amd import build as _b
-        _b.build(verbose=False)
     from tensorbnn_amd import _native as nat
-    from tensorbnn_amd.workloads import synth_problem, bench_eps
+    from tensorbnn_amd import parallel
+    from tensorbnn_amd.network import DualAveraging
+    from tensorbnn_amd.workloads import WORKLOADS, bench_eps, burned_state, synth_problem
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    # TBNN_BENCH_SINGLE_GPU=1 (test hook): every rank uses GPU 0 and the collectives run over gloo on host
-    # copies -- exercises the N > 1 control flow on a 1-GPU box.  Normal runs: one rank per GPU over RCCL.
-    single_gpu = os.environ.get("TBNN_BENCH_SINGLE_GPU", "0") == "1"
-    dev = 0 if single_gpu else local_rank
-    torch.cuda.set_device(dev)
-    cdev = "cpu" if single_gpu else "cuda"
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if single_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
-
-    layers, lik, X, Y, theta0, eta0 = synth_problem(
-        DIMS, N_ROWS, likelihood=nat.LIK_BERNOULLI if wl["lik"] == "bernoulli" else nat.LIK_GAUSSIAN)
-    eps_warm, eps = bench_eps(args.workload)
-    hyper = args.workload == "c5"          # configs[4]: hyper-HMC on the priors enabled (network.py:414-471)
+    wl = WORKLOADS[name]
+    DIMS, N_ROWS, L = wl["dims"], wl["n"], wl["L"]
+    layers, lik, X, Y, theta0, eta0 = synth_problem(DIMS, N_ROWS, likelihood=wl["lik"])
+    burned = None if args.from_initial else burned_state(name)
+    hyper = wl["hyper"]                   # configs[4]: hyper-HMC on the priors enabled (network.py:414-471)
+    da = None
+    if burned is not None:
+        theta0, eta0 = burned["theta"].astype(np.float32), burned["eta"].astype(np.float32)
+        eps_warm = eps = float(burned["eps"])
+        state = f"burned-in ({int(burned['epochs'])} epochs, tests/golden/{name}_burned.npz)"
+    else:
+        eps_warm, eps = bench_eps(name) if name != "c1" else (1e-4, 1e-4)
+        state = "initial state (no burned-in fixture): warm-up at eps_warmup"
     if args.eps is not None:
         eps_warm = eps = args.eps
+    if hyper:
+        da = DualAveraging(1e-2, burnin=10 ** 9)          # setupMCMC's default hyperStepSize; adapting throughout
+        if burned is not None and "da_h" in burned:
+            da.h, da.logEpsilonBar, da.step_size = np.float32(burned["da_h"]), np.float32(burned["da_logEpsilonBar"]), np.float32(burned["da_step"])
+    da_epoch = int(burned["da_epoch"]) if (hyper and burned is not None and "da_epoch" in burned) else 0
     kern = {"auto": nat.KERNEL_AUTO, "generic": nat.KERNEL_GENERIC, "fast": nat.KERNEL_FAST}[args.kernel]
     ch = nat.Chain(layers, likelihood=lik, device=dev, seed=50, chain_id=rank, kernel=kern)
     # inputs resident in HBM before the timed region (torch owns the buffers)
@@ -120,30 +172,66 @@ def main():
     ch.set_data_device(dX.data_ptr(), dY.data_ptr(), N_ROWS)
     ch.set_state(theta0)
     ch.set_hypers(eta0)
-    sample = torch.empty(ch.P + ch.H, dtype=torch.float32, device="cuda")
-    gathered = torch.empty(world * (ch.P + ch.H), dtype=torch.float32, device=cdev) if world > 1 else None
 
-    hyp_acc = []
+    # checkpoint-time gather: the native RCCL all-gather of the C ABI (tbnn_gather_samples); every rank must agree on
+    # the route, so a rank that cannot load / join says so through torch.distributed before anyone enters a collective
+    comm, gather_kind = None, "none"
+    sample = gathered = None
+    if world > 1:
+        cdev = ctx["cdev"]
+        ok = 1
+        try:
+            nat.comm_unique_id()                       # loads the collective library (non-collective)
+        except Exception as e:
+            ok = 0
+            print(f"[rank {rank}] native collective library unavailable: {e}", file=sys.stderr, flush=True)
+        t = torch.tensor([ok], dtype=torch.int32, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 1:
+            try:
+                comm = parallel.make_comm(ch)
+                ch.gather_samples(comm)
+            except Exception as e:
+                ok, comm = 0, None
+                print(f"[rank {rank}] native gather failed: {e}", file=sys.stderr, flush=True)
+            t = torch.tensor([ok], dtype=torch.int32, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 1:
+            gather_kind = "tbnn_gather_samples (RCCL all-gather on the chain's stream)"
+        else:                                          # torch.distributed carries the same P+H floats per rank
+            comm = None
+            gather_kind = "torch.distributed all_gather (native route unavailable, see stderr)"
+            sample = torch.empty(ch.P + ch.H, dtype=torch.float32, device="cuda")
+            gathered = torch.empty(world * (ch.P + ch.H), dtype=torch.float32, device=cdev)
+
+    hyp_acc, hyp_eps = [], []
 
     def run(epochs, profile_stride, eps):
+        nonlocal da_epoch
         ch.set_profiling(profile_stride)
         outs = []
         done = 0
         while done < epochs:
             k = min(args.sampling_step, epochs - done)
-            if hyper:                          # weight transition + hyper transition per epoch (hyper steps not counted)
+            if hyper:                          # weight transition + hyper transition + dual averaging per epoch (hyper steps not counted)
                 for _ in range(k):
                     outs.append(ch.hmc_step(eps, L))
-                    hyp_acc.append(ch.hyper_step(HYPER_EPS, 100)["accept_prob"])
+                    h = ch.hyper_step(float(da.step_size), 100)
+                    hyp_eps.append(float(da.step_size))
+                    hyp_acc.append(float(da.update(da_epoch, h["log_accept_ratio"])))
+                    da_epoch += 1
             else:
                 outs += ch.hmc_run(eps, L, k)
             done += k
             if world > 1:                      # checkpoint-time gather over RCCL/xGMI
-                ch.export_sample_device(sample.data_ptr())
-                if single_gpu:
-                    dist.all_gather(list(gathered.chunk(world)), sample.cpu())
+                if comm is not None:
+                    ch.gather_samples(comm)
                 else:
-                    dist.all_gather_into_tensor(gathered, sample)
+                    ch.export_sample_device(sample.data_ptr())
+                    if ctx["single_gpu"]:
+                        dist.all_gather(list(gathered.chunk(world)), sample.cpu())
+                    else:
+                        dist.all_gather_into_tensor(gathered, sample)
         return outs
 
     def fence():
@@ -151,14 +239,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup, 0, eps_warm)
-    hyp_acc.clear()
+    run(warmup, 0, eps_warm)
+    hyp_acc.clear(); hyp_eps.clear()
     fence()
     t0 = time.perf_counter()
-    outs = run(args.steps, 10, eps)
+    outs = run(steps, 10, eps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
+        cdev = ctx["cdev"]
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -170,67 +259,132 @@ def main():
         acc_prob = float(np.mean([o["accept_prob"] for o in outs]))
         acc_frac = float(np.mean([o["accepted"] for o in outs]))
 
-    total_leapfrog = world * args.steps * L
+    total_leapfrog = world * steps * L
     value = total_leapfrog / dt
     prof = [o["fwdbwd_us"] for o in outs if o["fwdbwd_us"] > 0]
     k_us = float(np.mean(prof)) if prof else None
     flops = algorithmic_flops(DIMS, N_ROWS)
-
-    if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("hbm_bytes_per_launch") if args.workload == "c2" else tj.get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = None
-        if k_us:
-            achieved = flops / (k_us * 1e-6) / 1e12
-            roofline = {"bound": "mfma", "kernel": ch.kernel_name, "achieved": round(achieved, 3),
-                        "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4),
-                        "traffic": traffic, "kernel_us": round(k_us, 2), "flop_per_launch": flops,
-                        "hbm_gbps_algorithmic": round((4.0 * N_ROWS * (DIMS[0] + DIMS[-1]) + 12.0 * ch.P)
-                                                      / (k_us * 1e-6) / 1e9, 2)}
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import c_oracle
-            import tbnn_oracle as o
-            bern = wl["lik"] == "bernoulli"
-            spec = o.make_spec(DIMS, likelihood=o.LIK_BERNOULLI if bern else o.LIK_GAUSSIAN,
-                               final_act=o.ACT_SIGMOID if bern else o.ACT_NONE)
-            co = c_oracle.COracle(spec, X, Y)
-            th = theta0.copy()
-            rng = np.random.default_rng(0)
-            if args.workload == "c2":
-                co.logp_grad(th, eta0)      # warm the thread pool
-            tc = time.perf_counter()
-            for e in range(args.cpu_epochs):
-                p0 = rng.standard_normal(ch.P).astype(np.float32)
-                # from the initial state only the warm-up step size is stable; the arithmetic per epoch is identical
-                th, _, _, _, _ = co.hmc_step(th, eta0, eps_warm, wl["cpu_L"], p0, float(np.log(rng.random())))
-            tc = time.perf_counter() - tc
-            cpu = {"value": round(args.cpu_epochs * wl["cpu_L"] / tc, 3), "unit": "leapfrog steps/s", "cores": co.threads,
-                   "kind": "port",
-                   "sample": f"{args.cpu_epochs} epochs x L={wl['cpu_L']} (+1 bootstrap gradient per epoch, as the reference "
-                             f"pays, Q10) of the same {N_ROWS}-row workload, OpenMP C restatement oracle/c"}
-        line = {
-            "metric": "leapfrog steps/sec (whole node)", "value": round(value, 2), "unit": "leapfrog steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["text"], "leapfrog_per_step": L, "eps": eps, "eps_warmup": eps_warm,
-                       "rows": N_ROWS, "chains": world, "parallelism": f"{world} independent chains",
-                       "kernel": ch.kernel_name},
-            "accept_ratio": round(acc_prob, 4), "accepted_fraction": round(acc_frac, 4),
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        if hyper:
-            line["hyper_accept_ratio"] = round(float(np.mean(hyp_acc)), 4) if hyp_acc else None
-        print(json.dumps(line), flush=True)
+    kernel_name = ch.kernel_name
+    theta_end, eta_end = (ch.get_state(), ch.get_hypers()) if rank == 0 else (None, None)
+    P = ch.P
+    if comm is not None:
+        comm.close()
     ch.close()
+    del dX, dY
+    if rank != 0:
+        return None
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch") if name == "c2" else tj.get(name, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = None
+    if k_us and name != "c1":
+        achieved = flops / (k_us * 1e-6) / 1e12
+        roofline = {"bound": "mfma", "kernel": kernel_name, "achieved": round(achieved, 3),
+                    "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4),
+                    "traffic": traffic, "kernel_us": round(k_us, 2), "flop_per_launch": flops,
+                    "hbm_gbps_algorithmic": round((4.0 * N_ROWS * (DIMS[0] + DIMS[-1]) + 12.0 * P) / (k_us * 1e-6) / 1e9, 2),
+                    "end_to_end_frac": round(value / world * flops / 1e12 / PEAK_TFLOPS, 4)}
+    elif name == "c1":
+        roofline = {"bound": "launch latency (7e5 FLOP per step: SURVEY 8(d) reports steps/s only)", "kernel": kernel_name,
+                    "kernel_us": round(k_us, 2) if k_us else None, "frac": None}
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(name, wl, X, Y, theta0, eta0, eps, P)
+    line = {
+        "metric": "leapfrog steps/sec (whole node)", "value": round(value, 2), "unit": "leapfrog steps/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["text"], "leapfrog_per_step": L, "eps": eps, "eps_warmup": eps_warm,
+                   "rows": N_ROWS, "chains": world, "parallelism": f"{world} independent chains",
+                   "kernel": kernel_name, "start_state": state, "sample_gather": gather_kind},
+        "accept_ratio": round(acc_prob, 4), "accepted_fraction": round(acc_frac, 4),
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    if hyper:
+        line["hyper_accept_ratio"] = round(float(np.mean(hyp_acc)), 4) if hyp_acc else None
+        line["hyper_step_size"] = {"first": hyp_eps[0], "last": hyp_eps[-1], "rule": "dual averaging, network.py:457-469"} if hyp_eps else None
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c4", "c5"],
+                    help="measure this workload alone (default: c2 = BASELINE configs[1], + the others as `secondary` at N = 1)")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--eps", type=float, default=None, help="leapfrog step size (default: fixture value)")
+    ap.add_argument("--sampling-step", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--from-initial", action="store_true", help="start from the initial state instead of the burned-in fixture")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fast"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    # the library is built before the ranks need it: local rank 0 builds (atomic rename), the others wait for the file
+    lib_path = os.path.join(ROOT, "tensorbnn_amd", "libtbnn.so")
+    if not os.path.exists(lib_path):
+        if local_rank == 0:
+            from tensorbnn_amd import build as _b
+            _b.build(verbose=False)
+        else:
+            t0 = time.time()
+            while not os.path.exists(lib_path):
+                if time.time() - t0 > 900:
+                    raise SystemExit("libtbnn.so did not appear (build it first: python -m tensorbnn_amd.build)")
+                time.sleep(0.5)
+    from tensorbnn_amd.workloads import WORKLOADS
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # TBNN_BENCH_SINGLE_GPU=1 (test hook): every rank uses GPU 0 and torch's collectives run over gloo on host
+    # copies -- exercises the N > 1 control flow on a 1-GPU box.  Normal runs: one rank per GPU over RCCL.
+    single_gpu = os.environ.get("TBNN_BENCH_SINGLE_GPU", "0") == "1"
+    dev = 0 if single_gpu else local_rank
+    torch.cuda.set_device(dev)
+    ctx = {"single_gpu": single_gpu, "cdev": "cpu" if single_gpu else "cuda"}
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if single_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+
+    main_wl = args.workload or "c2"
+    wl = WORKLOADS[main_wl]
+    steps = args.steps if args.steps is not None else wl["steps"]
+    warmup = args.warmup if args.warmup is not None else wl["warmup"]
+    line = run_workload(main_wl, steps, warmup, args, rank, world, dev, ctx)
+    if args.workload is None and world == 1 and not args.no_secondary:
+        sec = {}
+        for name in ("c4", "c5", "c1"):
+            w2 = WORKLOADS[name]
+            try:
+                r = run_workload(name, w2["steps"], w2["warmup"], args, rank, world, dev, ctx)
+                for k in ("metric", "higher_is_better", "scaling", "vs_baseline", "data", "n_gpus"):
+                    r.pop(k, None)
+                sec[CONFIG_KEY[name]] = r
+            except Exception as e:           # a secondary line must never take the headline line down with it
+                sec[CONFIG_KEY[name]] = {"error": repr(e)[:300]}
+        line["secondary"] = sec
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

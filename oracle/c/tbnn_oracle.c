@@ -95,7 +95,10 @@ double oracle_logp_grad(const onet* n, const float* th, const float* eta, const 
 #ifdef _OPENMP
     nth = omp_get_max_threads();
 #endif
-    float* gacc = (float*)calloc((size_t)nth * P, sizeof(float));
+    /* per-thread gradient accumulators ACROSS row blocks in double (the 64-row dot products inside a block are fp32
+     * like the reference's arithmetic): at n = 1e6 a sequential fp32 sum over 15k blocks would put the oracle's own
+     * rounding (~1e-4 of the tensor norm) on top of what the parity tests measure */
+    double* gacc = (double*)calloc((size_t)nth * P, sizeof(double));
     double* sacc = (double*)calloc((size_t)nth, sizeof(double));
 #pragma omp parallel
     {
@@ -106,7 +109,7 @@ double oracle_logp_grad(const onet* n, const float* th, const float* eta, const 
         float* A = (float*)malloc((size_t)sum * RB * sizeof(float));      /* a_0..a_L, [unit][row] */
         float* DZ = (float*)malloc((size_t)maxw * RB * sizeof(float));
         float* DA = (float*)malloc((size_t)maxw * RB * sizeof(float));
-        float* g = gacc + (size_t)t * P;
+        double* g = gacc + (size_t)t * P;
         double st = 0.0;
 #pragma omp for schedule(static)
         for (long b = 0; b < nblk; ++b) {
@@ -152,7 +155,7 @@ double oracle_logp_grad(const onet* n, const float* th, const float* eta, const 
                 const int in = n->in[l], out = n->out[l];
                 const float* W = th + woff[l];
                 const float* ain = A + (size_t)aoff[l] * RB; const float* aout = A + (size_t)aoff[l + 1] * RB;
-                float* gW = g + woff[l]; float* gb = gW + in * out;
+                double* gW = g + woff[l]; double* gb = gW + in * out;
                 for (int i = 0; i < out; ++i)
                     for (int r = 0; r < RB; ++r) DZ[i * RB + r] = DA[i * RB + r] * dactf(aout[i * RB + r], n->act[l]);
                 for (int i = 0; i < out; ++i) {
@@ -189,11 +192,13 @@ double oracle_logp_grad(const onet* n, const float* th, const float* eta, const 
         free(A); free(DZ); free(DA);
     }
     double stat = 0.0;
-    if (grad) memset(grad, 0, (size_t)P * sizeof(float));
-    for (int t = 0; t < nth; ++t) {
-        stat += sacc[t];
-        if (grad) for (int j = 0; j < P; ++j) grad[j] += gacc[(size_t)t * P + j];
-    }
+    for (int t = 0; t < nth; ++t) stat += sacc[t];
+    if (grad)
+        for (int j = 0; j < P; ++j) {
+            double sj = 0.0;
+            for (int t = 0; t < nth; ++t) sj += gacc[(size_t)t * P + j];
+            grad[j] = (float)sj;
+        }
     free(gacc); free(sacc);
     double lp = prior_logp_grad(n, th, eta, grad);
     if (n->lik == 2) lp += stat;
@@ -205,12 +210,12 @@ double oracle_logp_grad(const onet* n, const float* th, const float* eta, const 
     return lp;
 }
 
-/* one transition; returns accepted flag.  theta is updated in place. */
-int oracle_hmc_step(const onet* n, float* theta, const float* eta, const float* X, const float* Y, long nrows,
-                    float eps, int L, const float* p0, float log_u, double* lar_out, double* logp_old, double* logp_new)
+/* the proposal of one transition: q_out = q_L, *lar_out = log accept ratio (non-finite -> -inf) */
+void oracle_hmc_propose(const onet* n, const float* theta, const float* eta, const float* X, const float* Y, long nrows,
+                        float eps, int L, const float* p0, float* q_out, double* lar_out, double* logp_old, double* logp_new)
 {
     const int P = net_P(n);
-    float* q = (float*)malloc(P * sizeof(float)); float* p = (float*)malloc(P * sizeof(float));
+    float* q = q_out; float* p = (float*)malloc(P * sizeof(float));
     float* g = (float*)malloc(P * sizeof(float));
     memcpy(q, theta, P * sizeof(float));
     const double lp0 = oracle_logp_grad(n, q, eta, X, Y, nrows, g, NULL);      /* bootstrap_results (Q10) */
@@ -224,13 +229,34 @@ int oracle_hmc_step(const onet* n, float* theta, const float* eta, const float* 
     for (int j = 0; j < P; ++j) { p[j] = p[j] - 0.5f * eps * g[j]; k1 += (double)p[j] * p[j]; }
     double lar = lp - lp0 + 0.5 * k0 - 0.5 * k1;
     if (!isfinite(lar)) lar = -INFINITY;
-    const int acc = (double)log_u < lar;
-    if (acc) memcpy(theta, q, P * sizeof(float));
     if (lar_out) *lar_out = lar;
     if (logp_old) *logp_old = lp0;
     if (logp_new) *logp_new = lp;
-    free(q); free(p); free(g);
+    free(p); free(g);
+}
+
+/* one transition; returns accepted flag.  theta is updated in place. */
+int oracle_hmc_step(const onet* n, float* theta, const float* eta, const float* X, const float* Y, long nrows,
+                    float eps, int L, const float* p0, float log_u, double* lar_out, double* logp_old, double* logp_new)
+{
+    const int P = net_P(n);
+    float* q = (float*)malloc(P * sizeof(float));
+    double lar = 0.0;
+    oracle_hmc_propose(n, theta, eta, X, Y, nrows, eps, L, p0, q, &lar, logp_old, logp_new);
+    const int acc = (double)log_u < lar;
+    if (acc) memcpy(theta, q, P * sizeof(float));
+    if (lar_out) *lar_out = lar;
+    free(q);
     return acc;
+}
+
+/* thread count of the following calls (the cpu_baseline leg times 1 thread and the best of several counts) */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 int oracle_num_threads(void) {

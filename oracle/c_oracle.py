@@ -25,7 +25,11 @@ def load():
     lib.oracle_hmc_step.restype = C.c_int
     lib.oracle_hmc_step.argtypes = [C.POINTER(ONet), fp, fp, fp, fp, C.c_long, C.c_float, C.c_int, fp, C.c_float,
                                     dp, dp, dp]
+    lib.oracle_hmc_propose.restype = None
+    lib.oracle_hmc_propose.argtypes = [C.POINTER(ONet), fp, fp, fp, fp, C.c_long, C.c_float, C.c_int, fp, fp, dp, dp, dp]
     lib.oracle_num_threads.restype = C.c_int
+    lib.oracle_set_threads.restype = None
+    lib.oracle_set_threads.argtypes = [C.c_int]
     return lib
 
 
@@ -53,6 +57,10 @@ class COracle:
         self.P = spec.n_params
         self.threads = self.lib.oracle_num_threads()
 
+    def set_threads(self, n):
+        self.lib.oracle_set_threads(int(n))
+        self.threads = self.lib.oracle_num_threads()
+
     def logp_grad(self, theta, eta):
         th = np.ascontiguousarray(theta, dtype=np.float32)
         et = np.ascontiguousarray(eta, dtype=np.float32)
@@ -70,3 +78,14 @@ class COracle:
         acc = self.lib.oracle_hmc_step(C.byref(self.net), _p(th), _p(et), _p(self.X), _p(self.Y), self.n,
                                        float(eps), int(L), _p(p), float(log_u), C.byref(lar), C.byref(lo), C.byref(ln))
         return th, bool(acc), lar.value, lo.value, ln.value
+
+    def hmc_propose(self, theta, eta, eps, L, p0):
+        """(proposal q_L, log accept ratio, logp at theta, logp at q_L): the transition without the Metropolis decision"""
+        th = np.ascontiguousarray(theta, dtype=np.float32)
+        et = np.ascontiguousarray(eta, dtype=np.float32)
+        p = np.ascontiguousarray(p0, dtype=np.float32)
+        q = np.empty(self.P, dtype=np.float32)
+        lar, lo, ln = C.c_double(), C.c_double(), C.c_double()
+        self.lib.oracle_hmc_propose(C.byref(self.net), _p(th), _p(et), _p(self.X), _p(self.Y), self.n, float(eps), int(L),
+                                    _p(p), _p(q), C.byref(lar), C.byref(lo), C.byref(ln))
+        return q, lar.value, lo.value, ln.value

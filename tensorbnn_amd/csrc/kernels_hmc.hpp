@@ -283,6 +283,11 @@ __global__ void k_commit_scal(Scal* __restrict__ sc, Scal* __restrict__ host_cop
     if (sc->accepted) { sc->stat_cur = sc->stat_new; sc->prior_cur = sc->prior_new; sc->logp_cur = sc->logp_new; }
 }
 
+// trace slot 0 of a transition that starts from a cached (logp, grad): the chain's own record
+__global__ void k_trace_logp_cur(const Scal* __restrict__ sc, double* __restrict__ slot) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *slot = sc->logp_cur;
+}
+
 // debug: the chain RNG as tbnn_hmc_step draws it
 __global__ void k_debug_draw(uint32_t epoch, uint32_t purpose, uint32_t key0, uint32_t key1, int n,
                              float* __restrict__ normals, float* __restrict__ logu) {

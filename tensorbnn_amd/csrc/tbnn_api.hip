@@ -17,15 +17,6 @@
 #include "kernels_hmc.hpp"
 #include "kernels_hyper.hpp"
 #include "kernels_fast.hpp"
-// kernels_fast2.hpp (two waves per SIMD, a measured negative result) is only built on request: it needs the
-// AGPR-form build (no -amdgpu-mfma-vgpr-form, -DTBNN_ACC_AGPR=0) to fit its 256-register budget
-#ifdef TBNN_WITH_FAST2
-#include "kernels_fast2.hpp"
-#else
-static inline bool fast2_available(int) { return false; }
-template <class... A> static inline int fast2_launch(A...) { return -1; }
-__device__ unsigned long long g_ring_wait_cycles[2];
-#endif
 #include "kernels_fast3.hpp"
 #include "wide_api.hpp"
 #include "fused_ops.hpp"
@@ -59,7 +50,7 @@ struct tbnn_ctx {
     uint32_t key0 = 0, key1 = 0, epoch = 0;
     int kernel = TBNN_KERNEL_GENERIC;     // resolved variant
     int fast_id = -1;
-    int fast_ver = 1;                     // 1: kernels_fast.hpp, 2: two waves per SIMD (experimental), 3: fringe units on the VALU
+    int fast_ver = 1;                     // 1: kernels_fast.hpp, 3: kernels_fast3.hpp (fringe units off the 16x16 tiles)
     std::string kernel_name;
     // data
     float* dX = nullptr; float* dY = nullptr; bool own_data = false; long n = 0;
@@ -87,7 +78,8 @@ struct tbnn_ctx {
     Scal* sc = nullptr; Scal* sc_host = nullptr; Scal* sc_out = nullptr;   // sc_out: device copy for host
     double* trace = nullptr; int trace_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int profile = 0; long launch_no = 0; std::vector<hipEvent_t> pev;   // profile: event pair around every profile-th fwd+bwd launch
+    int profile = 0; long launch_no = 0;   // profile: event pair around every profile-th fwd+bwd launch
+    std::vector<hipEvent_t> pev; size_t pev_used = 0;   // pooled events: created once, re-used after every drain (no allocator in the timed loop)
     // hyper workspace
     float* hyp_ws = nullptr;
 };
@@ -233,7 +225,8 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
     HIPB(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     const size_t PB = (size_t)nd.P * sizeof(float);
     HIPB(hipMalloc(&h->q_cur, PB)); HIPB(hipMalloc(&h->g_cur, PB)); HIPB(hipMalloc(&h->q, PB));
-    HIPB(hipMalloc(&h->p, PB)); HIPB(hipMalloc(&h->g, PB)); HIPB(hipMalloc(&h->p0_inj, PB));
+    HIPB(hipMalloc(&h->p, PB)); HIPB(hipMalloc(&h->g, PB));
+    HIPB(hipMalloc(&h->p0_inj, (size_t)std::max(nd.P, nd.H) * sizeof(float)));   // injected momentum of either transition (H > P for tiny networks)
     HIPB(hipMalloc(&h->tmp, PB + (size_t)nd.H * sizeof(float)));
     HIPB(hipMalloc(&h->eta, (size_t)nd.H * sizeof(float)));
     HIPB(hipMalloc(&h->logu_inj, sizeof(float)));
@@ -282,13 +275,11 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
     }
     if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && fid >= 0) {
         h->kernel = TBNN_KERNEL_FAST; h->fast_id = fid; h->kernel_name = fast_name(fid);
-        // experimental two-waves-per-SIMD variant (kernels_fast2.hpp): measured equal to v1, off by default
-        {   // TBNN_FAST_VER=1|2|3 selects the variant (default: 3 where available)
+        {   // TBNN_FAST_VER=1|3 selects the variant (default: 3 where available)
             const char* ve = getenv("TBNN_FAST_VER");
             int want = ve ? atoi(ve) : 3;
-            if (want == 3 && !fast3_available(fid)) want = 1;
-            if (want == 2 && !fast2_available(fid)) want = 1;
-            h->fast_ver = (want >= 1 && want <= 3) ? want : 1;
+            if (want != 3 || !fast3_available(fid)) want = 1;
+            h->fast_ver = want;
         }
         if (h->fast_ver != 1) h->kernel_name = std::string("fast") + char('0' + h->fast_ver) + (h->kernel_name.c_str() + 4);
         h->img_floats = fast_image_floats(fid);
@@ -312,7 +303,15 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
 extern "C" int tbnn_param_count(tbnn_handle h) { NEED(h); return h->nd.P; }
 extern "C" int tbnn_hyper_count(tbnn_handle h) { NEED(h); return h->nd.H; }
 extern "C" const char* tbnn_kernel_name(tbnn_handle h) { return h ? h->kernel_name.c_str() : ""; }
-extern "C" int tbnn_set_profiling(tbnn_handle h, int stride) { NEED(h); h->profile = stride > 0 ? stride : 0; return 0; }
+extern "C" int tbnn_set_profiling(tbnn_handle h, int stride) {
+    NEED(h);
+    h->profile = stride > 0 ? stride : 0;
+    if (h->profile) {                       // fill the event pool now, outside any timed loop
+        HIPCHK(hipSetDevice(h->device));
+        while (h->pev.size() < 128) { hipEvent_t e = nullptr; HIPCHK(hipEventCreate(&e)); h->pev.push_back(e); }
+    }
+    return 0;
+}
 extern "C" int tbnn_set_epoch(tbnn_handle h, uint32_t epoch) { NEED(h); h->epoch = epoch; return 0; }
 
 // (re)allocate the fused-pass workspace for n rows
@@ -432,7 +431,17 @@ struct RcclApi {
 static RcclApi g_rccl;
 static int rccl_load() {
     if (g_rccl.lib) return 0;
-    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // TBNN_RCCL_LIB: explicit collective library (tests run the N > 1 paths on a 1-GPU box against tests/stubccl).
+    // Otherwise an RCCL the process has already loaded (torch ships its own copy) is re-used before a second copy
+    // is brought in: two RCCL instances in one process would each run their own bootstrap / proxy threads.
+    void* lib = nullptr;
+    if (const char* ov = getenv("TBNN_RCCL_LIB")) {
+        lib = dlopen(ov, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return fail(-5, std::string("TBNN_RCCL_LIB=") + ov + ": " + dlerror());
+    }
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) return fail(-5, std::string("cannot load librccl.so: ") + dlerror());
@@ -538,7 +547,10 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
     hipEvent_t a = nullptr, b = nullptr;
     const bool prof = h->profile > 0 && (h->launch_no++ % h->profile) == 0;
     if (prof) {
-        hipEventCreate(&a); hipEventCreate(&b); h->pev.push_back(a); h->pev.push_back(b);
+        if (h->pev_used + 2 > h->pev.size()) {
+            hipEventCreate(&a); hipEventCreate(&b); h->pev.push_back(a); h->pev.push_back(b);
+        }
+        a = h->pev[h->pev_used]; b = h->pev[h->pev_used + 1]; h->pev_used += 2;
         hipEventRecord(a, h->stream);
     }
     if (h->wide_id >= 0) {
@@ -550,7 +562,6 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
             return fail(-2, "registered kernel launch failed");
     } else if (h->kernel == TBNN_KERNEL_FAST) {
         int rc = h->fast_ver == 3 ? fast3_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat)
-               : h->fast_ver == 2 ? fast2_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat)
                                   : fast_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat);
         if (rc) return fail(-2, "fast kernel launch failed");
     } else {
@@ -596,12 +607,11 @@ static int ensure_current(tbnn_ctx* h, double* slot) {
 // mean duration (us) of the profiled fwd+bwd launches since the last drain
 static float drain_profile(tbnn_ctx* h) {
     double tot = 0.0; int cnt = 0;
-    for (size_t i = 0; i + 1 < h->pev.size(); i += 2) {
+    for (size_t i = 0; i + 1 < h->pev_used; i += 2) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->pev[i], h->pev[i + 1]) == hipSuccess) { tot += ms * 1000.0; ++cnt; }
     }
-    for (auto e : h->pev) hipEventDestroy(e);
-    h->pev.clear();
+    h->pev_used = 0;                      // the events stay in the pool
     return cnt ? (float)(tot / cnt) : 0.f;
 }
 
@@ -842,9 +852,13 @@ extern "C" int tbnn_metrics(tbnn_handle h, int which, const float* theta, float 
 static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, const float* d_logu, double* d_trace,
                               Scal* d_out) {
     const NetDev& nd = h->nd;
-    int rc = ensure_current(h, nullptr);
+    // logp0 of the trace: a fresh bootstrap evaluation writes it; a cached one (cur_valid) is copied from the chain's
+    // scalar record -- h->pstat then holds the statistic of the LAST fused launch (a rejected proposal, a
+    // tbnn_logp_grad probe), not of q_cur, so EN_CUR must not be re-derived from it
+    const bool cached = h->cur_valid;
+    int rc = ensure_current(h, d_trace);
     if (rc) return rc;
-    if (d_trace) launch_energy(h, EN_CUR, h->eta, h->q_cur, d_trace);   // re-derives logp0 from the cached stat
+    if (d_trace && cached) hipLaunchKernelGGL(k_trace_logp_cur, dim3(1), dim3(64), 0, h->stream, (const Scal*)h->sc, d_trace);
     hipLaunchKernelGGL(k_begin, dim3(1), dim3(1024), 0, h->stream, nd, d_p0, d_logu, h->epoch, h->key0, h->key1, h->p, h->sc);
     launch_update(h, UPD_FIRST, eps, h->eta, h->q, h->g);
     for (int t = 1; t <= L; ++t) {
@@ -1018,16 +1032,13 @@ extern "C" int tbnn_debug_stamps(tbnn_handle h, uint64_t* out5) {
     unsigned long long* d = nullptr;
     HIPCHK(hipMalloc(&d, 16 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(d, 0, 16 * sizeof(unsigned long long)));
-    { unsigned long long z[2] = {0, 0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_ring_wait_cycles), z, sizeof(z))); }
     hipLaunchKernelGGL(k_make_image, dim3((h->nd.P + 255) / 256), dim3(256), 0, h->stream, h->nd.P, h->q_cur, h->imgmap, h->qimg_cur);
     for (int rep = 0; rep < 3; ++rep) {
         if (h->fast_ver == 3) fast3_launch(h->fast_id, h->grid, h->stream, h->nd, h->qimg_cur, h->eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, d);
-        else if (h->fast_ver == 2) fast2_launch(h->fast_id, h->grid, h->stream, h->nd, h->qimg_cur, h->eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, d);
         else fast_launch(h->fast_id, h->grid, h->stream, h->nd, h->qimg_cur, h->eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, d);
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out5, d, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (h->fast_ver == 2) HIPCHK(hipMemcpyFromSymbol(out5 + 5, HIP_SYMBOL(g_ring_wait_cycles), 2 * sizeof(uint64_t)));
     hipFree(d);
     return 0;
 }

@@ -90,10 +90,18 @@ def source(dims, hact, lact, bern, family) -> str:
             f'extern "C" int tbnn_jit_ops(FusedOps* o) {{ JitNarrow<S, {f3}>::fill(o); return 0; }}\n')
 
 
+def _warn_generic(dims, why):
+    print(f"tensorbnn_amd: WARNING: network {dims} runs on the GENERIC thread-per-row kernel (~1 % of the MFMA roofline): "
+          f"{why}", file=sys.stderr, flush=True)
+
+
 def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Optional[str]:
-    """path of the compiled kernel library for this network, or None (generic kernel)"""
+    """path of the compiled kernel library for this network, or None (generic kernel, with a warning)"""
+    import fcntl
     sh = shape_of(layers, likelihood)
     if sh is None:
+        _warn_generic([int(layers[0][0])] + [int(l[1]) for l in layers],
+                      "the fused kernels need >= 2 dense layers with one activation for all hidden layers")
         return None
     dims, hact, lact, bern = sh
     key = hashlib.sha1(f"{dims}|{hact}|{lact}|{bern}|{_sources_stamp()}".encode()).hexdigest()[:20]
@@ -101,33 +109,61 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
     so, failed = os.path.join(d, f"tbnn_{key}.so"), os.path.join(d, f"tbnn_{key}.fail")
     if os.path.exists(so):
         return so
-    if os.path.exists(failed):
-        return None
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
-        return None                      # no compiler on this machine: generic kernel (not remembered as a failure)
-    print(f"tensorbnn_amd: compiling MFMA kernels for network {dims} (once; cached in {d})", file=sys.stderr, flush=True)
-    log = []
-    for fam in families(dims):
-        src = os.path.join(d, f"tbnn_{key}_{fam}.hip")
-        with open(src, "w") as f:
-            f.write(source(dims, hact, lact, bern, fam))
-        tmp = so + f".{os.getpid()}.tmp"
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
-        cmd += NARROW_FLAGS              # as build.py compiles the kernels (VGPR-form chain MFMAs)
-        cmd += ["-o", tmp, src]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)      # a child process: never an exec of this one
-        if r.returncode == 0:
-            os.replace(tmp, so)
-            return so
-        log.append(f"[{fam}] {r.stderr[-2000:]}")
-        if os.path.exists(tmp):
-            os.remove(tmp)
-    with open(failed, "w") as f:
-        f.write("\n".join(log) if log else "no kernel family applies to this shape\n")
-    return None
+        _warn_generic(dims, f"no ahead-of-time kernel covers this shape and {hipcc} is not present to instantiate one")
+        return None                      # no compiler on this machine: not remembered as a failure
+    # one builder per shape: the ranks of a node all reach this point together (Chain.__init__ on every rank); the
+    # first takes the lock and compiles, the others wait and pick the finished library up
+    with open(os.path.join(d, f"tbnn_{key}.lock"), "w") as lockf:
+        fcntl.flock(lockf, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(so):
+                return so
+            if os.path.exists(failed):
+                _warn_generic(dims, f"no kernel family compiles for this shape (diagnostics: {failed})")
+                return None
+            print(f"tensorbnn_amd: compiling MFMA kernels for network {dims} (once; cached in {d})", file=sys.stderr, flush=True)
+            log, deterministic = [], True
+            for fam in families(dims):
+                # per-process file names: nothing another process may be reading is ever truncated
+                src = os.path.join(d, f"tbnn_{key}_{fam}.{os.getpid()}.hip")
+                tmp = so + f".{os.getpid()}.tmp"
+                with open(src, "w") as f:
+                    f.write(source(dims, hact, lact, bern, fam))
+                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
+                cmd += NARROW_FLAGS              # as build.py compiles the kernels (VGPR-form chain MFMAs)
+                cmd += ["-o", tmp, src]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                try:
+                    r = subprocess.run(cmd, capture_output=True, text=True)      # a child process: never an exec of this one
+                    rc, err = r.returncode, r.stderr
+                except OSError as e:
+                    rc, err = -1, str(e)
+                for f_ in (src,):
+                    if os.path.exists(f_):
+                        os.remove(f_)
+                if rc == 0:
+                    os.replace(tmp, so)
+                    return so
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                # a compiler diagnostic ("error:") with a normal exit status is a property of the shape; anything else
+                # (killed, out of disk, exec failure) is transient and must not be remembered
+                if rc < 0 or "error:" not in err:
+                    deterministic = False
+                log.append(f"[{fam}] rc={rc}\n{err[-2000:]}")
+            if deterministic:
+                with open(failed + f".{os.getpid()}", "w") as f:
+                    f.write(f"sources {_sources_stamp()}\n" + ("\n".join(log) if log else "no kernel family applies to this shape\n"))
+                os.replace(failed + f".{os.getpid()}", failed)
+                _warn_generic(dims, f"no kernel family compiles for this shape (diagnostics: {failed})")
+            else:
+                _warn_generic(dims, "the kernel build failed for a transient reason (not cached; it is retried next time):\n" + "\n".join(log)[-1500:])
+            return None
+        finally:
+            fcntl.flock(lockf, fcntl.LOCK_UN)
 
 
 def ensure_registered(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> bool:

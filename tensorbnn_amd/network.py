@@ -17,6 +17,33 @@ from .metrics import Accuracy, PercentError, SquaredError
 from .paramAdapter import paramAdapter
 
 
+class DualAveraging(object):
+    """The hyper step-size adaptation of InnerStepHyper (network.py:457-469) with setupMCMC's constants
+    (network.py:241-248): float32 arithmetic, target 0.95, gamma 0.4, t0 10, kappa 0.75, mu = log(100 eps0) and the
+    exp(logEpsilonBar) applied while m < 0.8 burnin (Q6).  `network` runs one per chain; bench.py drives configs[4]'s
+    hyper transition with the same object."""
+
+    def __init__(self, hyperStepSize, burnin):
+        f = np.float32
+        self.target, self.gamma, self.t0, self.kappa = f(0.95), f(0.4), f(10), f(0.75)
+        self.h, self.logEpsilonBar = f(0), f(0)
+        self.mu = f(np.log(f(100 * hyperStepSize)))                          # :248
+        self.burnin = burnin
+        self.step_size = f(hyperStepSize)
+
+    def update(self, epoch, log_accept_ratio):
+        """epoch = iter_ before the increment; returns the acceptance probability it used (:459-460)"""
+        f = np.float32
+        m = f(epoch) + f(1)
+        accept = f(np.exp(f(log_accept_ratio))) if log_accept_ratio < 0 else f(1)
+        self.h = (f(1) - f(1) / (m + self.t0)) * self.h + (f(1) / (m + self.t0)) * (self.target - accept)
+        logEpsilon = self.mu - self.h * (m ** f(0.5)) / self.gamma
+        self.logEpsilonBar = (f(1) - m ** (-self.kappa)) * self.logEpsilonBar + m ** (-self.kappa) * logEpsilon
+        if m < f(self.burnin * 0.8):
+            self.step_size = f(np.exp(self.logEpsilonBar))
+        return accept
+
+
 class network(object):
     def __init__(self, dtype, inputDims, trainX, trainY, validateX, validateY, device=0, chain_id=0, seed=50,
                  kernel=nat.KERNEL_AUTO):
@@ -37,6 +64,7 @@ class network(object):
         self.device, self.chain_id, self.seed, self.kernel = device, chain_id, seed, kernel
         self._chain = None
         self._dense = []          # descriptors (in, out, act, prior)
+        self._lik_hypers = 0      # likelihood hyper entries at the tail of hyperStates (appended by train, once)
 
     # ------------------------------------------------------------------ model
     def add(self, layer, parameters=None):
@@ -57,6 +85,8 @@ class network(object):
         if layer.numHyperTensors > 0:
             for row in np.asarray(layer.hypers, dtype=np.float32):          # :189-191: one [1]-tensor per row
                 self.hyperStates.append(np.asarray(row, dtype=np.float32).reshape(1))
+        if self._chain is not None:       # the architecture changed: the old chain's device buffers go now, not at GC time
+            self._chain.close()
         self._chain = None
 
     def _theta(self):
@@ -138,28 +168,20 @@ class network(object):
         self.leapfrog = np.int32(leapfrogStart)
         self.cores = cores
         self.burnin = burnin
-        self.target = np.float32(0.95)                    # :241
-        self.gamma = np.float32(0.4)                      # :243
-        self.t0 = np.float32(10)
-        self.kappa = np.float32(0.75)
-        self.h = np.float32(0)
-        self.logEpsilonBar = np.float32(0)
-        self.mu = np.float32(np.log(np.float32(100 * hyperStepSize)))      # :248
+        self._da = DualAveraging(hyperStepSize, burnin)   # :241-248
         self.dualAveraging = dualAveraging
-        self.hyper_step_size = np.float32(hyperStepSize)
         self.hyperLeapfrog = hyperLeapfrog
+
+    # the reference keeps these scalars on the network object (network.py:241-248)
+    hyper_step_size = property(lambda self: self._da.step_size)
+    h = property(lambda self: self._da.h)
+    logEpsilonBar = property(lambda self: self._da.logEpsilonBar)
+    target = property(lambda self: self._da.target)
+    mu = property(lambda self: self._da.mu)
 
     def _dual_averaging(self, epoch, log_accept_ratio):
         """network.py:457-469 (epoch = iter_ before the increment)."""
-        f = np.float32
-        m = f(epoch) + f(1)
-        accept = f(np.exp(f(log_accept_ratio))) if log_accept_ratio < 0 else f(1)
-        self.h = (f(1) - f(1) / (m + self.t0)) * self.h + (f(1) / (m + self.t0)) * (self.target - accept)
-        logEpsilon = self.mu - self.h * (m ** f(0.5)) / self.gamma
-        self.logEpsilonBar = (f(1) - m ** (-self.kappa)) * self.logEpsilonBar + m ** (-self.kappa) * logEpsilon
-        if m < f(self.burnin * 0.8):
-            self.hyper_step_size = f(np.exp(self.logEpsilonBar))
-        return accept
+        return self._da.update(epoch, log_accept_ratio)
 
     def train(self, epochs, samplingStep, likelihood, metricList=[], adjustHypers=True, scaleExp=False,
               folderName=None, networksPerFile=1000, displaySkip=1, verbose=True, gather=None):
@@ -171,9 +193,16 @@ class network(object):
         self.makeResponseLikelihood = likelihood.makeResponseLikelihood
         self.metricList = metricList
         self.adjustHypers = adjustHypers
-        for val in likelihood.hypers:                                        # :542-543
+        # :542-543 appends the likelihood's hypers on EVERY call, so a second train() (a continued run) hands H+1 values
+        # to the sampler; here they are appended once and replaced when the likelihood changes
+        if self._lik_hypers:
+            del self.hyperStates[-self._lik_hypers:]
+        for val in likelihood.hypers:
             self.hyperStates.append(np.asarray(val, dtype=np.float32).reshape(1))
+        self._lik_hypers = len(likelihood.hypers)
         ch = self._ensure_chain(likelihood)
+        if verbose:
+            print("tensorbnn_amd: fused kernel", ch.kernel_name)
         ch.set_state(self._theta())
         ch.set_hypers(np.concatenate(self.hyperStates) if self.hyperStates else np.zeros(0, np.float32))
 

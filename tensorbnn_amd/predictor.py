@@ -96,6 +96,7 @@ class predictor(object):
         if self._chain is None:
             self._chain = nat.Chain(self._descriptor(), likelihood=nat.LIK_FIXED_GAUSSIAN, fixed_sd=1.0,
                                     device=self.device)
+            print("tensorbnn_amd: forward kernel", self._chain.kernel_name)    # once; Chain warns when it is the generic one
         x = np.asarray(inputMatrix, dtype=np.float32)
         # one native call for the whole ensemble (tbnn_forward_many): the rows are staged once, narrow networks run
         # as one batched launch of the forward-only MFMA kernel

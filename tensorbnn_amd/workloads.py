@@ -6,6 +6,8 @@ Y = teacher(X) + N(0, 0.1^2) PCG64(5678), standardised; classification
 Y ~ Bernoulli(sigmoid(teacher logits)).  Initial chain state N(0, sqrt(2/out))
 (reference layer.py:253-262) from PCG64(1000*(layer+1)) (+1 for biases).
 """
+import os
+
 import numpy as np
 
 from . import _native as nat
@@ -21,6 +23,36 @@ _BENCH_EPS = {"c2": (2.0e-5, 8.0e-5),
 
 def bench_eps(cfg: str):
     return _BENCH_EPS[cfg]
+
+
+# BASELINE.json configs as workloads: c1 = configs[0] (plumbing), c2 = configs[1] (the metric's config; configs[2] is c2
+# on every GPU), c4 = configs[3], c5 = configs[4].  steps / warmup: bench.py's defaults per workload.
+WORKLOADS = {
+    "c1": dict(dims=[1, 10, 10, 1], n=1_000, L=100, lik=nat.LIK_GAUSSIAN, hyper=False, steps=100, warmup=10,
+               text="BASELINE configs[0]: 1->10->10->1 Relu BNN (Cauchy DenseLayer, GaussianLikelihood sd=0.1), "
+                    "1k-row fp32 synthetic regression, L=100 leapfrog, 1 chain (launch-latency-bound plumbing case)"),
+    "c2": dict(dims=[5, 50, 50, 50, 1], n=100_000, L=50, lik=nat.LIK_GAUSSIAN, hyper=False, steps=200, warmup=20,
+               text="BASELINE configs[1]: 5->50->50->50->1 Relu BNN (Cauchy DenseLayer, GaussianLikelihood sd=0.1), "
+                    "100k-row fp32 synthetic regression, L=50 leapfrog, 1 chain per GPU"),
+    "c4": dict(dims=[10, 200, 200, 200, 1], n=1_000_000, L=100, lik=nat.LIK_GAUSSIAN, hyper=False, steps=10, warmup=2,
+               text="BASELINE configs[3]: 10->200->200->200->1 Relu BNN (Cauchy DenseLayer, GaussianLikelihood sd=0.1), "
+                    "1M-row fp32 synthetic regression, L=100 leapfrog, 1 chain per GPU"),
+    "c5": dict(dims=[20, 100, 100, 2], n=500_000, L=50, lik=nat.LIK_BERNOULLI, hyper=True, steps=40, warmup=5,
+               text="BASELINE configs[4]: 20->100->100->2 Relu/Sigmoid BNN (Cauchy DenseLayer, BernoulliLikelihood), "
+                    "500k-row fp32 synthetic classification, L=50 leapfrog + hyper-HMC (L_h=100, dual averaging) per epoch, "
+                    "1 chain per GPU"),
+}
+_GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def burned_state(cfg: str):
+    """the committed burned-in chain state of a config (tools/make_burned.py), or None: dict with theta, eta, eps, L,
+    accept and, for configs[4], the dual-averaging state of the hyper step size"""
+    path = os.path.join(_GOLDEN, f"{cfg}_burned.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    return {k: z[k] for k in z.files}
 
 
 def _act(z, a):

@@ -122,13 +122,17 @@ def test_bench_multi_rank_control_flow(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
            "--sampling-step", "3"]
-    env = dict(os.environ, TBNN_BENCH_SINGLE_GPU="1", OMP_NUM_THREADS="4")
+    # torch's collectives over gloo (two ranks on one GPU); the checkpoint gather is the native tbnn_gather_samples, its
+    # collective library pointed at the test stub (RCCL itself refuses two ranks on one device)
+    from test_gpu_multirank import build_stub
+    env = dict(os.environ, TBNN_BENCH_SINGLE_GPU="1", OMP_NUM_THREADS="4", TBNN_RCCL_LIB=build_stub())
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["chains"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["sample_gather"].startswith("tbnn_gather_samples") and "secondary" not in d
     assert d["value"] > 0 and d["roofline"]["frac"] > 0.05
 
 

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/<cfg>_burned.npz: a burned-in chain state per BASELINE config, from which bench.py starts its
+timed region and the free-running parity tests start their chains ("eps chosen once per config so that
+the mean accept probability is in [0.6, 0.9], recorded in the fixture metadata").
+
+  python tools/make_burned.py [c2 c4 c5 c1] [--out DIR]          (needs the GPU: the burn-in is thousands of epochs)
+
+Burn-in: the chain starts at workloads.synth_problem's initial state (log-prob ~ -2.7e7 at configs[1], where only
+eps <= 4e-5 is stable) and runs blocks of epochs at the config's L; after every block eps is multiplied by 1.25 when the
+block's mean accept probability exceeded 0.9 and by 0.8 when it fell below 0.6.  configs[4] runs the hyper transition
+(L_h = 100) after every weight transition with the reference's dual averaging (network.py:457-469).  Then eps is
+scanned from the burned state (every candidate restarts there; CHAIN RNG epoch offset per candidate) and the fixture
+keeps the largest candidate whose mean accept probability lies in [0.6, 0.9].
+Fixture: theta, eta, eps, L, accept (of the chosen eps), scan (eps, accept pairs), epochs, rng epoch counter, and for
+configs[4] the dual-averaging state (h, logEpsilonBar, step size, epoch index).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tensorbnn_amd import _native as nat                     # noqa: E402
+from tensorbnn_amd.network import DualAveraging              # noqa: E402
+from tensorbnn_amd.workloads import WORKLOADS, synth_problem  # noqa: E402
+
+PLAN = {   # blocks x epochs per block of burn-in, starting eps, scan candidates (multiples of the burn-in's final eps)
+    "c1": dict(blocks=60, per=50, eps0=1e-4),
+    "c2": dict(blocks=100, per=20, eps0=2e-5),
+    "c4": dict(blocks=24, per=5, eps0=1e-6),
+    "c5": dict(blocks=40, per=10, eps0=5e-5),
+}
+SCAN = (0.5, 0.63, 0.8, 1.0, 1.25, 1.6, 2.0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cfgs", nargs="*", default=["c2", "c5", "c4", "c1"])
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    for cfg in args.cfgs:
+        wl, plan = WORKLOADS[cfg], PLAN[cfg]
+        layers, lik, X, Y, theta0, eta0 = synth_problem(wl["dims"], wl["n"], likelihood=wl["lik"])
+        ch = nat.Chain(layers, likelihood=lik, device=0, seed=50, chain_id=0)
+        ch.set_data(X, Y); ch.set_state(theta0); ch.set_hypers(eta0)
+        L, eps = wl["L"], plan["eps0"]
+        hyper = wl["hyper"]
+        da = DualAveraging(1e-2, burnin=10 ** 9) if hyper else None         # setupMCMC default hyperStepSize, always adapting
+        ep = 0
+        for b in range(plan["blocks"]):
+            accs = []
+            for _ in range(plan["per"]):
+                accs.append(ch.hmc_step(eps, L)["accept_prob"])
+                if hyper:
+                    h = ch.hyper_step(float(da.step_size), 100)
+                    da.update(ep, h["log_accept_ratio"])
+                ep += 1
+            m = float(np.mean(accs))
+            if m > 0.9:
+                eps *= 1.25
+            elif m < 0.6:
+                eps *= 0.8
+            if b % 5 == 0 or b == plan["blocks"] - 1:
+                lp = ch.logp_grad()[0]
+                print(f"[{cfg}] block {b:3d} epoch {ep:5d} eps {eps:.3e} accept {m:.3f} logp {lp:.6e}"
+                      + (f" eps_h {float(da.step_size):.3e}" if hyper else ""), flush=True)
+        theta, eta = ch.get_state(), ch.get_hypers()
+        scan = []
+        n_scan = max(20, 2 * plan["per"])
+        for k, f in enumerate(SCAN):
+            ch.set_state(theta); ch.set_hypers(eta); ch.set_epoch(1_000_000 * (k + 1))
+            e = eps * f
+            a = float(np.mean([ch.hmc_step(e, L)["accept_prob"] for _ in range(n_scan)]))
+            scan.append((e, a))
+            print(f"[{cfg}] scan eps {e:.3e} -> accept {a:.3f}", flush=True)
+        ok = [(e, a) for e, a in scan if 0.6 <= a <= 0.9]
+        best = max(ok) if ok else min(scan, key=lambda t: abs(t[1] - 0.75))
+        meta = dict(cfg=cfg, dims=wl["dims"], rows=wl["n"], L=L, epochs=ep, eps=best[0], accept=best[1], scan=scan,
+                    kernel=ch.kernel_name)
+        out = dict(theta=theta, eta=eta, eps=np.float64(best[0]), L=np.int32(L), accept=np.float64(best[1]),
+                   scan=np.asarray(scan), epochs=np.int64(ep))
+        if hyper:
+            out.update(da_h=np.float32(da.h), da_logEpsilonBar=np.float32(da.logEpsilonBar), da_step=np.float32(da.step_size),
+                       da_epoch=np.int64(ep))
+            meta["hyper_step_size"] = float(da.step_size)
+        np.savez(os.path.join(args.out, f"{cfg}_burned.npz"), **out)
+        with open(os.path.join(args.out, f"{cfg}_burned.json"), "w") as f:
+            json.dump(meta, f, indent=1)
+        print(json.dumps(meta), flush=True)
+        ch.close()
+
+
+if __name__ == "__main__":
+    main()
