@@ -8,6 +8,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "_build", "libtbnn_oracle.so")
+MAX_THREADS = None
 
 
 class ONet(C.Structure):
@@ -30,6 +31,9 @@ def load():
     lib.oracle_num_threads.restype = C.c_int
     lib.oracle_set_threads.restype = None
     lib.oracle_set_threads.argtypes = [C.c_int]
+    global MAX_THREADS
+    if MAX_THREADS is None:
+        MAX_THREADS = lib.oracle_num_threads()       # before anyone calls oracle_set_threads (process-global in OpenMP)
     return lib
 
 
@@ -55,7 +59,10 @@ class COracle:
         self.Y = np.ascontiguousarray(Y, dtype=np.float32)
         self.n = self.X.shape[0]
         self.P = spec.n_params
-        self.threads = self.lib.oracle_num_threads()
+        self.max_threads = MAX_THREADS
+        # default: at most 32 threads (the GPU boxes show 256 logical CPUs but schedule a fraction of them: more threads
+        # than that ran 10x slower there); bench.py scans the count itself
+        self.set_threads(int(os.environ.get("TBNN_ORACLE_THREADS", min(MAX_THREADS, 32))))
 
     def set_threads(self, n):
         self.lib.oracle_set_threads(int(n))

@@ -106,16 +106,16 @@ def test_free_running_accept_ratio_parity_configs1(native):
             th_c = q_c
         out = ch.hmc_step(eps, L, p0=p0, log_u=lu)
         agree += int(bool(out["accepted"]) == (lu < lar_c))
-        dlar.append(abs(out["log_accept_ratio"] - lar_c))
+        dlar.append(abs(out["log_accept_ratio"] - lar_c) / (2e-2 + 1e-4 * abs(lar_c)))         # in units of the stated tolerance
         acc_g.append(out["accept_prob"]); acc_c.append(min(1.0, float(np.exp(min(lar_c, 0.0)))))
         if ep % 20 == 19:
             state_err.append(float(np.abs(ch.get_state() - th_c).max() / np.abs(th_c).max()))
     mg, mc = float(np.mean(acc_g)), float(np.mean(acc_c))
     print(f"free-running configs[1]: accept ratio HIP {mg:.4f} oracle/c {mc:.4f}; decision agreement {agree}/{EPOCHS}; "
-          f"max |dlar| {max(dlar):.3e}; relative state distance every 20 epochs {['%.1e' % s for s in state_err]}")
+          f"max |dlar| / (2e-2 + 1e-4 |lar|) {max(dlar):.3f}; relative state distance every 20 epochs {['%.1e' % s for s in state_err]}")
     assert abs(mg - mc) <= 0.02, (mg, mc)
     assert agree == EPOCHS, (agree, max(dlar))
-    assert max(dlar) <= 2e-2 + 1e-4 * 50, max(dlar)
+    assert max(dlar) <= 1.0, max(dlar)
     if os.path.exists(fx):
         assert 0.55 <= mc <= 0.95, mc              # the regime SURVEY 8(d) asks for
     ch.close()

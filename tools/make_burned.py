@@ -10,7 +10,8 @@ eps <= 4e-5 is stable) and runs blocks of epochs at the config's L; after every 
 block's mean accept probability exceeded 0.9 and by 0.8 when it fell below 0.6.  configs[4] runs the hyper transition
 (L_h = 100) after every weight transition with the reference's dual averaging (network.py:457-469).  Then eps is
 scanned from the burned state (every candidate restarts there; CHAIN RNG epoch offset per candidate) and the fixture
-keeps the largest candidate whose mean accept probability lies in [0.6, 0.9].
+keeps the candidate whose mean accept probability lies in [0.6, 0.9] and is closest to 0.8 (the stability cliff is
+sharp: at configs[1] 9.5e-5 gives 0.68 and 1.2e-4 gives 0.0, so the largest admissible candidate is not a safe choice).
 Fixture: theta, eta, eps, L, accept (of the chosen eps), scan (eps, accept pairs), epochs, rng epoch counter, and for
 configs[4] the dual-averaging state (h, logEpsilonBar, step size, epoch index).
 """
@@ -78,9 +79,10 @@ def main():
             scan.append((e, a))
             print(f"[{cfg}] scan eps {e:.3e} -> accept {a:.3f}", flush=True)
         ok = [(e, a) for e, a in scan if 0.6 <= a <= 0.9]
-        best = max(ok) if ok else min(scan, key=lambda t: abs(t[1] - 0.75))
+        best = min(ok, key=lambda t: (abs(t[1] - 0.8), -t[0])) if ok else min(scan, key=lambda t: abs(t[1] - 0.75))
         meta = dict(cfg=cfg, dims=wl["dims"], rows=wl["n"], L=L, epochs=ep, eps=best[0], accept=best[1], scan=scan,
-                    kernel=ch.kernel_name)
+                    kernel=ch.kernel_name,
+                    eps_rule="scan candidate with mean accept probability in [0.6, 0.9] closest to 0.8 (ties: the larger eps)")
         out = dict(theta=theta, eta=eta, eps=np.float64(best[0]), L=np.int32(L), accept=np.float64(best[1]),
                    scan=np.asarray(scan), epochs=np.int64(ep))
         if hyper:
