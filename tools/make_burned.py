@@ -33,6 +33,7 @@ PLAN = {   # blocks x epochs per block of burn-in, starting eps, scan candidates
     "c2": dict(blocks=100, per=20, eps0=2e-5),
     "c4": dict(blocks=24, per=5, eps0=1e-6),
     "c5": dict(blocks=40, per=10, eps0=5e-5),
+    "c5g": dict(blocks=40, per=10, eps0=5e-5),
 }
 SCAN = (0.5, 0.63, 0.8, 1.0, 1.25, 1.6, 2.0)
 
@@ -45,7 +46,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     for cfg in args.cfgs:
         wl, plan = WORKLOADS[cfg], PLAN[cfg]
-        layers, lik, X, Y, theta0, eta0 = synth_problem(wl["dims"], wl["n"], likelihood=wl["lik"])
+        layers, lik, X, Y, theta0, eta0 = synth_problem(wl["dims"], wl["n"], prior=wl["prior"], likelihood=wl["lik"])
         ch = nat.Chain(layers, likelihood=lik, device=0, seed=50, chain_id=0)
         ch.set_data(X, Y); ch.set_state(theta0); ch.set_hypers(eta0)
         L, eps = wl["L"], plan["eps0"]
