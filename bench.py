@@ -131,7 +131,7 @@ def cpu_baseline(name, wl, X, Y, theta, eta, eps, P):
                           "sample": f"{ep1} epoch x L={L1} on the first {n_one} rows, scaled by rows to {wl['n']}; {dt1:.1f} s"}}
     try:                                               # PyTorch-CPU value+grad (secondary cross-check)
         import torch_ref
-        tt = torch_ref.TorchTarget(spec, X, Y)
+        tt = torch_ref.TorchTarget(spec, X, Y, threads=best)     # (OpenMP's thread count is process-global: set it back)
         tt.value_and_grad(theta, eta)
         n_ev, t0 = 0, time.perf_counter()
         while n_ev < 20 and (n_ev == 0 or time.perf_counter() - t0 < 10.0):

@@ -679,6 +679,260 @@ struct FringeOut {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Cooperative tail.  The tile loop hands every wave whole 16-row tiles; n = 100,000 rows are 6250 tiles = 6 rounds of
+// 1024 waves + 106 tiles, and a 7th round with 106 of 1024 waves busy costs a full tile time (12 % of the row loop).
+// The left-over tiles (at most 2 per workgroup) are instead run by the FOUR waves of a workgroup together, the unit
+// dimension split over the waves: wave w owns M tile w of every hidden layer (the last wave the fringe units),
+//   forward   own tile of a_l = act(W_l[tile w] a_{l-1}) over the full K -> exchanged through LDS (1 KB per tile, one
+//             barrier), after which every wave holds all of a_l in the D layout exactly as the tile loop would;
+//   last layer, likelihood and delta_{L-1} (VALU, a few dozen instructions) redundantly on every wave;
+//   delta     own tile of delta_{l-1} = act' (W_l^T[tile w] delta_l), exchanged when another delta step follows;
+//   dW        wave w: the N tiles of its own M tile (A operand: its delta tile through its own transposed image),
+//             into a small separate accumulator set dWc that the epilogue adds to the wave's staged tiles; the fringe
+//             owner: the fringe rows (fdw); wave 0: the last layer's per-lane sums.
+// A wave issues ~90 MFMAs instead of ~350 and meets 4 barriers: ~0.4 of a tile time, for every workgroup at once.
+// Shapes with more than FAST_WAVES M tiles in a hidden layer (or no room for the 8.4-KB exchange buffers) keep the plain loop.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef TBNN_F3_COOP
+#define TBNN_F3_COOP 1
+#endif
+template <class S>
+struct Coop3 {
+    using C = F3Cfg<S>;
+    static constexpr int L = C::NL - 1;                                   // the all-fringe last layer
+    static constexpr int NFd = C::maxNF() > 0 ? C::maxNF() : 1;
+    static constexpr int HL = L > 0 ? L : 1;                              // hidden layers
+    static constexpr bool shape_ok() {
+        if (C::NL < 2 || !TBNN_F3_M4 || !TBNN_F3_FB) return false;
+        for (int l = 0; l < L; ++l) if (C::MT(l) > FAST_WAVES || C::MTF(l) < 1) return false;
+        return true;
+    }
+    static constexpr int XAF = FAST_WAVES * 256;                          // fringe values behind the 4 tiles of an exchange buffer
+    static constexpr int XB = XAF + 32;                                   // floats per exchange buffer; two alternate
+    static constexpr bool ENABLED = TBNN_F3_COOP && shape_ok() && ((size_t)C::LDS3_FLOATS + 2 * XB) * 4 + 64 <= 160 * 1024;
+    static constexpr int cwoff(int l) { int o = 0; for (int m = 0; m < l && m < C::NLM3; ++m) o += C::MTF(m) > 0 ? C::NT(m) : 0; return o; }
+    static constexpr int DWC = cwoff(C::NL) > 0 ? cwoff(C::NL) : 1;
+    static constexpr int FPd = C::FP_REGS > 0 ? C::FP_REGS : 1;
+
+    // the transposed image of layer l's output (input of layer l+1) for the dW MFMAs, as Fwd3::run writes it
+    template <int l>
+    static __device__ __forceinline__ void image(const Tile3<S>& T, float* wl, int i16, int g) {
+        if constexpr (l + 1 < C::NL && C::MTF(l + 1 < C::NL ? l + 1 : l) > 0) {
+            constexpr int u1 = C::in(l + 1);
+            float* aimg = wl + C::aoff3(l + 1);
+#pragma unroll
+            for (int mt = 0; mt < C::MT(l); ++mt) {
+                f32x4 v = T.a[C::aroff(l) + mt];
+                if constexpr (u1 % 16 != 0) {
+                    constexpr int osl = ones_slot(u1);
+                    if (mt == osl / 16 && g == (osl % 16) / 4) v[osl % 4] = 1.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) aimg[(16 * mt + 4 * g + r) * C::PR + i16] = v[r];
+            }
+        }
+    }
+
+    // hidden layer l: own tile, exchange, all tiles
+    template <int l>
+    static __device__ __forceinline__ void fwd(Tile3<S>& T, f32x4 (&own)[HL], const float* __restrict__ lds, float* wl, float* xch, int& xsel,
+                                                int wave, int lane, int i16, int g) {
+        constexpr int MT = C::MTF(l), NF = C::NF(l);
+        float* xb = xch + xsel * XB;
+        xsel ^= 1;
+        f32x4 mine = {0.f, 0.f, 0.f, 0.f};
+        if (wave < MT) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * wave + 4 * g);
+            if constexpr (l == 0) {
+#pragma unroll
+                for (int t = 0; t < C::KS0; ++t) acc = mfma16(lds[C::woff(0) + (16 * wave + i16) * C::LDW(0) + 4 * t + g], T.x0[t], acc);
+            } else {
+                const float* wrow = lds + C::woff(l) + (16 * wave + i16) * C::LDW(l) + 4 * g;
+#pragma unroll
+                for (int kt = 0; kt < C::KG(l); ++kt) {
+                    const f32x4 A = load_ks(wrow + 16 * kt, C::ksteps(C::in(l), kt));
+#pragma unroll
+                    for (int s = 0; s < C::ksteps(C::in(l), kt); ++s) acc = mfma16(A[s], T.a[C::aroff(l - 1) + kt][s], acc);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[r] = actc_fwd<S::act(l)>(acc[r]);
+            *reinterpret_cast<f32x4*>(xb + wave * 256 + lane * 4) = mine;
+        } else if (NF > 0 && wave == MT) {
+            const float* prow = lds + C::woff(l) + (16 * MT + 4 * (i16 & 3)) * C::LDW(l);
+            f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (l == 0) {
+#pragma unroll
+                for (int t = 0; t < C::KS0; ++t) pacc = mfma4(prow[4 * t + g], T.x0[t], pacc);
+            } else {
+                pacc = fringe_partials<S, C::in(l)>(prow + 4 * g, &T.a[C::aroff(l > 0 ? l - 1 : 0)]);
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float a = actc_fwd<S::act(l)>(gsum_mfma(pacc[f]) + lds[C::boff(l) + C::fslot(l, f)]);
+                if (g == f) mine[0] = a;
+                if (g == 0) xb[XAF + 16 * f + i16] = a;
+            }
+            *reinterpret_cast<f32x4*>(xb + MT * 256 + lane * 4) = mine;
+        }
+        own[l] = mine;
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < C::MT(l); ++mt) T.a[C::aroff(l) + mt] = *reinterpret_cast<const f32x4*>(xb + mt * 256 + lane * 4);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) T.af[l][f] = xb[XAF + 16 * f + i16];
+        image<l>(T, wl, i16, g);
+        if constexpr (l + 1 < L) fwd<l + 1>(T, own, lds, wl, xch, xsel, wave, lane, i16, g);
+    }
+
+    // layer l backward: dW_l for the own M tile (own_dz: this wave's tile of delta_l; dzf: the fringe deltas, valid on the
+    // fringe owner), then the own tile of delta_{l-1} from ALL of delta_l (dz)
+    template <int l>
+    static __device__ __forceinline__ void bwd(f32x4 (&dWc)[DWC], float (&FP)[FPd], const Tile3<S>& T, const f32x4 (&own)[HL],
+                                                const float* __restrict__ lds, float* wl, float* xch, int& xsel, int wave, int lane, int i16, int g,
+                                                const f32x4 (&dz)[C::MT(l)], const f32x4 own_dz, const float (&dzf)[NFd]) {
+        constexpr int MT = C::MTF(l), NT = C::NT(l), NF = C::NF(l);
+        if constexpr (MT > 0) {
+            float* dimg = wl + C::doff3;
+            const float* aimg = wl + C::aoff3(l);
+            const bool fown = C::FB(l) && wave == MT;
+            if (wave < MT || fown) {
+                float Bop[NT][4];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(aimg + (16 * nt + i16) * C::PR + 4 * g);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) Bop[nt][s] = b[s];
+                }
+                if (wave < MT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dimg[(16 * wave + 4 * g + r) * C::PR + i16] = own_dz[r];
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(dimg + (16 * wave + i16) * C::PR + 4 * g);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) dWc[cwoff(l) + nt] = mfma16(a[s], Bop[nt][s], dWc[cwoff(l) + nt]);
+                } else {
+                    float* fd = wl + C::fdoff3 + 32 * g;
+                    float Fop[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if constexpr (NF == 2) {
+                        *reinterpret_cast<f32x2*>(fd + 2 * i16) = f32x2{dzf[0], dzf[NF > 1 ? 1 : 0]};
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(fd + 8 * g), v = *reinterpret_cast<const f32x4*>(fd + 8 * g + 4);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) { Fop[s] = u[s]; Fop[4 + s] = v[s]; }
+                    } else {
+                        fd[i16] = dzf[0];
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(fd + 4 * g);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) Fop[s] = u[s];
+                    }
+                    Bwd3<S, l>::fdw(FP, Fop, Bop);
+                }
+            }
+        }
+        if constexpr (NF > 0 && !C::FB(l)) {
+            if (wave == MT) FringeDW<S, l>::run(FP, T, dzf, g);
+        }
+        if constexpr (l > 0) {
+            constexpr int MTP = C::MTF(l - 1), NFP = C::NF(l - 1), K = C::out(l);
+            constexpr bool XCHG = l - 1 > 0;                              // delta_0 feeds no further delta step
+            float* xb = xch + xsel * XB;
+            if constexpr (XCHG) xsel ^= 1;
+            f32x4 odz = {0.f, 0.f, 0.f, 0.f};
+            float dzpf[NFd];
+#pragma unroll
+            for (int f = 0; f < NFd; ++f) dzpf[f] = 0.f;
+            if (wave < MTP) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* trow = lds + C::toff(l) + (16 * wave + i16) * C::LDT(l) + 4 * g;
+#pragma unroll
+                for (int kt = 0; kt < C::cdiv(K, 16); ++kt) {
+                    const f32x4 A = load_ks(trow + 16 * kt, C::ksteps(K, kt));
+#pragma unroll
+                    for (int s = 0; s < C::ksteps(K, kt); ++s) acc = mfma16(A[s], dz[kt][s], acc);
+                }
+                odz = actc_bwd_mul4<S::act(l - 1), false>(acc, own[l - 1]);
+                if constexpr (XCHG) *reinterpret_cast<f32x4*>(xb + wave * 256 + lane * 4) = odz;
+            } else if (NFP > 0 && wave == MTP) {
+                const f32x4 pacc = fringe_partials<S, K>(lds + C::toff(l) + (16 * MTP + 4 * (i16 & 3)) * C::LDT(l) + 4 * g, dz);
+#pragma unroll
+                for (int f = 0; f < NFP; ++f) {
+                    dzpf[f] = actc_bwd_mul<S::act(l - 1)>(gsum_mfma(pacc[f]), T.af[l - 1][f]);
+                    if (g == f) odz[0] = dzpf[f];
+                    if constexpr (XCHG) { if (g == 0) xb[XAF + 16 * f + i16] = dzpf[f]; }
+                }
+                if constexpr (XCHG) *reinterpret_cast<f32x4*>(xb + MTP * 256 + lane * 4) = odz;
+            }
+            f32x4 dzp[C::MT(l - 1)];
+#pragma unroll
+            for (int mt = 0; mt < C::MT(l - 1); ++mt) dzp[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (XCHG) {
+                __syncthreads();
+#pragma unroll
+                for (int mt = 0; mt < C::MT(l - 1); ++mt) dzp[mt] = *reinterpret_cast<const f32x4*>(xb + mt * 256 + lane * 4);
+#pragma unroll
+                for (int f = 0; f < NFP; ++f) dzpf[f] = xb[XAF + 16 * f + i16];
+            }
+            bwd<l - 1>(dWc, FP, T, own, lds, wl, xch, xsel, wave, lane, i16, g, dzp, odz, dzpf);
+        }
+    }
+
+    // one 16-row tile on the four waves of the workgroup (every wave holds the tile's x / y of row i16)
+    static __device__ __forceinline__ void tile(f32x4 (&dWc)[DWC], float (&FP)[FPd], double& stat, const float* __restrict__ lds, float* wl,
+                                                 float* xch, int wave, int lane, int i16, int g, float inv_var,
+                                                 const float (&x)[C::KS0], const float (&y)[C::out(C::NL - 1)], bool rvalid) {
+        constexpr int d_in = C::in(0), d_out = C::out(C::NL - 1);
+        Tile3<S> T;
+        f32x4 own[HL];
+        int xsel = 0;
+#pragma unroll
+        for (int t = 0; t < C::KS0; ++t) {
+            T.x0[t] = x[t];
+            const int u = 4 * t + g;
+            if (u < d_in) wl[C::aoff3(0) + u * C::PR + i16] = x[t];
+        }
+        fwd<0>(T, own, lds, wl, xch, xsel, wave, lane, i16, g);
+        {   // the all-fringe last layer: every wave (a dozen 4x4x1 MFMAs)
+            const f32x4 dA[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, dB[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+            Fwd3<S, L>::run(T, lds, wl, i16, g, dA, dB);
+        }
+        float dzf[NFd];
+#pragma unroll
+        for (int o = 0; o < NFd; ++o) dzf[o] = 0.f;
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) dzf[o] = rvalid ? lik_delta<S>(T.af[L][o], y[o], inv_var, g == 0 && wave == 0, stat) : 0.f;
+        if (wave == 0) FringeDW<S, L>::run(FP, T, dzf, g);
+        f32x4 dzL[C::MT(L)];
+#pragma unroll
+        for (int mt = 0; mt < C::MT(L); ++mt) dzL[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 dzp[C::MT(L - 1)];
+        float dzpf[NFd];
+#pragma unroll
+        for (int f = 0; f < NFd; ++f) dzpf[f] = 0.f;
+        Bwd3<S, L>::da(T, lds, i16, g, dzL, dzf, dzp, dzpf);             // delta_{L-1}: VALU, every tile on every wave
+        f32x4 odz = dzp[0];
+#pragma unroll
+        for (int mt = 1; mt < C::MTF(L - 1); ++mt) if (wave == mt) odz = dzp[mt];
+        bwd<L - 1>(dWc, FP, T, own, lds, wl, xch, xsel, wave, lane, i16, g, dzp, odz, dzpf);
+    }
+
+    // epilogue: add this wave's cooperative accumulators to its staged tiles [t0, t0 + cnt) (mine[t - t0][lane])
+    template <int l>
+    static __device__ __forceinline__ void merge(f32x4* mine, const f32x4 (&dWc)[DWC], int wave, int lane, int t0, int cnt) {
+        if constexpr (C::MTF(l) > 0) {
+            if (wave < C::MTF(l)) {
+#pragma unroll
+                for (int nt = 0; nt < C::NT(l); ++nt) {
+                    const int t = C::dwoff3(l) + wave * C::NT(l) + nt - t0;
+                    if (t >= 0 && t < cnt) mine[t * 64 + lane] += dWc[cwoff(l) + nt];
+                }
+            }
+        }
+        if constexpr (l + 1 < C::NLM3) merge<l + 1>(mine, dWc, wave, lane, t0, cnt);
+    }
+};
+
 template <class S>
 __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_fwd_bwd_fast3(
     NetDev nd, const float* __restrict__ qimg, const float* __restrict__ eta,

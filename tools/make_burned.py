@@ -72,7 +72,7 @@ def main():
                       + (f" eps_h {float(da.step_size):.3e}" if hyper else ""), flush=True)
         theta, eta = ch.get_state(), ch.get_hypers()
         scan = []
-        n_scan = max(20, 2 * plan["per"])
+        n_scan = max(40, 4 * plan["per"])        # the acceptance of a 20-epoch window is too noisy to rank step sizes
         for k, f in enumerate(SCAN):
             ch.set_state(theta); ch.set_hypers(eta); ch.set_epoch(1_000_000 * (k + 1))
             e = eps * f
