@@ -941,11 +941,13 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 {
     using C = F3Cfg<S>;
     static_assert(C::VL && C::NF(C::NL - 1) == C::out(C::NL - 1) && C::MTF(C::NL - 1) == 0, "fast3: last layer must be all-fringe");
-    static_assert(C::LDS3_FLOATS * 4 + 64 <= 160 * 1024, "LDS budget");
+    using CO = Coop3<S>;
+    static_assert((C::LDS3_FLOATS + (CO::ENABLED ? 2 * CO::XB : 4)) * 4 + 64 <= 160 * 1024, "LDS budget");
     static_assert((size_t)FAST_WAVES * C::FP_REGS * 64 <= (size_t)C::LDS3_FLOATS, "fringe staging does not fit");
 #define TB_STAMP(i) do { if (stamps && threadIdx.x == 0 && blockIdx.x == 0) { stamps[i] = wall_clock64(); stamps[8 + i] = clock64(); } } while (0)
     TB_STAMP(0);
     __shared__ __attribute__((aligned(16))) float lds[C::LDS3_FLOATS];
+    __shared__ __attribute__((aligned(16))) float xch[CO::ENABLED ? 2 * CO::XB : 4];     // cooperative tail: exchange buffers
     __shared__ double red[FAST_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
@@ -1002,10 +1004,33 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int o = 0; o < d_out; ++o) yn[o] = ok ? Y[row * d_out + o] : 0.f;
     };
+    // full rounds of W tiles run on the tile loop; a remainder of at most 2 tiles per workgroup runs as cooperative rounds
+    // (Coop3), tile = main_end + round * gridDim.x + blockIdx.x
+    long main_end = ntiles;
+    int ncoop = 0;
+    if constexpr (CO::ENABLED) {
+        const long G = gridDim.x, rem = ntiles % W;
+        if (rem > 0 && rem <= 2 * G) { main_end = ntiles - rem; ncoop = rem <= G ? 1 : 2; }
+    }
+    // the cooperative tiles' rows are fetched now: their latency hides under the whole tile loop
+    float xc[2][C::KS0], yc[2][d_out];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long ct = main_end + (long)j * gridDim.x + blockIdx.x;
+        const long row = ct * 16 + i16;
+        const bool ok = CO::ENABLED && j < ncoop && ct < ntiles && row < n;
+#pragma unroll
+        for (int t = 0; t < C::KS0; ++t) {
+            const int u = 4 * t + g;
+            xc[j][t] = (ok && u < d_in) ? X[row * d_in + u] : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) yc[j][o] = ok ? Y[row * d_out + o] : 0.f;
+    }
     long tile = wg;
     fetch(tile);
     bool first = true;
-    for (; tile < ntiles; tile += W) {
+    for (; tile < main_end; tile += W) {
         Tile3<S> T;
         float y[d_out];
         const bool rvalid = tile * 16 + i16 < n;
@@ -1055,6 +1080,23 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     }
     TB_STAMP(3);
     mfma_drain();
+    f32x4 dWc[CO::DWC];
+#pragma unroll
+    for (int t = 0; t < CO::DWC; ++t) dWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (CO::ENABLED) {
+#pragma unroll 1
+        for (int j = 0; j < ncoop; ++j) {                       // one copy of the body: the second round's rows by select
+            const long ct = main_end + (long)j * gridDim.x + blockIdx.x;
+            if (ct >= ntiles) break;                            // workgroup-uniform: the barriers inside are met by all 4 waves
+            float xj[C::KS0], yj[d_out];
+#pragma unroll
+            for (int t = 0; t < C::KS0; ++t) xj[t] = j == 0 ? xc[0][t] : xc[1][t];
+#pragma unroll
+            for (int o = 0; o < d_out; ++o) yj[o] = j == 0 ? yc[0][o] : yc[1][o];
+            CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xj, yj, ct * 16 + i16 < n);
+        }
+    }
+    TB_STAMP(5);
 
     // ---- epilogue
     const double wtot = wave_sum(stat);
@@ -1070,6 +1112,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::DW3_TILES * 64);
 #pragma unroll
         for (int t = 0; t < C::DW3_TILES; ++t) mine[t * 64 + lane] = dW[t];
+        if constexpr (CO::ENABLED) { if (ncoop > 0) CO::template merge<0>(mine, dWc, wave, lane, 0, C::DW3_TILES); }
 #pragma unroll
         for (int r = 0; r < C::FP_REGS; ++r) lb[((size_t)(wave * C::FP_REGS + r) * 4 + g) * 16 + i16] = FP[r];
         __syncthreads();
@@ -1083,8 +1126,9 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                 f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::EP3_TILES * 64);
 #pragma unroll
                 for (int t = t0; t < t0 + C::EP3_TILES && t < C::DW3_TILES; ++t) mine[(t - t0) * 64 + lane] = dW[t];
-                __syncthreads();
                 const int cnt = (C::DW3_TILES - t0) < C::EP3_TILES ? (C::DW3_TILES - t0) : C::EP3_TILES;
+                if constexpr (CO::ENABLED) { if (ncoop > 0) CO::template merge<0>(mine, dWc, wave, lane, t0, cnt); }
+                __syncthreads();
                 SlabOut3<S, 0>::run(lds, slab, wave, lane, t0, cnt);
             }
         }

@@ -331,6 +331,8 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
         HIPCHK(hipMalloc(&h->wslabB, h->wplan.slabB_floats * sizeof(float)));
     } else if (h->kernel == TBNN_KERNEL_FAST) {
         grid = h->jit ? h->jit->grid(n) : fast_grid(h->fast_id, n);
+        // test hook: a smaller grid puts small row counts into the many-rounds + cooperative-tail regime of the big ones
+        if (const char* ge = getenv("TBNN_FAST_GRID")) { const int gg = atoi(ge); if (gg >= 1 && gg < grid) grid = gg; }
         h->scratchPerWG = 0;
     } else {
         const long nblk = (n + GEN_RB - 1) / GEN_RB;

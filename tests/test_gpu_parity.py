@@ -110,6 +110,41 @@ def test_logp_grad_fast_ragged_rows(native, n):
     check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
 
 
+@pytest.mark.parametrize("dims,act,prior,lik,n,grid", [
+    ([5, 50, 50, 50, 1], o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, 2000, 10),     # 125 tiles = 3 rounds of 40 + 5: one cooperative round, half the workgroups idle
+    ([5, 50, 50, 50, 1], o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, 2000, 3),      # 10 rounds of 12 + 5: two cooperative rounds, the second with one dummy tile
+    ([5, 50, 50, 50, 1], o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, 1991, 10),     # the last cooperative tile is ragged (7 of 16 rows)
+    ([5, 50, 50, 50, 1], o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, 650, 10),      # 41 tiles = 1 round + 1 tile
+    ([5, 50, 50, 50, 1], o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, 2000, 5),      # 6 rounds of 20 + 5: every workgroup has a cooperative tile
+    ([1, 10, 10, 1], o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, 1000, 5),          # one M tile per layer: wave 0 alone works, the barriers still meet
+    ([1, 10, 10, 10, 1], o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_FIXED_GAUSSIAN, 700, 4),
+])
+def test_logp_grad_fast_cooperative_tail(native, monkeypatch, dims, act, prior, lik, n, grid):
+    """k_fwd_bwd_fast3's cooperative tail (Coop3: the left-over tiles of the last round on the 4 waves of a workgroup
+    together), forced at small row counts by a small grid (TBNN_FAST_GRID); full size: test_fast_vs_generic_full_size,
+    tests/test_gpu_fullsize.py.  Value, gradient and statistic against the fp64 oracle and the plain loop (a grid that
+    leaves no remainder)."""
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, act, prior, lik)
+    monkeypatch.setenv("TBNN_FAST_GRID", str(grid))
+    lp, g = check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+    monkeypatch.delenv("TBNN_FAST_GRID")
+    lp0, g0 = check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+    assert abs(lp - lp0) <= 1e-6 * abs(lp0)
+    assert np.abs(g - g0).max() <= 2e-5 * np.abs(g0).max()
+    # a transition through it: trace of log-probs and the decision
+    rng = np.random.default_rng(1)
+    p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+    monkeypatch.setenv("TBNN_FAST_GRID", str(grid))
+    ch = make_chain(native, spec, native.KERNEL_FAST)
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    eps = 2e-3 if lik == o.LIK_FIXED_GAUSSIAN else 5e-5
+    out = ch.hmc_step(eps, 4, p0=p0, log_u=float(np.log(0.5)), trace=True)
+    ref = o.weight_step(spec, theta, eta, X, Y, eps, 4, p0, float(np.log(0.5)), np.float64)
+    np.testing.assert_allclose(out["trace_logp"], ref.trace_logp, rtol=LOGP_RTOL, atol=2e-3)
+    assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-4 * abs(ref.log_accept_ratio)
+    ch.close()
+
+
 def test_fast_vs_generic_full_size(native):
     """BASELINE configs[1] at full size (n=1e5): MFMA kernel vs generic kernel vs fp64 oracle."""
     spec, X, Y, theta, eta = o.synth_problem([5, 50, 50, 50, 1], 100000)
