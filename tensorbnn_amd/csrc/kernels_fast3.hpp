@@ -1116,7 +1116,9 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int r = 0; r < C::FP_REGS; ++r) lb[((size_t)(wave * C::FP_REGS + r) * 4 + g) * 16 + i16] = FP[r];
         __syncthreads();
+        TB_STAMP(6);
         SlabOut3<S, 0>::run(lds, slab, wave, lane, 0, C::DW3_TILES);
+        TB_STAMP(7);
         FringeOut<S, 0>::run(lb, slab, tid);
     } else {
         if constexpr (C::DW3_TILES > 0) {

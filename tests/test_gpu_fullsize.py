@@ -165,8 +165,9 @@ def test_free_running_hyper_chain_full_parameter_count(native, prior):
             assert abs(eps_g - eps_o) <= 2e-2 * eps_o, (ep, eps_g, eps_o)
             ref = o.hyper_step(spec, e_o, theta, X, Y, eps_g, 100, p0, 1e30, np.float64)      # log u = +inf: the proposal only
             lar_o = ref.log_accept_ratio
-            if not (lar_o > -50.0):
-                # an unstable trajectory (the step of the moment is far too large: energy errors of 1e3 .. inf).  Its value
+            if not (abs(lar_o) < 50.0):
+                # an unstable trajectory (the step of the moment is far too large: energy errors of 1e2 .. inf, of either
+                # sign when it lands next to the pole of the improper Cauchy target).  Its value
                 # is not comparable digit by digit -- near the pole of the improper Cauchy target even its SIGN depends on
                 # the arithmetic: at epoch 40 of this very sequence the fp64 oracle gets -3.1e4, the fp32 oracle arm
                 # +3.8e3 and the HIP path +5.5e3 (a blown-up trajectory that lands next to the pole).  Both arms reject
@@ -187,7 +188,7 @@ def test_free_running_hyper_chain_full_parameter_count(native, prior):
                 n_acc += 1
             np.testing.assert_allclose(ch.get_hypers(), e_o, rtol=eta_rtol, atol=2e-6, err_msg=f"eta after epoch {ep}")
             # both arms adapt on their OWN log accept ratio (a blown-up trajectory counts as the rejection it was made)
-            accs.append(float(da_g.update(ep, out["log_accept_ratio"] if lar_o > -50.0 else lar_o)))
+            accs.append(float(da_g.update(ep, out["log_accept_ratio"] if abs(lar_o) < 50.0 else lar_o)))
             o.dual_averaging_update(da_o, ep, lar_o)
     print(f"hyper chain [{prior}]: accepted {n_acc}/100, mean accept prob {np.mean(accs):.3f} (last 50: {np.mean(accs[50:]):.3f}), "
           f"step size 1e-2 -> {float(da_g.step_size):.3e}, {blown} blown-up trajectories (both arms reject), max |dlar| of the "

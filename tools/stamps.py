@@ -14,5 +14,5 @@ for n in (16384, 98304, 100000, 114688):
     t = np.array(list(out)[:8], dtype=np.float64); d = (t - t[0]) * 0.01
     c = np.array(list(out)[8:16], dtype=np.float64)
     print(f"n {n}: prologue {d[1]:.2f} us, first tile end {d[2]:.2f}, tile loop end {d[3]:.2f}, cooperative tail end {d[5]:.2f}, "
-          f"end {d[4]:.2f}; shader clock over the launch {(c[4] - c[0]) / (d[4] + 1e-9):.0f} MHz")
+          f"staged {d[6]:.2f}, tile slabs out {d[7]:.2f}, end {d[4]:.2f}; shader clock over the launch {(c[4] - c[0]) / (d[4] + 1e-9):.0f} MHz")
     ch.close()
