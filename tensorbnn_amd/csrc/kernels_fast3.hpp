@@ -958,14 +958,20 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         const float4* src = reinterpret_cast<const float4*>(qimg);
         float4* dst = reinterpret_cast<float4*>(lds);
         float4 v[IT];
+        // every workgroup of the grid reads the same 78 KB at the same moment: start each one at a different 4-KB piece
+        // (rot), or the requests of a whole XCD queue on the L2 channels of one piece after the other
+#ifndef TBNN_F3_PROROT
+#define TBNN_F3_PROROT 1
+#endif
+        const int rot = TBNN_F3_PROROT ? (int)(blockIdx.x % IT) : 0;
 #pragma unroll
-        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; v[k] = e < N4 ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int k = 0; k < IT; ++k) { const int kk = k + rot < IT ? k + rot : k + rot - IT, e = tid + kk * FAST_THREADS; v[k] = e < N4 ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
         __builtin_amdgcn_sched_barrier(0);
         float4* z = reinterpret_cast<float4*>(wl);
         for (int e = lane; e < C::WAVE3_FLOATS / 4; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
+        for (int k = 0; k < IT; ++k) { const int kk = k + rot < IT ? k + rot : k + rot - IT, e = tid + kk * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
     }
     __syncthreads();
     TB_STAMP(1);

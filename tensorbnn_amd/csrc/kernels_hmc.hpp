@@ -55,6 +55,18 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int c4 = blockIdx.x * UPD_COLS + tx;          // float4 column
     const int j0 = c4 * 4;
+    // the finishing threads (ty < 4: one parameter each) fetch everything they need that does not depend on the reduced
+    // gradient BEFORE the slab loads: one memory round trip instead of two on the critical path of a leapfrog step
+    const int jf = j0 + ty;
+    const bool fin = ty < 4 && jf < nd.P;
+    float q_j = 0.f, p_j = 0.f, gc_j = 0.f, qc_j = 0.f, loc = 0.f, scale = 1.f;
+    int prior = 0, m0 = -1, m1 = -1;
+    if (fin) {
+        if (mode != UPD_FIRST) { prior_params(nd, eta, jf, prior, loc, scale); q_j = q[jf]; }
+        if (mode == UPD_FIRST) { gc_j = g_cur[jf]; qc_j = q_cur[jf]; }
+        if (mode != UPD_GRAD_ONLY) p_j = p[jf];
+        if (imgmap && (mode == UPD_FIRST || mode == UPD_MID)) { m0 = imgmap[jf]; m1 = imgmap[nd.P + jf]; }
+    }
     float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mode != UPD_FIRST) {
         float4 s0 = gs, s1 = gs, s2 = gs, s3 = gs;
@@ -95,29 +107,24 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
         gs = part[0][tx];
     }
     // ty selects which of the 4 parameters of the column this thread finishes
-    if (ty >= 4) return;
-    const int j = j0 + ty;
-    if (j >= nd.P) return;
+    if (!fin) return;
+    const int j = jf;
     float gj = ty == 0 ? gs.x : ty == 1 ? gs.y : ty == 2 ? gs.z : gs.w;
-    if (mode != UPD_FIRST) {
-        int prior; float loc, scale;
-        prior_params(nd, eta, j, prior, loc, scale);
-        gj += prior_grad(prior, loc, scale, q[j]);
-    }
+    if (mode != UPD_FIRST) gj += prior_grad(prior, loc, scale, q_j);
     if (mode == UPD_GRAD_ONLY) { g[j] = gj; return; }
     if (mode == UPD_FIRST) {
-        const float pj = p[j] + 0.5f * eps * g_cur[j];       // half kick
-        const float qj = q_cur[j] + eps * pj;                 // drift
+        const float pj = p_j + 0.5f * eps * gc_j;            // half kick
+        const float qj = qc_j + eps * pj;                     // drift
         p[j] = pj; q[j] = qj;
-        if (imgmap) { qimg[imgmap[j]] = qj; const int m1 = imgmap[nd.P + j]; if (m1 >= 0) qimg[m1] = qj; }
+        if (imgmap) { qimg[m0] = qj; if (m1 >= 0) qimg[m1] = qj; }
         return;
     }
-    float pj = p[j] + eps * gj;                               // full kick
+    float pj = p_j + eps * gj;                                // full kick
     g[j] = gj;
     if (mode == UPD_MID) {
-        const float qj = q[j] + eps * pj;                     // drift
+        const float qj = q_j + eps * pj;                      // drift
         p[j] = pj; q[j] = qj;
-        if (imgmap) { qimg[imgmap[j]] = qj; const int m1 = imgmap[nd.P + j]; if (m1 >= 0) qimg[m1] = qj; }
+        if (imgmap) { qimg[m0] = qj; if (m1 >= 0) qimg[m1] = qj; }
     } else {
         pj = pj - 0.5f * eps * gj;                            // undo half kick
         p[j] = pj;
