@@ -952,52 +952,12 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, g = lane >> 4;
     float* wl = lds + C::STATIC_FLOATS + wave * C::WAVE3_FLOATS;
-    {
-        // all image loads in flight first, the zero fill of the per-wave images under their latency, then the LDS stores
-        constexpr int N4 = C::STATIC_FLOATS / 4, IT = (N4 + FAST_THREADS - 1) / FAST_THREADS;
-        const float4* src = reinterpret_cast<const float4*>(qimg);
-        float4* dst = reinterpret_cast<float4*>(lds);
-        float4 v[IT];
-        // every workgroup of the grid reads the same 78 KB at the same moment: start each one at a different 4-KB piece
-        // (rot), or the requests of a whole XCD queue on the L2 channels of one piece after the other
-#ifndef TBNN_F3_PROROT
-#define TBNN_F3_PROROT 1
-#endif
-        const int rot = TBNN_F3_PROROT ? (int)(blockIdx.x % IT) : 0;
-#pragma unroll
-        for (int k = 0; k < IT; ++k) { const int kk = k + rot < IT ? k + rot : k + rot - IT, e = tid + kk * FAST_THREADS; v[k] = e < N4 ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
-        __builtin_amdgcn_sched_barrier(0);
-        float4* z = reinterpret_cast<float4*>(wl);
-        for (int e = lane; e < C::WAVE3_FLOATS / 4; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < IT; ++k) { const int kk = k + rot < IT ? k + rot : k + rot - IT, e = tid + kk * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
-    }
-    __syncthreads();
-    TB_STAMP(1);
-
     constexpr int d_in = C::in(0), d_out = C::out(C::NL - 1), L = C::NL - 1;
-    constexpr int NFd = C::maxNF() > 0 ? C::maxNF() : 1;
-    f32x4 dW[C::DW3_TILES > 0 ? C::DW3_TILES : 1];
-#pragma unroll
-    for (int t = 0; t < C::DW3_TILES; ++t) dW[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float FP[C::FP_REGS > 0 ? C::FP_REGS : 1];
-#pragma unroll
-    for (int t = 0; t < C::FP_REGS; ++t) FP[t] = 0.f;
-    const float sigma = lik_sigma(nd, eta);
-    const float inv_var = 1.f / (sigma * sigma);
-    double stat = 0.0;
     const long ntiles = (n + 15) / 16;
     const long W = (long)gridDim.x * FAST_WAVES;
     const long wg = (long)blockIdx.x * FAST_WAVES + wave;
-
-    if (g == 0) wl[C::aoff3(0) + d_in * C::PR + i16] = 1.f;
-#pragma unroll
-    for (int l = 1; l < C::NLM3; ++l)
-        if (C::in(l) % 16 == 0 && g == 0) wl[C::aoff3(l) + C::in(l) * C::PR + i16] = 1.f;
-    f32x4 A0[C::MTF(0) > 0 ? C::MTF(0) : 1], B0[C::MTF(0) > 0 ? C::MTF(0) : 1];
-    Fwd3<S, 0>::preload(A0, B0, lds, i16, g);
-
+    // the rows of this wave's first tile (and of the cooperative tiles) are requested before anything else: their HBM
+    // latency (the first tile took 7.5 us instead of 6.1) hides under the prologue's image loads
     float xn[C::KS0], yn[d_out];
     auto fetch = [&](long tile) {
         const long row = tile * 16 + i16;
@@ -1035,6 +995,48 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     }
     long tile = wg;
     fetch(tile);
+    {
+        // all image loads in flight first, the zero fill of the per-wave images under their latency, then the LDS stores
+        constexpr int N4 = C::STATIC_FLOATS / 4, IT = (N4 + FAST_THREADS - 1) / FAST_THREADS;
+        const float4* src = reinterpret_cast<const float4*>(qimg);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        float4 v[IT];
+        // every workgroup of the grid reads the same 78 KB at the same moment: start each one at a different 4-KB piece
+        // (rot), or the requests of a whole XCD queue on the L2 channels of one piece after the other
+#ifndef TBNN_F3_PROROT
+#define TBNN_F3_PROROT 1
+#endif
+        const int rot = TBNN_F3_PROROT ? (int)(blockIdx.x % IT) : 0;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { const int kk = k + rot < IT ? k + rot : k + rot - IT, e = tid + kk * FAST_THREADS; v[k] = e < N4 ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        __builtin_amdgcn_sched_barrier(0);
+        float4* z = reinterpret_cast<float4*>(wl);
+        for (int e = lane; e < C::WAVE3_FLOATS / 4; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < IT; ++k) { const int kk = k + rot < IT ? k + rot : k + rot - IT, e = tid + kk * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
+    }
+    __syncthreads();
+    TB_STAMP(1);
+
+    constexpr int NFd = C::maxNF() > 0 ? C::maxNF() : 1;
+    f32x4 dW[C::DW3_TILES > 0 ? C::DW3_TILES : 1];
+#pragma unroll
+    for (int t = 0; t < C::DW3_TILES; ++t) dW[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float FP[C::FP_REGS > 0 ? C::FP_REGS : 1];
+#pragma unroll
+    for (int t = 0; t < C::FP_REGS; ++t) FP[t] = 0.f;
+    const float sigma = lik_sigma(nd, eta);
+    const float inv_var = 1.f / (sigma * sigma);
+    double stat = 0.0;
+
+    if (g == 0) wl[C::aoff3(0) + d_in * C::PR + i16] = 1.f;
+#pragma unroll
+    for (int l = 1; l < C::NLM3; ++l)
+        if (C::in(l) % 16 == 0 && g == 0) wl[C::aoff3(l) + C::in(l) * C::PR + i16] = 1.f;
+    f32x4 A0[C::MTF(0) > 0 ? C::MTF(0) : 1], B0[C::MTF(0) > 0 ? C::MTF(0) : 1];
+    Fwd3<S, 0>::preload(A0, B0, lds, i16, g);
+
     bool first = true;
     for (; tile < main_end; tile += W) {
         Tile3<S> T;

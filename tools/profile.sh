@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=${1:-r01}
 OUT=gpurun_out/$R
 mkdir -p $OUT
-BENCH="python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline"
+BENCH="python3 bench.py --workload c2 --steps 40 --warmup 10 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
@@ -23,7 +23,7 @@ for tag in ("pmc_fetch","pmc_write","pmc_sq","pmc_lds"):
     acc=collections.defaultdict(lambda: [0.0,0])
     for r in rows(f"{tag}/**/*counter_collection.csv"):
         k=r.get("Kernel_Name","")
-        if "k_fwd_bwd_fast" not in k: continue
+        if "k_fwd_bwd_fast" not in k or "Li5ELi50" not in k and "5, 50, 50, 50" not in k: continue
         acc[r["Counter_Name"]][0]+=float(r["Counter_Value"]); acc[r["Counter_Name"]][1]+=1
     for c,(v,n) in acc.items(): summ[c]={"mean_per_launch": v/max(n,1), "launches": n}
 json.dump(summ, open(os.path.join(out,"pmc_summary_fwd_bwd_fast.json"),"w"), indent=1)
