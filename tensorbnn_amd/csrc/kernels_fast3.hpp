@@ -949,7 +949,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     __shared__ __attribute__((aligned(16))) float lds[C::LDS3_FLOATS];
     __shared__ __attribute__((aligned(16))) float xch[CO::ENABLED ? 2 * CO::XB : 4];     // cooperative tail: exchange buffers
     __shared__ double red[FAST_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform branches stay s_cbranch
     const int i16 = lane & 15, g = lane >> 4;
     float* wl = lds + C::STATIC_FLOATS + wave * C::WAVE3_FLOATS;
     constexpr int d_in = C::in(0), d_out = C::out(C::NL - 1), L = C::NL - 1;

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     static_assert(C::LDS_FLOATS * 4 + 64 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     __shared__ double red[WIDE_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: see k_dw_wide
     const int i16 = lane & 15, g = lane >> 4;
     constexpr int d_in = C::d_in, d_out = C::d_out, NM = C::NM, LL = C::LL;
     const long ntiles = (n + 15) / 16;
@@ -782,7 +782,9 @@ __global__ __launch_bounds__(WIDE_THREADS, WideCfg<S>::DW_OCC) void k_dw_wide(
     using C = WideCfg<S>;
     static_assert(WIDE_RING * C::DW_SLOT_FLOATS * 4 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) float lds[WIDE_RING * C::DW_SLOT_FLOATS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // wave index as a SCALAR (the compiler does not know threadIdx.x >> 6 is wave-uniform: every `b = wave + 4j < SB` below
+    // would become an exec-mask branch with zero-filled else arms, and the block addresses vector arithmetic)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long ntiles = (n + 15) / 16;
     const int b = blockIdx.x;
     int l = 1;
