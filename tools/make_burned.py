@@ -32,8 +32,8 @@ PLAN = {   # blocks x epochs per block of burn-in, starting eps, scan candidates
     "c1": dict(blocks=60, per=50, eps0=1e-4),
     "c2": dict(blocks=100, per=20, eps0=2e-5),
     "c4": dict(blocks=24, per=5, eps0=1e-6),
-    "c5": dict(blocks=40, per=10, eps0=5e-5),
-    "c5g": dict(blocks=40, per=10, eps0=5e-5),
+    "c5": dict(blocks=40, per=10, eps0=5e-5, n_scan=120, scan=(0.25, 0.35, 0.5, 0.63, 0.8, 1.0, 1.25, 1.6)),   # erratic acceptance (stiff prior): long windows
+    "c5g": dict(blocks=40, per=10, eps0=5e-5, n_scan=80),
 }
 SCAN = (0.5, 0.63, 0.8, 1.0, 1.25, 1.6, 2.0)
 
@@ -72,8 +72,8 @@ def main():
                       + (f" eps_h {float(da.step_size):.3e}" if hyper else ""), flush=True)
         theta, eta = ch.get_state(), ch.get_hypers()
         scan = []
-        n_scan = max(40, 4 * plan["per"])        # the acceptance of a 20-epoch window is too noisy to rank step sizes
-        for k, f in enumerate(SCAN):
+        n_scan = plan.get("n_scan", max(40, 4 * plan["per"]))        # the acceptance of a 20-epoch window is too noisy to rank step sizes
+        for k, f in enumerate(plan.get("scan", SCAN)):
             ch.set_state(theta); ch.set_hypers(eta); ch.set_epoch(1_000_000 * (k + 1))
             e = eps * f
             a = float(np.mean([ch.hmc_step(e, L)["accept_prob"] for _ in range(n_scan)]))
