@@ -265,7 +265,7 @@ def test_hyper_logp_grad(native, case):
     ch.close()
 
 
-@pytest.mark.parametrize("case", ["c1", "trainreg", "c5_small"])
+@pytest.mark.parametrize("case", ["c1", "trainreg", "c5_small", "tiny"])      # tiny: H = 5 > P = 4 (injected momentum buffer)
 def test_hyper_step_injected(native, case):
     spec, X, Y, theta, eta = problem(case)
     rng = np.random.default_rng(11)
