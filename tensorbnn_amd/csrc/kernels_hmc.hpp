@@ -49,8 +49,11 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     const float* __restrict__ slabs, int nslab, int pitch,
     const float* __restrict__ q_cur, const float* __restrict__ g_cur,
     float* __restrict__ q, float* __restrict__ p, float* __restrict__ g,
-    const int* __restrict__ imgmap, float* __restrict__ qimg)
+    const int* __restrict__ imgmap, float* __restrict__ qimg, float* __restrict__ gd = nullptr)
 {
+    // gd (optional): the DATA term of the gradient alone (the reduced slabs, before the prior is added): kept next to the
+    // state so that a hyper transition, which changes only the prior and the likelihood's sigma, can refresh the cached
+    // (log-prob, gradient) of the current state without another pass over the rows (k_refresh_after_hyper)
     __shared__ float4 part[UPD_GROUPS][UPD_COLS];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int c4 = blockIdx.x * UPD_COLS + tx;          // float4 column
@@ -110,6 +113,7 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     if (!fin) return;
     const int j = jf;
     float gj = ty == 0 ? gs.x : ty == 1 ? gs.y : ty == 2 ? gs.z : gs.w;
+    if (mode != UPD_FIRST && gd) gd[j] = gj;
     if (mode != UPD_FIRST) gj += prior_grad(prior, loc, scale, q_j);
     if (mode == UPD_GRAD_ONLY) { g[j] = gj; return; }
     if (mode == UPD_FIRST) {
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(1024) void k_begin(
     }
 }
 
-enum { EN_CUR = 0, EN_NEW = 1, EN_TRACE = 2 };
+enum { EN_CUR = 0, EN_NEW = 1, EN_TRACE = 2, EN_REFRESH = 3 };   // EN_REFRESH: EN_CUR from the cached statistic sc->stat_cur
 // Single-workgroup kernel: total target log-prob (+ kinetic energy and the
 // Metropolis decision when which == EN_NEW).
 __global__ __launch_bounds__(1024) void k_energy(
@@ -239,8 +243,10 @@ __global__ __launch_bounds__(1024) void k_energy(
 {
     __shared__ double red[16];
     double st = 0.0;
-    for (int w = threadIdx.x; w < nslab; w += blockDim.x) st += partial_stat[w];
-    st = block_sum(st, red);
+    if (which != EN_REFRESH) {
+        for (int w = threadIdx.x; w < nslab; w += blockDim.x) st += partial_stat[w];
+        st = block_sum(st, red);
+    }
     double pr = prior_logp_partial(nd, eta, q);
     pr = block_sum(pr, red);
     double k1 = 0.0, d2 = 0.0;
@@ -255,6 +261,7 @@ __global__ __launch_bounds__(1024) void k_energy(
         d2 = block_sum(d2, red);
     }
     if (threadIdx.x != 0) return;
+    if (which == EN_REFRESH) { st = sc->stat_cur; which = EN_CUR; }
     const double lp = pr + data_logp(nd, eta, st, n);
     if (which == EN_TRACE) { *trace_slot = lp; return; }
     if (which == EN_CUR) {
@@ -277,11 +284,29 @@ __global__ __launch_bounds__(1024) void k_energy(
 // k_commit_scal afterwards so that logp_old stays readable for the host.)
 __global__ __launch_bounds__(256) void k_commit(
     int P, const Scal* __restrict__ sc, const float* __restrict__ q, const float* __restrict__ g,
-    float* __restrict__ q_cur, float* __restrict__ g_cur)
+    float* __restrict__ q_cur, float* __restrict__ g_cur, const float* __restrict__ gd, float* __restrict__ gd_cur)
 {
     if (!sc->accepted) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < P) { q_cur[j] = q[j]; g_cur[j] = g[j]; }
+    if (j < P) { q_cur[j] = q[j]; g_cur[j] = g[j]; gd_cur[j] = gd[j]; }
+}
+
+// After an ACCEPTED hyper transition (eta_old -> eta): the prediction does not depend on eta, so the data-term gradient at
+// the current state only rescales with the likelihood's sigma (Gaussian: 1/sigma^2; fixed-sd / Bernoulli: unchanged) and
+// the statistic is the cached one; the prior terms are O(P).  Replaces a whole fused pass over the rows per epoch.
+__global__ __launch_bounds__(256) void k_refresh_grad_after_hyper(
+    NetDev nd, const float* __restrict__ eta_old, const float* __restrict__ eta, const float* __restrict__ q_cur,
+    float* __restrict__ gd_cur, float* __restrict__ g_cur)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nd.P) return;
+    const float so = lik_sigma(nd, eta_old), sn = lik_sigma(nd, eta);
+    const float scl = nd.lik == TBNN_LIK_GAUSSIAN ? (so / sn) * (so / sn) : 1.f;
+    int prior; float loc, scale;
+    prior_params(nd, eta, j, prior, loc, scale);
+    const float gd = gd_cur[j] * scl;
+    gd_cur[j] = gd;
+    g_cur[j] = gd + prior_grad(prior, loc, scale, q_cur[j]);
 }
 // copies the record for the host, then rolls cur <- new when accepted
 __global__ void k_commit_scal(Scal* __restrict__ sc, Scal* __restrict__ host_copy) {

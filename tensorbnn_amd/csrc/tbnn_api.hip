@@ -60,6 +60,7 @@ struct tbnn_ctx {
     // chain state
     float *q_cur = nullptr, *g_cur = nullptr, *q = nullptr, *p = nullptr, *g = nullptr, *eta = nullptr;
     float *p0_inj = nullptr, *logu_inj = nullptr, *tmp = nullptr;
+    float *gd = nullptr, *gd_cur = nullptr, *eta_prev = nullptr;   // data-term gradient of the proposal / current state; eta before a hyper step
     bool cur_valid = false;               // (logp, grad, stat) cached at q_cur for the current eta/data
     bool q_img_valid = false;             // h->qimg mirrors h->q (maintained by k_update)
     // fused-pass workspace
@@ -175,7 +176,7 @@ extern "C" int tbnn_destroy(tbnn_handle h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->own_data) { hipFree(h->dX); hipFree(h->dY); }
-    float* bufs[] = {h->q_cur, h->g_cur, h->q, h->p, h->g, h->eta, h->p0_inj, h->logu_inj, h->tmp,
+    float* bufs[] = {h->q_cur, h->g_cur, h->q, h->p, h->g, h->eta, h->p0_inj, h->logu_inj, h->tmp, h->gd, h->gd_cur, h->eta_prev,
                      h->slabs, h->scratch, h->hyp_ws, h->wstore, h->wslabA, h->wslabB, h->grow, h->dXv, h->dYv, h->fbuf};
     if (h->mpart) hipFree(h->mpart);
     for (float* b : bufs) if (b) hipFree(b);
@@ -229,6 +230,8 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
     HIPB(hipMalloc(&h->p0_inj, (size_t)std::max(nd.P, nd.H) * sizeof(float)));   // injected momentum of either transition (H > P for tiny networks)
     HIPB(hipMalloc(&h->tmp, PB + (size_t)nd.H * sizeof(float)));
     HIPB(hipMalloc(&h->eta, (size_t)nd.H * sizeof(float)));
+    HIPB(hipMalloc(&h->eta_prev, (size_t)nd.H * sizeof(float)));
+    HIPB(hipMalloc(&h->gd, PB)); HIPB(hipMalloc(&h->gd_cur, PB));
     HIPB(hipMalloc(&h->logu_inj, sizeof(float)));
     HIPB(hipMalloc(&h->sc, sizeof(Scal))); HIPB(hipMalloc(&h->sc_out, sizeof(Scal)));
     HIPB(hipHostMalloc(&h->sc_host, sizeof(Scal)));
@@ -588,8 +591,10 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
 static void launch_update(tbnn_ctx* h, int mode, float eps, const float* eta, float* q, float* g) {
     const int gx = (h->pitch / 4 + UPD_COLS - 1) / UPD_COLS;
     const bool img = h->kernel == TBNN_KERNEL_FAST && q == h->q;
+    // the data-term gradient goes with its state: the proposal's (h->gd) or, for the bootstrap evaluation, the current one's
+    float* gd = g == h->g_cur ? h->gd_cur : (g == h->g ? h->gd : nullptr);
     hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, h->nd, mode, eps, eta, grad_slabs(h), grad_nslab(h),
-                       h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg);
+                       h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg, gd);
     if (img && (mode == UPD_FIRST || mode == UPD_MID)) h->q_img_valid = true;
 }
 static void launch_energy(tbnn_ctx* h, int which, const float* eta, const float* q, double* slot) {
@@ -632,7 +637,7 @@ extern "C" int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* et
     if (rc) return rc;
     const int gx = (h->pitch / 4 + UPD_COLS - 1) / UPD_COLS;
     hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, nd, (int)UPD_GRAD_ONLY, 0.f, de, grad_slabs(h), grad_nslab(h),
-                       h->pitch, h->q_cur, h->g_cur, const_cast<float*>(dq), h->p, h->tmp, (const int*)nullptr, (float*)nullptr);
+                       h->pitch, h->q_cur, h->g_cur, const_cast<float*>(dq), h->p, h->tmp, (const int*)nullptr, (float*)nullptr, (float*)nullptr);
     // EN_TRACE leaves the chain's scalar record alone; stat comes from the slabs
     if (!h->trace || h->trace_cap < 2) {
         if (h->trace) hipFree(h->trace);
@@ -874,7 +879,8 @@ static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, 
         launch_update(h, t < L ? UPD_MID : UPD_LAST, eps, h->eta, h->q, h->g);
     }
     launch_energy(h, EN_NEW, h->eta, h->q, d_trace ? d_trace + L : nullptr);
-    hipLaunchKernelGGL(k_commit, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, h->sc, h->q, h->g, h->q_cur, h->g_cur);
+    hipLaunchKernelGGL(k_commit, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, h->sc, h->q, h->g, h->q_cur, h->g_cur,
+                       (const float*)h->gd, h->gd_cur);
     hipLaunchKernelGGL(k_commit_scal, dim3(1), dim3(64), 0, h->stream, h->sc, d_out);
     HIPCHK(hipGetLastError());
     h->epoch += 1;
@@ -981,6 +987,7 @@ extern "C" int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const fl
     const float* d_p0 = nullptr; const float* d_lu = nullptr;
     if (p0) { HIPCHK(hipMemcpyAsync(h->p0_inj, p0, (size_t)nd.H * sizeof(float), hipMemcpyHostToDevice, h->stream)); d_p0 = h->p0_inj; }
     if (log_u) { HIPCHK(hipMemcpyAsync(h->logu_inj, log_u, sizeof(float), hipMemcpyHostToDevice, h->stream)); d_lu = h->logu_inj; }
+    HIPCHK(hipMemcpyAsync(h->eta_prev, h->eta, (size_t)nd.H * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     // the hyper transition uses the epoch counter of the weight transition that preceded it
     const uint32_t ep = h->epoch > 0 ? h->epoch - 1 : 0;
@@ -992,9 +999,19 @@ extern "C" int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const fl
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1);
     if (out) fill_out(*h->sc_host, L_h, ms * 1000.f, 0.f, out);
-    // eta changed => the weight target changed: prior part of logp/grad at q_cur must be refreshed;
-    // the data statistic is unchanged but the simplest correct thing is a full refresh.
-    if (h->sc_host->accepted) h->cur_valid = false;
+    // eta changed => the weight target changed.  The prediction does not depend on eta: the cached statistic stays, the
+    // data-term gradient rescales with sigma, the prior terms are recomputed -- O(P), no pass over the rows
+    // (TBNN_HYPER_FULL_REFRESH=1: the round-1 behaviour, a whole bootstrap evaluation)
+    if (h->sc_host->accepted) {
+        static const bool full = getenv("TBNN_HYPER_FULL_REFRESH") && atoi(getenv("TBNN_HYPER_FULL_REFRESH"));
+        if (full || !h->cur_valid) h->cur_valid = false;
+        else {
+            hipLaunchKernelGGL(k_refresh_grad_after_hyper, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd, (const float*)h->eta_prev,
+                               (const float*)h->eta, (const float*)h->q_cur, h->gd_cur, h->g_cur);
+            launch_energy(h, EN_REFRESH, h->eta, h->q_cur, nullptr);
+            HIPCHK(hipGetLastError());
+        }
+    }
     return 0;
 }
 

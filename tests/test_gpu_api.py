@@ -93,20 +93,35 @@ def test_accept_ratio_parity_with_oracle_chain(native):
     ch.close()
 
 
-def test_hyper_transition_changes_weight_target(native):
-    """after an accepted hyper transition the cached (logp, grad) is refreshed"""
-    spec, X, Y, theta, eta = o.synth_problem([1, 10, 10, 1], 200)
+@pytest.mark.parametrize("case", ["gaussian_lik", "bernoulli", "fixed_gaussian_prior"])
+def test_hyper_transition_changes_weight_target(native, case):
+    """after an accepted hyper transition the cached (log-prob, gradient) of the current state is refreshed WITHOUT another
+    pass over the rows (k_refresh_grad_after_hyper: the data-term gradient rescales with the likelihood's sigma, the prior
+    terms are recomputed): the next transition's whole log-prob trace -- its first step moves along the refreshed gradient --
+    must be the oracle's at the new eta; several (weight, hyper) rounds, rejects in between"""
+    dims, n, act, prior, lik = {"gaussian_lik": ([1, 10, 10, 1], 200, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
+                                "bernoulli": ([20, 32, 16, 48, 2], 300, o.ACT_SIGMOID, o.PRIOR_CAUCHY, o.LIK_BERNOULLI),
+                                "fixed_gaussian_prior": ([1, 10, 10, 10, 1], 64, o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_FIXED_GAUSSIAN)}[case]
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, act, prior, lik)
     layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
-    ch = native.Chain(layers, likelihood=spec.likelihood)
+    ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd)
     ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
-    ch.hmc_step(1e-4, 3)
-    h = ch.hyper_step(1e-5, 5, log_u=-1e30)
-    assert h["accepted"] == 1
-    eta2, th2 = ch.get_hypers(), ch.get_state()
-    assert np.abs(eta2 - eta).max() > 0
-    out = ch.hmc_step(1e-4, 3, p0=np.zeros(ch.P, np.float32), log_u=1e30)
-    lp, _ = o.target_log_prob_and_grad(spec, th2, eta2, X, Y, np.float64)
-    assert abs(out["logp_old"] - lp) <= 4e-6 * abs(lp) + 1e-3
+    rng = np.random.default_rng(12)
+    eps = 2e-3 if lik == o.LIK_FIXED_GAUSSIAN else 1e-4
+    ch.hmc_step(eps, 3)
+    for rnd in range(3):
+        h = ch.hyper_step(1e-5, 5, log_u=-1e30)                 # forced accept: eta moves
+        assert h["accepted"] == 1
+        eta2, th2 = ch.get_hypers(), ch.get_state()
+        assert np.abs(eta2 - eta).max() > 0
+        p0 = (0.1 * rng.standard_normal(ch.P)).astype(np.float32)
+        lu = 1e30 if rnd == 1 else float(np.log(0.7))            # a forced reject in the middle round
+        out = ch.hmc_step(eps, 3, p0=p0, log_u=lu, trace=True)
+        ref = o.weight_step(spec, th2, eta2, X, Y, eps, 3, p0, lu, np.float64)
+        assert abs(out["logp_old"] - ref.logp_old) <= 4e-6 * abs(ref.logp_old) + 1e-3, (case, rnd)
+        np.testing.assert_allclose(out["trace_logp"], ref.trace_logp, rtol=4e-6, atol=2e-3, err_msg=f"{case} round {rnd}")
+        assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-4 * abs(ref.log_accept_ratio) + 1e-6 * abs(ref.logp_old)
+        assert bool(out["accepted"]) == ref.accepted
     ch.close()
 
 
