@@ -748,13 +748,20 @@ struct Coop3 {
 #pragma unroll
                 for (int t = 0; t < C::KS0; ++t) acc = mfma16(lds[C::woff(0) + (16 * wave + i16) * C::LDW(0) + 4 * t + g], T.x0[t], acc);
             } else {
+                // one M tile per wave: a single chain of 13 MFMAs would run at the 40-cycle dependent latency; two
+                // accumulators (even / odd k-groups) keep it at the 32-cycle issue rate
                 const float* wrow = lds + C::woff(l) + (16 * wave + i16) * C::LDW(l) + 4 * g;
+                f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kt = 0; kt < C::KG(l); ++kt) {
                     const f32x4 A = load_ks(wrow + 16 * kt, C::ksteps(C::in(l), kt));
 #pragma unroll
-                    for (int s = 0; s < C::ksteps(C::in(l), kt); ++s) acc = mfma16(A[s], T.a[C::aroff(l - 1) + kt][s], acc);
+                    for (int s = 0; s < C::ksteps(C::in(l), kt); ++s) {
+                        if (kt & 1) acc1 = mfma16(A[s], T.a[C::aroff(l - 1) + kt][s], acc1);
+                        else acc = mfma16(A[s], T.a[C::aroff(l - 1) + kt][s], acc);
+                    }
                 }
+                acc += acc1;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) mine[r] = actc_fwd<S::act(l)>(acc[r]);
@@ -844,14 +851,18 @@ struct Coop3 {
 #pragma unroll
             for (int f = 0; f < NFd; ++f) dzpf[f] = 0.f;
             if (wave < MTP) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 const float* trow = lds + C::toff(l) + (16 * wave + i16) * C::LDT(l) + 4 * g;
 #pragma unroll
                 for (int kt = 0; kt < C::cdiv(K, 16); ++kt) {
                     const f32x4 A = load_ks(trow + 16 * kt, C::ksteps(K, kt));
 #pragma unroll
-                    for (int s = 0; s < C::ksteps(K, kt); ++s) acc = mfma16(A[s], dz[kt][s], acc);
+                    for (int s = 0; s < C::ksteps(K, kt); ++s) {
+                        if (kt & 1) acc1 = mfma16(A[s], dz[kt][s], acc1);
+                        else acc = mfma16(A[s], dz[kt][s], acc);
+                    }
                 }
+                acc += acc1;
                 odz = actc_bwd_mul4<S::act(l - 1), false>(acc, own[l - 1]);
                 if constexpr (XCHG) *reinterpret_cast<f32x4*>(xb + wave * 256 + lane * 4) = odz;
             } else if (NFP > 0 && wave == MTP) {
