@@ -10,7 +10,9 @@ SRC = [os.path.join(HERE, "csrc", "tbnn_api.hip"), os.path.join(HERE, "csrc", "t
 # AccVGPRs by hand (kernels_fast.hpp, mfma16_acc)
 NARROW_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 PER_SOURCE_FLAGS = {"tbnn_api.hip": NARROW_FLAGS,
-                    "tbnn_wide.hip": NARROW_FLAGS + os.environ.get("TBNN_WIDE_FLAGS", "").split()}     # + experiments
+                    # experiments: TBNN_WIDE_FLAGS adds flags to the wide translation unit, TBNN_WIDE_AGPR_FORM=1 drops the VGPR form there
+                    "tbnn_wide.hip": ([] if os.environ.get("TBNN_WIDE_AGPR_FORM") == "1" else NARROW_FLAGS)
+                                     + os.environ.get("TBNN_WIDE_FLAGS", "").split()}
 OBJ_DIR = os.path.join(HERE, "_obj")
 OUT = os.path.join(HERE, "libtbnn.so")
 
