@@ -156,7 +156,9 @@ for k in range(3):
 if rank == 0:
     parallel.write_chain_folders(sys.argv[2], st, [(2, 2), (2, 1)], ["dense"], 2)
 torch.distributed.barrier()
-print("rank", rank, "ok")
+# one marker file per rank (the launcher forwards the ranks' stdout through pipes and may interleave two lines)
+os.makedirs(sys.argv[2], exist_ok=True)
+open(os.path.join(sys.argv[2], f"rank{rank}.ok"), "w").write("ok")
 '''
 
 
@@ -174,7 +176,7 @@ def test_two_process_gloo_gather(tmp_path):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert os.path.exists(tmp_path / "out" / "rank0.ok") and os.path.exists(tmp_path / "out" / "rank1.ok"), r.stdout + r.stderr
     for c in range(2):
         mats, hyp = o.load_networks(str(tmp_path / "out" / f"chain{c}"))
         assert mats[0].shape == (3, 2, 2) and mats[1].shape == (3, 2, 1) and len(hyp) == 3
@@ -270,3 +272,39 @@ def test_adapter_grid_search_threads_agree(monkeypatch):
     a, b, c = run(1), run(None), run(3)
     assert a == b == c
     assert len(set(a[10:])) > 3          # the search did move (eps, L) around
+
+
+def test_burned_fixtures_are_consistent():
+    """the committed burned-in chain states bench.py and the free-running parity tests start from (tools/make_burned.py):
+    shapes match the workloads, the step size is one the recorded scan (or tools/epscal.py's note) supports"""
+    import json
+    from tensorbnn_amd.workloads import WORKLOADS, burned_state
+    gold = os.path.join(ROOT, "tests", "golden")
+    for cfg, wl in WORKLOADS.items():
+        b = burned_state(cfg)
+        assert b is not None, cfg
+        dims = wl["dims"]
+        P = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
+        H = 4 * (len(dims) - 1) + (1 if wl["lik"] == 0 else 0)
+        assert b["theta"].shape == (P,) and b["eta"].shape == (H,) and b["theta"].dtype == np.float32
+        assert np.all(np.isfinite(b["theta"])) and np.all(np.isfinite(b["eta"]))
+        assert int(b["L"]) == wl["L"] and int(b["epochs"]) >= 100
+        scan = b["scan"]
+        assert scan.shape[1] == 2 and scan[:, 0].min() * 0.5 <= float(b["eps"]) <= scan[:, 0].max()
+        assert np.any((scan[:, 1] >= 0.6) & (scan[:, 1] <= 0.9))            # the scan found the regime SURVEY 8(d) asks for
+        meta = json.load(open(os.path.join(gold, f"{cfg}_burned.json")))
+        assert meta["rows"] == wl["n"] and meta["dims"] == dims and abs(meta["eps"] - float(b["eps"])) < 1e-12
+        if wl["hyper"]:
+            assert "da_step" in b and float(b["da_step"]) > 0
+
+
+def test_bench_host_helpers():
+    """bench.py's host-side pieces that need no GPU: algorithmic FLOP per leapfrog step, CPU topology"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.algorithmic_flops([5, 50, 50, 50, 1], 100_000) == pytest.approx(3.13e9, rel=2e-3)
+    assert bench.algorithmic_flops([10, 200, 200, 200, 1], 1_000_000) == pytest.approx(4.892e11, rel=1e-3)
+    assert bench.algorithmic_flops([20, 100, 100, 2], 500_000) == pytest.approx(3.46e10, rel=2e-3)
+    logical, physical = bench.host_cpus()
+    assert 1 <= physical <= logical
+    assert set(bench.CONFIG_KEY) >= {"c1", "c2", "c4", "c5"}
