@@ -44,16 +44,22 @@ def gather_samples(sample: torch.Tensor) -> torch.Tensor:
 
 class SampleGatherer:
     """Collects the chain-major gathered samples on every rank and lets rank 0
-    write one reference-format folder per chain (chain<c>/)."""
+    write one reference-format folder per chain (chain<c>/).  With a native communicator (`comm` = make_comm(chain)) the
+    gather is the C ABI's own RCCL all-gather on the chain's stream (tbnn_gather_samples) -- the route bench.py times;
+    without one it goes through torch.distributed (any backend: the gloo CPU tests drive it with fake chains)."""
 
-    def __init__(self, P, H, device=None):
+    def __init__(self, P, H, device=None, comm=None):
         self.P, self.H = P, H
+        self.comm = comm
         self.device = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
         self.buf = torch.empty(P + H, dtype=torch.float32, device=self.device)
         self.samples = []            # list of [world, P+H] host arrays
 
     def __call__(self, chain, iter_):
         """train(gather=...) hook: export the chain's (theta, eta) on the device and all-gather it."""
+        if self.comm is not None:
+            self.samples.append(chain.gather_samples(self.comm))
+            return
         if self.buf.is_cuda:
             chain.export_sample_device(self.buf.data_ptr())
         else:   # CPU tests drive this path with fake chains
