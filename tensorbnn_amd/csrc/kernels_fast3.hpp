@@ -944,6 +944,16 @@ struct Coop3 {
     }
 };
 
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4: lane i lands at lbase + 16 i; lbase is
+// wave-uniform).  The builtin exists in the device pass only; the host pass needs just the kernel's stub.
+__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lbase) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(gsrc, lbase, 16, 0, 0);
+#else
+    (void)gsrc; (void)lbase;
+#endif
+}
+
 template <class S>
 __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_fwd_bwd_fast3(
     NetDev nd, const float* __restrict__ qimg, const float* __restrict__ eta,
@@ -1006,26 +1016,35 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     }
     long tile = wg;
     fetch(tile);
+    // The W^T images (delta chain: needed from the first BACKWARD pass on) do not go through registers: each wave sends its
+    // share straight to LDS with global_load_lds (1 KB per instruction, no VGPRs held), and the wait + barrier that makes
+    // them visible sits behind the first tile's forward pass -- the prologue proper stages the W / bias images only.
+#ifndef TBNN_F3_WTDMA
+#define TBNN_F3_WTDMA 1
+#endif
+    constexpr bool WTDMA = TBNN_F3_WTDMA && C::STATIC_FLOATS > C::WB_FLOATS;
+    if constexpr (WTDMA) {
+        constexpr int WT = C::STATIC_FLOATS - C::WB_FLOATS, NCHUNK = (WT + 255) / 256;
+        static_assert(C::WB_FLOATS % 4 == 0 && WT % 4 == 0, "16-B pieces");
+        for (int c = wave; c < NCHUNK; c += FAST_WAVES) {
+            const int off = C::WB_FLOATS + c * 256;
+            if (c * 256 + lane * 4 < WT) lds_dma16(qimg + off + lane * 4, lds + off);
+        }
+    }
     {
         // all image loads in flight first, the zero fill of the per-wave images under their latency, then the LDS stores
-        constexpr int N4 = C::STATIC_FLOATS / 4, IT = (N4 + FAST_THREADS - 1) / FAST_THREADS;
+        constexpr int N4 = (WTDMA ? C::WB_FLOATS : C::STATIC_FLOATS) / 4, IT = (N4 + FAST_THREADS - 1) / FAST_THREADS;
         const float4* src = reinterpret_cast<const float4*>(qimg);
         float4* dst = reinterpret_cast<float4*>(lds);
         float4 v[IT];
-        // every workgroup of the grid reads the same 78 KB at the same moment: start each one at a different 4-KB piece
-        // (rot), or the requests of a whole XCD queue on the L2 channels of one piece after the other
-#ifndef TBNN_F3_PROROT
-#define TBNN_F3_PROROT 1
-#endif
-        const int rot = TBNN_F3_PROROT ? (int)(blockIdx.x % IT) : 0;
 #pragma unroll
-        for (int k = 0; k < IT; ++k) { const int kk = k + rot < IT ? k + rot : k + rot - IT, e = tid + kk * FAST_THREADS; v[k] = e < N4 ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; v[k] = e < N4 ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
         __builtin_amdgcn_sched_barrier(0);
         float4* z = reinterpret_cast<float4*>(wl);
         for (int e = lane; e < C::WAVE3_FLOATS / 4; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < IT; ++k) { const int kk = k + rot < IT ? k + rot : k + rot - IT, e = tid + kk * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
+        for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
     }
     __syncthreads();
     TB_STAMP(1);
@@ -1049,6 +1068,14 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     Fwd3<S, 0>::preload(A0, B0, lds, i16, g);
 
     bool first = true;
+    // the W^T images in flight: every wave of the workgroup must meet ONE barrier behind its own wait.  When all four waves
+    // have a tile in the loop that barrier sits behind the first forward pass; otherwise here.
+    bool wt_pending = WTDMA;
+    if (WTDMA && !((long)blockIdx.x * FAST_WAVES + FAST_WAVES - 1 < main_end)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        wt_pending = false;
+    }
     for (; tile < main_end; tile += W) {
         Tile3<S> T;
         float y[d_out];
@@ -1064,6 +1091,11 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         fetch(tile + W);
         TSTAMP(0);
         Fwd3<S, 0>::run(T, lds, wl, i16, g, A0, B0);
+        if (wt_pending) {                       // first tile only, the same on all four waves
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            wt_pending = false;
+        }
         // likelihood on the all-fringe last layer
         float dzf[NFd];
 #pragma unroll
