@@ -49,6 +49,28 @@ def test_jit_kernel_parity(native, case):
     ch.close()
 
 
+@pytest.mark.parametrize("case,grid", [("narrow_fringe1", 5), ("narrow_fringe2_sigmoid", 4), ("narrow_tanh", 7)])
+def test_jit_kernel_cooperative_tail(native, monkeypatch, case, grid):
+    """the cooperative tail (Coop3) of run-time instantiated narrow kernels: one / two fringe units per layer, a 2-output last
+    layer, non-Relu hidden layers; a small grid (TBNN_FAST_GRID) puts these row counts into the rounds + left-over regime"""
+    c = CASES[case]
+    spec, X, Y, theta, eta = o.synth_problem(c["dims"], c["n"], c["act"], c["prior"], c["lik"])
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    ntiles, W = (c["n"] + 15) // 16, 4 * grid
+    assert 0 < ntiles % W <= 2 * grid, "the case must leave a cooperative remainder"
+    monkeypatch.setenv("TBNN_FAST_GRID", str(grid))
+    ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, kernel=native.KERNEL_FAST, jit=True)
+    assert ch.kernel_name.startswith("jit-fast3<"), ch.kernel_name
+    ch.set_data(X, Y)
+    lp, g, st = ch.logp_grad(theta, eta)
+    lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)
+    assert abs(lp - lp64) <= 4e-6 * abs(lp64) + 1e-3
+    for l, (ow, ob) in zip(spec.layers, spec.offsets()):
+        for a, b in ((ow, ob), (ob, ob + l.out_dim)):
+            assert np.abs(g[a:b] - g64[a:b]).max() <= 1e-4 * max(np.abs(g64[a:b]).max(), 1e-3), (case, a, b)
+    ch.close()
+
+
 def test_jit_unsupported_shape_falls_back(native):
     """mixed hidden activations: no fused family -> AUTO runs on the generic kernel, FAST fails loudly"""
     layers = [(4, 8, native.ACT_RELU, native.PRIOR_CAUCHY), (8, 8, native.ACT_TANH, native.PRIOR_CAUCHY),
