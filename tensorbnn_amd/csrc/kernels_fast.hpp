@@ -109,6 +109,14 @@ __device__ __forceinline__ float actc_bwd_mul(float acc, float a) {
     else return acc * actc_bwd<ACT>(a);
 }
 
+// diagnostic: padding of the weight-image rows (TBNN_WPAD) and of fast3's transposed images (TBNN_PPAD), in floats; 4 / 4 in
+// the product (8 makes the b128 operand reads bank-conflict-free on gfx950 but does not fit configs[1]'s LDS)
+#ifndef TBNN_WPAD
+#define TBNN_WPAD 4
+#endif
+#ifndef TBNN_PPAD
+#define TBNN_PPAD 4
+#endif
 template <class S>
 struct FastCfg {
     static constexpr int NL = S::NL;
@@ -118,7 +126,7 @@ struct FastCfg {
     static constexpr int MT(int l) { return cdiv(out(l), 16); }          // M tiles of layer l's output
     static constexpr int NT(int l) { return cdiv(in(l) + 1, 16); }       // N tiles of dW_l (+1: ones column -> db)
     static constexpr int KG(int l) { return cdiv(in(l), 16); }           // 16-unit k groups of layer l's input
-    static constexpr int LDW(int l) { return 16 * KG(l) + 4; }           // pitch of the W_l image (== 4 mod 8)
+    static constexpr int LDW(int l) { return 16 * KG(l) + TBNN_WPAD; }   // pitch of the W_l image (== 4 mod 8)
     static constexpr int maxMT() { int m = 0; for (int l = 0; l < NL; ++l) m = MT(l) > m ? MT(l) : m; return m; }
     static constexpr int PA(int l) { return 16 * NT(l) + 4; }            // pitch of the image of a_l = input of layer l (== 4 mod 8)
     static constexpr int PD = 16 * maxMT() + 4;                          // pitch of the delta image
@@ -130,7 +138,7 @@ struct FastCfg {
     static constexpr int boff(int l) { int o = W_FLOATS; for (int m = 0; m < l; ++m) o += 16 * MT(m); return o; }
     static constexpr int WB_FLOATS = boff(NL);                           // == the global padded image (k_update writes it)
     // transposed weight images W_l^T [in-unit][out-unit] for the delta chain (l >= 1), built in the prologue
-    static constexpr int LDT(int l) { return 16 * MT(l) + 4; }
+    static constexpr int LDT(int l) { return 16 * MT(l) + TBNN_WPAD; }
     // last layer with <= 2 outputs runs on the VALU (16 FMAs per output instead of padded MFMA tiles)
     static constexpr bool VL = NL >= 2 && out(NL - 1) <= 2;
     static constexpr int NLM = VL ? NL - 1 : NL;                          // layers on the MFMA path

@@ -59,7 +59,7 @@ struct F3Cfg : FastCfg<S> {
     // transposed images, column-major: [input slot][row], pitch PR floats.  A lane's 4 operand rows (4g..4g+3)
     // are then one 16-B read (a single wave gets poor ds_read_b32 throughput); the D-layout writes become
     // bank-conflict-free b32 pairs.
-    static constexpr int PR = 20;
+    static constexpr int PR = 16 + TBNN_PPAD;
     static constexpr int aoff3(int l) { int o = 0; for (int m = 0; m < l && m < NLM3; ++m) o += 16 * B::NT(m) * PR; return o; }
     static constexpr int doff3 = aoff3(NLM3);
     static constexpr int fdoff3 = doff3 + 16 * B::maxMT() * PR;   // fringe deltas [lane group copy][row][NF]: 4 x 32 floats

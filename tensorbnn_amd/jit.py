@@ -104,7 +104,8 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                       "the fused kernels need >= 2 dense layers with one activation for all hidden layers")
         return None
     dims, hact, lact, bern = sh
-    key = hashlib.sha1(f"{dims}|{hact}|{lact}|{bern}|{_sources_stamp()}".encode()).hexdigest()[:20]
+    extra = os.environ.get("TBNN_JIT_FLAGS", "").split()          # diagnostic builds (-DTBNN_WPAD=8 ...); part of the cache key
+    key = hashlib.sha1(f"{dims}|{hact}|{lact}|{bern}|{_sources_stamp()}|{extra}".encode()).hexdigest()[:20]
     d = cache_dir()
     so, failed = os.path.join(d, f"tbnn_{key}.so"), os.path.join(d, f"tbnn_{key}.fail")
     if os.path.exists(so):
@@ -132,7 +133,7 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                 with open(src, "w") as f:
                     f.write(source(dims, hact, lact, bern, fam))
                 cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
-                cmd += NARROW_FLAGS              # as build.py compiles the kernels (VGPR-form chain MFMAs)
+                cmd += NARROW_FLAGS + extra      # as build.py compiles the kernels (VGPR-form chain MFMAs)
                 cmd += ["-o", tmp, src]
                 if verbose:
                     print(" ".join(cmd), flush=True)
