@@ -44,10 +44,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    # link next to the target and rename: a rank that waits for the file (bench.py) never maps a half-written library
+    tmp = OUT + f".{os.getpid()}.tmp"
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
+    os.replace(tmp, OUT)
     return OUT
 
 
