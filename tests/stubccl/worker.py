@@ -78,6 +78,9 @@ def main():
             if spec.n_hypers:                                # the hyper transition reads the all-reduced statistic
                 h = ch.hyper_step(1e-5, 5, p0=np.random.default_rng(6).standard_normal(spec.n_hypers).astype(np.float32), log_u=-1e30)
                 res[name + "_hlar"] = np.array(h["log_accept_ratio"]); res[name + "_eta"] = ch.get_hypers()
+                # and the transition after it starts from the cached state refreshed for the new eta (no pass over the rows)
+                o3 = ch.hmc_step(1e-5, 3, p0=p0, log_u=-1e30, trace=True)
+                res[name + "_trace3"] = np.asarray(o3["trace_logp"]); res[name + "_theta3"] = ch.get_state()
             comm.close(); ch.close()
     else:
         raise SystemExit("unknown mode " + mode)

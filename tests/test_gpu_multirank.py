@@ -92,9 +92,13 @@ def test_row_shard_two_ranks(tmp_path, native):
         np.testing.assert_array_equal(ranks[0][name + "_g"], ranks[1][name + "_g"])
         if spec.n_hypers:
             h = ref.hyper_step(1e-5, 5, p0=np.random.default_rng(6).standard_normal(spec.n_hypers).astype(np.float32), log_u=-1e30)
+            o3 = ref.hmc_step(1e-5, 3, p0=p0, log_u=-1e30, trace=True)
+            th3 = ref.get_state()
             for r in ranks:
                 assert abs(float(r[name + "_hlar"]) - h["log_accept_ratio"]) <= 2e-3 + 1e-5 * abs(h["log_accept_ratio"])
                 np.testing.assert_allclose(r[name + "_eta"], ref.get_hypers(), rtol=1e-5, atol=1e-6)
+                np.testing.assert_allclose(r[name + "_trace3"], o3["trace_logp"], rtol=2e-7, atol=1e-4)
+                np.testing.assert_allclose(r[name + "_theta3"], th3, rtol=0, atol=4e-6 * max(1.0, np.abs(th3).max()))
         # and the chain they walked is the oracle's: value and gradient of the whole data set
         lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)
         assert abs(float(ranks[0][name + "_lp"]) - lp64) <= 4e-6 * abs(lp64) + 1e-3
