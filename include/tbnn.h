@@ -152,6 +152,11 @@ int tbnn_set_epoch(tbnn_handle h, uint32_t epoch);
 /* record a hipEvent pair around every stride-th fused fwd+bwd launch on the
  * chain's stream (fills fwdbwd_us); stride <= 0 turns it off */
 int tbnn_set_profiling(tbnn_handle h, int stride);
+/* diagnostic (tools/stamps.py): launches the narrow fused kernel three times at the current state and returns the
+ * in-kernel stamps of workgroup 0 of the last launch: out16[0..7] = 100 MHz wall clock at start, prologue done, first
+ * tile done, tile loop done, end, cooperative tail done, staging done, tile slabs done; out16[8..15] = the shader clock at
+ * the same points.  Narrow ahead-of-time kernels only; the chain state is not touched. */
+int tbnn_debug_stamps(tbnn_handle h, uint64_t* out16);
 
 /* ---- predictions and metrics over the staged rows: no host traffic but the result.
  * network.__init__ stages the validation set next to the training set (network.py:47-51). ---- */

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("tbnn_debug_draw", C.c_int, [_H, C.c_uint32, C.c_uint32, C.c_int32, _fp, _fp]),
     ("tbnn_set_epoch", C.c_int, [_H, C.c_uint32]),
     ("tbnn_set_profiling", C.c_int, [_H, C.c_int]),
+    ("tbnn_debug_stamps", C.c_int, [_H, C.POINTER(C.c_uint64)]),
     ("tbnn_set_validation", C.c_int, [_H, _fp, _fp, C.c_int64]),
     ("tbnn_predict", C.c_int, [_H, C.c_int, _fp, _fp]),
     ("tbnn_forward_many", C.c_int, [_H, _fp, C.c_int32, C.c_int64, C.c_int, _fp, C.c_int64, _fp]),

@@ -51,9 +51,11 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     float* __restrict__ q, float* __restrict__ p, float* __restrict__ g,
     const int* __restrict__ imgmap, float* __restrict__ qimg, float* __restrict__ gd = nullptr)
 {
-    // gd (optional): the DATA term of the gradient alone (the reduced slabs, before the prior is added): kept next to the
-    // state so that a hyper transition, which changes only the prior and the likelihood's sigma, can refresh the cached
-    // (log-prob, gradient) of the current state without another pass over the rows (k_refresh_after_hyper)
+    // gd (optional): the DATA term of the gradient alone (the reduced slabs, before the prior is added), stored SIGMA-FREE
+    // (times sigma^2 for the Gaussian likelihood): kept next to the state so that a hyper transition, which changes only
+    // the prior and the likelihood's sigma, can refresh the cached (log-prob, gradient) of the current state without
+    // another pass over the rows (k_refresh_grad_after_hyper) -- and without compounding a rescaling factor over
+    // consecutive accepted hyper steps
     __shared__ float4 part[UPD_GROUPS][UPD_COLS];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int c4 = blockIdx.x * UPD_COLS + tx;          // float4 column
@@ -113,7 +115,10 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     if (!fin) return;
     const int j = jf;
     float gj = ty == 0 ? gs.x : ty == 1 ? gs.y : ty == 2 ? gs.z : gs.w;
-    if (mode != UPD_FIRST && gd) gd[j] = gj;
+    if (mode != UPD_FIRST && gd) {
+        const float sg = nd.lik == TBNN_LIK_GAUSSIAN ? lik_sigma(nd, eta) : 1.f;
+        gd[j] = gj * (sg * sg);
+    }
     if (mode != UPD_FIRST) gj += prior_grad(prior, loc, scale, q_j);
     if (mode == UPD_GRAD_ONLY) { g[j] = gj; return; }
     if (mode == UPD_FIRST) {
@@ -135,10 +140,10 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     }
 }
 
-// row-sharded chains: sum the per-workgroup slabs into ONE dense row (the all-reduce operand);
+// row-sharded chains: sum the per-workgroup slabs into ONE dense row (the all-reduce operand: doubles when outd is given);
 // 64 parameters x 4 slab groups per block, fixed order
 __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slabs, int nslab, int pitch, int P,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, double* __restrict__ outd = nullptr) {
     __shared__ float part[4][64];
     const int x = threadIdx.x, y = threadIdx.y, j = blockIdx.x * 64 + x;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -153,7 +158,32 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
     }
     part[y][x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (y == 0 && j < P) out[j] = (part[0][x] + part[1][x]) + (part[2][x] + part[3][x]);
+    if (y == 0 && j < P) {
+        const float v = (part[0][x] + part[1][x]) + (part[2][x] + part[3][x]);
+        if (out) out[j] = v;
+        if (outd) outd[j] = (double)v;
+    }
+}
+
+// row-sharded chains: the operand of the ONE all-reduce per fused pass -- buf[0..P) = the dense gradient row as doubles
+// (row == null: k_slab_reduce has already written them), buf[P] = this rank's statistic summed over its workgroups
+__global__ __launch_bounds__(256) void k_shard_pack(int P, const float* __restrict__ row, const double* __restrict__ pstat, int nstat,
+                                                     double* __restrict__ buf) {
+    __shared__ double red[4];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row && j < P) buf[j] = (double)row[j];
+    if (blockIdx.x == 0) {
+        double st = 0.0;
+        for (int w = threadIdx.x; w < nstat; w += blockDim.x) st += pstat[w];
+        st = block_sum(st, red);
+        if (threadIdx.x == 0) buf[P] = st;
+    }
+}
+__global__ __launch_bounds__(256) void k_shard_unpack(int P, const double* __restrict__ buf, float* __restrict__ row,
+                                                       double* __restrict__ stat_red) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < P) row[j] = (float)buf[j];
+    if (j == 0) stat_red[0] = buf[P];
 }
 
 // plain copy (tbnn_get_state: theta into device-mapped pinned host memory)
@@ -291,22 +321,21 @@ __global__ __launch_bounds__(256) void k_commit(
     if (j < P) { q_cur[j] = q[j]; g_cur[j] = g[j]; gd_cur[j] = gd[j]; }
 }
 
-// After an ACCEPTED hyper transition (eta_old -> eta): the prediction does not depend on eta, so the data-term gradient at
-// the current state only rescales with the likelihood's sigma (Gaussian: 1/sigma^2; fixed-sd / Bernoulli: unchanged) and
-// the statistic is the cached one; the prior terms are O(P).  Replaces a whole fused pass over the rows per epoch.
+// After an ACCEPTED hyper transition (-> eta): the prediction does not depend on eta, so the data-term gradient at the
+// current state only rescales with the likelihood's sigma (Gaussian: 1/sigma^2; fixed-sd / Bernoulli: unchanged) and the
+// statistic is the cached one; the prior terms are O(P).  Replaces a whole fused pass over the rows per epoch.  gd_cur is
+// the sigma-free data term k_update stored: it is only READ here, so nothing compounds over repeated hyper steps.
 __global__ __launch_bounds__(256) void k_refresh_grad_after_hyper(
-    NetDev nd, const float* __restrict__ eta_old, const float* __restrict__ eta, const float* __restrict__ q_cur,
-    float* __restrict__ gd_cur, float* __restrict__ g_cur)
+    NetDev nd, const float* __restrict__ eta, const float* __restrict__ q_cur,
+    const float* __restrict__ gd_cur, float* __restrict__ g_cur)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nd.P) return;
-    const float so = lik_sigma(nd, eta_old), sn = lik_sigma(nd, eta);
-    const float scl = nd.lik == TBNN_LIK_GAUSSIAN ? (so / sn) * (so / sn) : 1.f;
+    const float sn = lik_sigma(nd, eta);
+    const float inv_var = nd.lik == TBNN_LIK_GAUSSIAN ? 1.f / (sn * sn) : 1.f;
     int prior; float loc, scale;
     prior_params(nd, eta, j, prior, loc, scale);
-    const float gd = gd_cur[j] * scl;
-    gd_cur[j] = gd;
-    g_cur[j] = gd + prior_grad(prior, loc, scale, q_cur[j]);
+    g_cur[j] = gd_cur[j] * inv_var + prior_grad(prior, loc, scale, q_cur[j]);
 }
 // copies the record for the host, then rolls cur <- new when accepted
 __global__ void k_commit_scal(Scal* __restrict__ sc, Scal* __restrict__ host_copy) {

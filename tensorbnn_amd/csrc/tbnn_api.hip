@@ -71,6 +71,7 @@ struct tbnn_ctx {
     int nslab = 0;                        // gradient slabs k_update reduces (wide: 1, already reduced)
     // row-sharded chain (tbnn_set_row_shard): all-reduce of the dense data-term gradient row + statistic
     tbnn_comm* shard = nullptr; long n_total = 0; float* grow = nullptr; double* pstat_red = nullptr;
+    double* shard_buf = nullptr;          // the all-reduce operand: P gradient values + the statistic, as doubles
     int* imgmap = nullptr; float* qimg = nullptr; float* qimg_cur = nullptr; int img_floats = 0;   // fast kernel: padded weight images
     size_t scratchPerWG = 0;
     float* pin_dev = nullptr;              // device-side address of pin
@@ -78,6 +79,7 @@ struct tbnn_ctx {
                                            // into pageable memory costs ~180 us, through pinned memory ~15 us
     Scal* sc = nullptr; Scal* sc_host = nullptr; Scal* sc_out = nullptr;   // sc_out: device copy for host
     double* trace = nullptr; int trace_cap = 0;
+    Scal* d_recs = nullptr; Scal* h_recs = nullptr; int recs_cap = 0;     // tbnn_hmc_run: per-epoch records (pooled)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int profile = 0; long launch_no = 0;   // profile: event pair around every profile-th fwd+bwd launch
     std::vector<hipEvent_t> pev; size_t pev_used = 0;   // pooled events: created once, re-used after every drain (no allocator in the timed loop)
@@ -182,12 +184,15 @@ extern "C" int tbnn_destroy(tbnn_handle h) {
     for (float* b : bufs) if (b) hipFree(b);
     if (h->pstat) hipFree(h->pstat);
     if (h->pstat_red) hipFree(h->pstat_red);
+    if (h->shard_buf) hipFree(h->shard_buf);
     if (h->imgmap) hipFree(h->imgmap);
     if (h->qimg) hipFree(h->qimg);
     if (h->qimg_cur) hipFree(h->qimg_cur);
     if (h->sc) hipFree(h->sc);
     if (h->sc_out) hipFree(h->sc_out);
     if (h->trace) hipFree(h->trace);
+    if (h->d_recs) hipFree(h->d_recs);
+    if (h->h_recs) hipHostFree(h->h_recs);
     if (h->sc_host) hipHostFree(h->sc_host);
     if (h->pin) hipHostFree(h->pin);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -311,7 +316,8 @@ extern "C" int tbnn_set_profiling(tbnn_handle h, int stride) {
     h->profile = stride > 0 ? stride : 0;
     if (h->profile) {                       // fill the event pool now, outside any timed loop
         HIPCHK(hipSetDevice(h->device));
-        while (h->pev.size() < 128) { hipEvent_t e = nullptr; HIPCHK(hipEventCreate(&e)); h->pev.push_back(e); }
+        // 256 pairs: more than any tbnn_hmc_run of bench.py profiles between two drains
+        while (h->pev.size() < 512) { hipEvent_t e = nullptr; HIPCHK(hipEventCreate(&e)); h->pev.push_back(e); }
     }
     return 0;
 }
@@ -357,6 +363,8 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
     HIPCHK(hipMemset(h->pstat_red, 0, (size_t)PSTAT_CAP * sizeof(double)));
     if (h->grow) { hipFree(h->grow); h->grow = nullptr; }
     HIPCHK(hipMalloc(&h->grow, (size_t)h->pitch * sizeof(float)));
+    if (h->shard_buf) { hipFree(h->shard_buf); h->shard_buf = nullptr; }
+    HIPCHK(hipMalloc(&h->shard_buf, ((size_t)nd.P + 1) * sizeof(double)));
     return 0;
 }
 
@@ -530,7 +538,7 @@ extern "C" int tbnn_set_row_shard(tbnn_handle h, tbnn_comm_handle c, int64_t n_t
 }
 // rows that normalise the likelihood / entries of the statistic buffer to sum
 static inline long rows_total(const tbnn_ctx* h) { return h->shard ? h->n_total : h->n; }
-static inline int stat_entries(const tbnn_ctx* h) { return h->shard ? PSTAT_CAP : h->grid; }
+static inline int stat_entries(const tbnn_ctx* h) { return h->shard ? 1 : h->grid; }      // sharded: pstat_red[0] is the all-reduced sum
 // local statistic buffer: entries >= grid stay zero; the all-reduced copy is separate (ranks may have different grids)
 static inline const double* stat_ptr(const tbnn_ctx* h) { return h->shard ? h->pstat_red : h->pstat; }
 // the gradient slabs k_update reduces
@@ -574,15 +582,19 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
                            h->dY, h->n, h->scratch, h->scratchPerWG, h->slabs, h->pitch, h->pstat);
     }
     if (h->shard) {
-        // dense data-term gradient row (the wide path already has one) + statistic, summed over the ranks in place
-        float* row = h->slabs;
-        if (h->wide_id < 0) {
-            hipLaunchKernelGGL(k_slab_reduce, dim3((h->nd.P + 63) / 64), dim3(64, 4), 0, h->stream, (const float*)h->slabs, h->nslab,
-                               h->pitch, h->nd.P, h->grow);
-            row = h->grow;
-        }
-        NCCLCHK(g_rccl.AllReduce(row, row, (size_t)h->nd.P, ncclFloat, ncclSum, h->shard->comm, h->stream));
-        NCCLCHK(g_rccl.AllReduce(h->pstat, h->pstat_red, (size_t)PSTAT_CAP, ncclDouble, ncclSum, h->shard->comm, h->stream));
+        // ONE collective per fused pass: the dense data-term gradient row (P values; the wide path already has one) and the
+        // statistic, summed to one value on the device, travel together as P + 1 doubles (the sum over the ranks is then
+        // taken in double and rounded once; at configs[1]-class step times a second small all-reduce would cost as much as
+        // the step), summed over the ranks in place, unpacked into the row k_update reads and pstat_red[0]
+        float* row = h->wide_id < 0 ? h->grow : h->slabs;
+        const int P = h->nd.P;
+        if (h->wide_id < 0)
+            hipLaunchKernelGGL(k_slab_reduce, dim3((P + 63) / 64), dim3(64, 4), 0, h->stream, (const float*)h->slabs, h->nslab,
+                               h->pitch, P, (float*)nullptr, h->shard_buf);
+        hipLaunchKernelGGL(k_shard_pack, dim3((P + 255) / 256), dim3(256), 0, h->stream, P, h->wide_id < 0 ? (const float*)nullptr : (const float*)row,
+                           (const double*)h->pstat, h->grid, h->shard_buf);
+        NCCLCHK(g_rccl.AllReduce(h->shard_buf, h->shard_buf, (size_t)P + 1, ncclDouble, ncclSum, h->shard->comm, h->stream));
+        hipLaunchKernelGGL(k_shard_unpack, dim3((P + 255) / 256), dim3(256), 0, h->stream, P, (const double*)h->shard_buf, row, h->pstat_red);
     }
     if (prof) hipEventRecord(b, h->stream);
     HIPCHK(hipGetLastError());
@@ -935,22 +947,29 @@ extern "C" int tbnn_hmc_run(tbnn_handle h, float eps, int32_t L, int32_t n_epoch
     if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
     if (L < 1 || n_epochs < 1) return fail(-1, "L and n_epochs must be >= 1");
     HIPCHK(hipSetDevice(h->device));
-    Scal* d_recs = nullptr;
-    HIPCHK(hipMalloc(&d_recs, (size_t)n_epochs * sizeof(Scal)));
+    // per-epoch records: a pooled device buffer and a pooled pinned host mirror (no allocator call -- hipFree synchronises
+    // the device -- inside a caller's timed loop once the pool has grown to the largest n_epochs seen)
+    if (h->recs_cap < n_epochs) {
+        if (h->d_recs) hipFree(h->d_recs);
+        if (h->h_recs) hipHostFree(h->h_recs);
+        h->d_recs = nullptr; h->h_recs = nullptr; h->recs_cap = 0;
+        const int cap = std::max(n_epochs, 64);
+        HIPCHK(hipMalloc(&h->d_recs, (size_t)cap * sizeof(Scal)));
+        HIPCHK(hipHostMalloc(&h->h_recs, (size_t)cap * sizeof(Scal)));
+        h->recs_cap = cap;
+    }
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int e = 0; e < n_epochs; ++e) {
-        int rc = enqueue_transition(h, eps, L, nullptr, nullptr, nullptr, d_recs + e);
-        if (rc) { hipFree(d_recs); return rc; }
+        int rc = enqueue_transition(h, eps, L, nullptr, nullptr, nullptr, h->d_recs + e);
+        if (rc) return rc;
     }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
-    std::vector<Scal> recs(n_epochs);
-    HIPCHK(hipMemcpyAsync(recs.data(), d_recs, (size_t)n_epochs * sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_recs, h->d_recs, (size_t)n_epochs * sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1);
     const float fb = h->profile ? drain_profile(h) : 0.f;
     if (outs)
-        for (int e = 0; e < n_epochs; ++e) fill_out(recs[e], L, ms * 1000.f / n_epochs, fb, outs + e);
-    hipFree(d_recs);
+        for (int e = 0; e < n_epochs; ++e) fill_out(h->h_recs[e], L, ms * 1000.f / n_epochs, fb, outs + e);
     return 0;
 }
 
@@ -1006,8 +1025,8 @@ extern "C" int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const fl
         static const bool full = getenv("TBNN_HYPER_FULL_REFRESH") && atoi(getenv("TBNN_HYPER_FULL_REFRESH"));
         if (full || !h->cur_valid) h->cur_valid = false;
         else {
-            hipLaunchKernelGGL(k_refresh_grad_after_hyper, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd, (const float*)h->eta_prev,
-                               (const float*)h->eta, (const float*)h->q_cur, h->gd_cur, h->g_cur);
+            hipLaunchKernelGGL(k_refresh_grad_after_hyper, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd,
+                               (const float*)h->eta, (const float*)h->q_cur, (const float*)h->gd_cur, h->g_cur);
             launch_energy(h, EN_REFRESH, h->eta, h->q_cur, nullptr);
             HIPCHK(hipGetLastError());
         }
@@ -1042,9 +1061,9 @@ extern "C" int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, 
     return 0;
 }
 
-// diagnostic: 100 MHz wall-clock stamps of workgroup 0 inside one fused launch
-// [0] start, [1] prologue done, [2] first tile done, [3] tile loop done, [4] end
+// diagnostic: stamps of workgroup 0 inside one fused launch (include/tbnn.h)
 extern "C" int tbnn_debug_stamps(tbnn_handle h, uint64_t* out5) {
+    if (!out5) return fail(-1, "null out16");
     NEED(h);
     if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0 || h->jit || !h->dX) return fail(-1, "debug_stamps: narrow fast kernel + data required");
     HIPCHK(hipSetDevice(h->device));

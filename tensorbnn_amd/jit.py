@@ -18,6 +18,7 @@ Requirements common to both: one activation for all hidden layers; dense layers 
 """
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from typing import Optional, Sequence
@@ -152,7 +153,12 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                     os.remove(tmp)
                 # a compiler diagnostic ("error:") with a normal exit status is a property of the shape; anything else
                 # (killed, out of disk, exec failure) is transient and must not be remembered
-                if rc < 0 or "error:" not in err:
+                # -- and so is a driver-level "error:" without a source location (an OOM-killed clang child: "clang: error:
+                # unable to execute command: Killed"; a full disk: "error: unable to open output file"): only a located
+                # diagnostic (<file>:<line>:<col>: error:) says something about the shape
+                located = re.search(r"^[^\s:][^:\n]*:\d+:\d+: (fatal )?error:", err, re.M) is not None
+                transient = re.search(r"unable to execute command|No space left|Killed|signal|unable to open output file|Cannot allocate memory", err) is not None
+                if rc < 0 or not located or transient:
                     deterministic = False
                 log.append(f"[{fam}] rc={rc}\n{err[-2000:]}")
             if deterministic:

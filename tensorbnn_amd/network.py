@@ -83,6 +83,11 @@ class network(object):
             self._dense[-1][2] = int(layer.act_kind)
         self.layers.append(layer)
         if layer.numHyperTensors > 0:
+            # a layer added after a first train(): the likelihood's hypers sit at the tail of hyperStates (appended by
+            # train); take them off so that the layer's rows go where the eta layout expects them -- train() re-appends
+            if self._lik_hypers:
+                del self.hyperStates[-self._lik_hypers:]
+                self._lik_hypers = 0
             for row in np.asarray(layer.hypers, dtype=np.float32):          # :189-191: one [1]-tensor per row
                 self.hyperStates.append(np.asarray(row, dtype=np.float32).reshape(1))
         if self._chain is not None:       # the architecture changed: the old chain's device buffers go now, not at GC time

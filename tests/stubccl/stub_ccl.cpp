@@ -49,9 +49,12 @@ bool barrier(StubComm* c) {
 }
 size_t dtype_bytes(ncclDataType_t t) { return t == ncclFloat ? 4 : t == ncclDouble ? 8 : 0; }
 std::atomic<int> g_ids{0};
+std::atomic<int> g_allreduce_calls{0};
 }  // namespace
 
 extern "C" {
+// test hook: all-reduce calls this process has made (the row-sharded chain must issue exactly one per fused pass)
+int stubccl_allreduce_calls() { return g_allreduce_calls.load(); }
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "ok" : "stub collective library error"; }
 
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
@@ -113,6 +116,7 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataT
     StubComm* c = (StubComm*)comm;
     const size_t b = count * dtype_bytes(dt);
     if (!b || b > SLOT_BYTES || op != ncclSum) return ncclInvalidArgument;
+    g_allreduce_calls.fetch_add(1);
     if (hipStreamSynchronize(st) != hipSuccess) return ncclUnhandledCudaError;
     if (hipMemcpy(c->seg->slot[c->rank], send, b, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
     if (!barrier(c)) return ncclSystemError;

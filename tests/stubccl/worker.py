@@ -67,7 +67,11 @@ def main():
             comm = nat.Comm(ch, world, rank, uid)
             lo, hi = parallel.shard_rows(ch, X, Y, comm)
             ch.set_state(theta); ch.set_hypers(eta)
+            import ctypes
+            stub = ctypes.CDLL(os.environ["TBNN_RCCL_LIB"], mode=ctypes.RTLD_GLOBAL)      # the instance libtbnn resolved
+            c0 = stub.stubccl_allreduce_calls()
             lp, g, st = ch.logp_grad(theta, eta)
+            res[name + "_allreduce_per_pass"] = np.array(stub.stubccl_allreduce_calls() - c0)
             p0 = np.random.default_rng(5).standard_normal(spec.n_params).astype(np.float32)
             outs = [ch.hmc_step(1e-5, 4, p0=p0, log_u=-1e30, trace=True), ch.hmc_step(1e-5, 3)]      # injected, then free-running
             res[name + "_rows"] = np.array([lo, hi]); res[name + "_kernel"] = np.array(ch.kernel_name)

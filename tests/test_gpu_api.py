@@ -133,14 +133,14 @@ def test_bench_multi_rank_control_flow(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29500 + (os.getpid() % 2000)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--sampling-step", "3"]
+    # plain `bench.py --gpus 2`, as the driver runs it: bench.py starts its own two ranks (torch.distributed.run as a child)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--sampling-step", "3"]
     # torch's collectives over gloo (two ranks on one GPU); the checkpoint gather is the native tbnn_gather_samples, its
     # collective library pointed at the test stub (RCCL itself refuses two ranks on one device)
     from test_gpu_multirank import build_stub
     env = dict(os.environ, TBNN_BENCH_SINGLE_GPU="1", OMP_NUM_THREADS="4", TBNN_RCCL_LIB=build_stub())
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

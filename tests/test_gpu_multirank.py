@@ -78,6 +78,7 @@ def test_row_shard_two_ranks(tmp_path, native):
         rows = [tuple(r[name + "_rows"]) for r in ranks]
         assert rows[0][0] == 0 and rows[0][1] == rows[1][0] and rows[1][1] == n and rows[0][1] % 16 == 0, rows
         for r in ranks:
+            assert int(r[name + "_allreduce_per_pass"]) == 1               # gradient row + statistic in ONE collective
             assert str(r[name + "_kernel"]) == ref.kernel_name
             assert abs(float(r[name + "_lp"]) - lp0) <= 1e-7 * abs(lp0) + 1e-6
             assert abs(float(r[name + "_st"]) - st0) <= 1e-9 * abs(st0)

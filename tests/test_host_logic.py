@@ -120,6 +120,35 @@ def test_train_loop_order_and_file_format(tmp_path, monkeypatch):
         assert open(tmp_path / "ora" / f, "rb").read() == open(tmp_path / "run" / f, "rb").read(), f
 
 
+def test_add_after_train_keeps_eta_layout(tmp_path, monkeypatch):
+    """a layer added after a first train() must not end up behind the likelihood's hypers -- eta is
+    (layer rows ..., likelihood hypers) whatever the call order"""
+    from tensorbnn_amd.layer import DenseLayer
+    from tensorbnn_amd.likelihood import GaussianLikelihood
+    net = build_net()
+    seen = []
+
+    def chain_for(self, likelihood=None):
+        H = sum(h.size for h in self.hyperStates)
+        c = FakeChain(sum(s.size for s in self.states), H)
+        seen.append(c)
+        return c
+
+    monkeypatch.setattr(type(net), "_ensure_chain", chain_for)
+    net.setupMCMC(stepSizeStart=1e-3, leapfrogStart=5, leapfogMin=5, leapFrogMax=6, burnin=2, averagingSteps=2)
+    monkeypatch.chdir(tmp_path)
+    net.train(1, 1, GaussianLikelihood(sd=0.1), adjustHypers=False, verbose=False)
+    assert seen[-1].H == 13 and seen[-1].ebase[-1] == pytest.approx(0.1 ** 0.5)
+    net._dense[-1][2] = 1                                   # (test double: pretend a Relu followed the last layer)
+    lay = DenseLayer(1, 1, seed=4000)
+    lay.hypers = np.asarray(lay.hypers, np.float32) + 7.0   # recognisable rows
+    net.add(lay)
+    net.train(1, 1, GaussianLikelihood(sd=0.1), adjustHypers=False, verbose=False)
+    eta = seen[-1].ebase
+    assert eta.size == 17 and eta[-1] == pytest.approx(0.1 ** 0.5)                 # likelihood hyper last
+    np.testing.assert_allclose(eta[12:16], np.asarray(lay.hypers, np.float32).reshape(-1))    # the new layer's rows before it
+
+
 def test_dual_averaging_matches_oracle():
     net = build_net()
     net.setupMCMC(hyperStepSize=0.01, burnin=100)
@@ -308,3 +337,50 @@ def test_bench_host_helpers():
     logical, physical = bench.host_cpus()
     assert 1 <= physical <= logical
     assert set(bench.CONFIG_KEY) >= {"c1", "c2", "c4", "c5"}
+
+
+def test_bench_line_fits_driver_tail():
+    """the stdout line of bench.py keeps every config's value / roofline fraction / CPU baseline within 2 KB (the driver's
+    record keeps a 2-KB tail); checked on the committed full record of round 2 with the rocprof fields filled in"""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r02b_bench_full.json")))
+    for r in [full] + list(full["secondary"].values()):
+        if r.get("roofline") and r["roofline"].get("frac") is not None:
+            r["roofline"].update(frac_rocprof=0.4291, rocprof_kernel_us=4849.123, rocprof_source="profiles/r03z_c4_kernel_stats.csv")
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) <= 2300
+    tail = text[-2048:]
+    for key in ("configs[3]", "configs[4]", "configs[4]g", "configs[0]"):
+        assert f'"{key}": {{"value"' in tail
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line
+    assert line["roofline"]["frac_rocprof"] == 0.4291 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with no launcher around it starts torch.distributed.run --nproc-per-node N as a child
+    (never exec) with the same arguments"""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

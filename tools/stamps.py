@@ -6,7 +6,6 @@ import ctypes as C, numpy as np
 from tensorbnn_amd import _native as nat
 from tensorbnn_amd.workloads import synth_problem
 layers, lik, X, Y, th, eta = synth_problem([5, 50, 50, 50, 1], 114688)
-nat.lib.tbnn_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 for n in (16384, 98304, 100000, 114688):
     ch = nat.Chain(layers, likelihood=lik); ch.set_data(X[:n], Y[:n]); ch.set_state(th); ch.set_hypers(eta)
     out = (C.c_uint64 * 16)()
