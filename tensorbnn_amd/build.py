@@ -5,14 +5,15 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "tbnn_api.hip"), os.path.join(HERE, "csrc", "tbnn_wide.hip"),
-       os.path.join(HERE, "csrc", "adapter.cpp")]
+       os.path.join(HERE, "csrc", "tbnn_mid.hip"), os.path.join(HERE, "csrc", "adapter.cpp")]
 # both kernel families: the chain MFMAs write ArchVGPRs (their results feed the VALU), dW accumulators are pinned to
 # AccVGPRs by hand (kernels_fast.hpp, mfma16_acc)
 NARROW_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 PER_SOURCE_FLAGS = {"tbnn_api.hip": NARROW_FLAGS,
                     # experiments: TBNN_WIDE_FLAGS adds flags to the wide translation unit, TBNN_WIDE_AGPR_FORM=1 drops the VGPR form there
                     "tbnn_wide.hip": ([] if os.environ.get("TBNN_WIDE_AGPR_FORM") == "1" else NARROW_FLAGS)
-                                     + os.environ.get("TBNN_WIDE_FLAGS", "").split()}
+                                     + os.environ.get("TBNN_WIDE_FLAGS", "").split(),
+                    "tbnn_mid.hip": NARROW_FLAGS + os.environ.get("TBNN_MID_FLAGS", "").split()}
 OBJ_DIR = os.path.join(HERE, "_obj")
 OUT = os.path.join(HERE, "libtbnn.so")
 

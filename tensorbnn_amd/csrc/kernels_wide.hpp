@@ -32,6 +32,8 @@
 #include "kernels_fast.hpp"
 #include "wide_api.hpp"
 
+#ifndef TBNN_SFOR_DEFINED
+#define TBNN_SFOR_DEFINED
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
 template <int I, int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -39,6 +41,15 @@ __device__ __forceinline__ void sfor(F&& f) {
 }
 #define SFOR_LAMBDA(name) [&](auto name##_) __attribute__((always_inline))
 #define SFOR_VAL(name) decltype(name##_)::value
+// y = sum over the 16 lanes of a lane group (same lane >> 4)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+#endif
 
 #define WIDE_WAVES 4
 // diagnostic build only (-DWIDE_STAMPS): shader-clock stamps of workgroup 0 / wave 0 during its SECOND block
@@ -180,15 +191,6 @@ struct WideCfg {
     static constexpr int DW_OCC = (WIDE_DW_OCC_MAX >= 2 && 2 * WIDE_RING * DW_SLOT_FLOATS * 4 <= 150 * 1024 &&
                                    4 * maxDWT() + 4 * DW_NGW * WIDE_DW_PD + 48 <= 232) ? 2 : 1;
 };
-
-// y = sum over the 16 lanes of a lane group (same lane >> 4)
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    return v;
-}
 
 // ---------------------------------------------------------------------------------------------
 // k_chain_wide

@@ -19,6 +19,7 @@
 #include "kernels_fast.hpp"
 #include "kernels_fast3.hpp"
 #include "wide_api.hpp"
+#include "mid_api.hpp"
 #include "fused_ops.hpp"
 #include <mutex>
 
@@ -51,6 +52,7 @@ struct tbnn_ctx {
     int kernel = TBNN_KERNEL_GENERIC;     // resolved variant
     int fast_id = -1;
     int fast_ver = 1;                     // 1: kernels_fast.hpp, 3: kernels_fast3.hpp (fringe units off the 16x16 tiles)
+    int mid_id = -1;                      // >= 0: kernels_mid.hpp (mid-width fused kernel; narrow-family workspace and launch signature)
     std::string kernel_name;
     // data
     float* dX = nullptr; float* dY = nullptr; bool own_data = false; long n = 0;
@@ -156,7 +158,7 @@ extern "C" int tbnn_fused_kernel_available(const tbnn_net_desc* desc) {
     NetDev nd;
     int rc = build_netdev(desc, nd);
     if (rc) return rc;
-    if (fast_lookup(nd) >= 0) return 1;
+    if (fast_lookup(nd) >= 0 || mid_lookup(nd) >= 0) return 1;
     if (wide_lookup(nd) >= 0) return 2;
     return find_jit(nd) ? 3 : 0;
 }
@@ -252,9 +254,24 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
     h->kernel = TBNN_KERNEL_GENERIC; h->kernel_name = "generic";
     const int want = desc->kernel;
     const int fid = fast_lookup(nd);
-    const int wid = fid < 0 ? wide_lookup(nd) : -1;
-    const FusedOps* jo = (fid < 0 && wid < 0) ? find_jit(nd) : nullptr;
-    if (want == TBNN_KERNEL_FAST && fid < 0 && wid < 0 && !jo) return bail(-1, "TBNN_KERNEL_FAST requested but no specialised kernel covers this shape");
+    // TBNN_MID=0 (diagnostic / A-B runs): shapes both families cover take the wide path (two kernels through HBM)
+    const bool mid_on = !(getenv("TBNN_MID") && atoi(getenv("TBNN_MID")) == 0);
+    const int mid = (fid < 0 && mid_on) ? mid_lookup(nd) : -1;
+    const int wid = (fid < 0 && mid < 0) ? wide_lookup(nd) : -1;
+    const FusedOps* jo = (fid < 0 && mid < 0 && wid < 0) ? find_jit(nd) : nullptr;
+    if (want == TBNN_KERNEL_FAST && fid < 0 && mid < 0 && wid < 0 && !jo) return bail(-1, "TBNN_KERNEL_FAST requested but no specialised kernel covers this shape");
+    if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && mid >= 0) {
+        h->kernel = TBNN_KERNEL_FAST; h->mid_id = mid; h->kernel_name = mid_name(mid);
+        h->img_floats = mid_image_floats(mid);
+        std::vector<int> map(2 * (size_t)nd.P);
+        mid_image_map_id(mid, map.data());
+        HIPB(hipMalloc(&h->imgmap, map.size() * sizeof(int)));
+        HIPB(hipMemcpy(h->imgmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPB(hipMalloc(&h->qimg, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg_cur, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg, 0, (size_t)h->img_floats * sizeof(float)));       // padding stays zero for ever
+        HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
+    }
     if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && jo) {
         h->kernel = TBNN_KERNEL_FAST; h->jit = jo; h->kernel_name = jo->name;
         if (jo->family == TBNN_FAMILY_WIDE) { h->wide_id = 1000; jo->plan(16, &h->wplan); }
@@ -339,7 +356,7 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
         HIPCHK(hipMalloc(&h->wslabA, h->wplan.slabA_floats * sizeof(float)));
         HIPCHK(hipMalloc(&h->wslabB, h->wplan.slabB_floats * sizeof(float)));
     } else if (h->kernel == TBNN_KERNEL_FAST) {
-        grid = h->jit ? h->jit->grid(n) : fast_grid(h->fast_id, n);
+        grid = h->jit ? h->jit->grid(n) : (h->mid_id >= 0 ? mid_grid_id(h->mid_id, n) : fast_grid(h->fast_id, n));
         // test hook: a smaller grid puts small row counts into the many-rounds + cooperative-tail regime of the big ones
         if (const char* ge = getenv("TBNN_FAST_GRID")) { const int gg = atoi(ge); if (gg >= 1 && gg < grid) grid = gg; }
         h->scratchPerWG = 0;
@@ -573,6 +590,9 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
     } else if (h->kernel == TBNN_KERNEL_FAST && h->jit) {
         if (h->jit->launch(h->grid, h->stream, &h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat))
             return fail(-2, "registered kernel launch failed");
+    } else if (h->kernel == TBNN_KERNEL_FAST && h->mid_id >= 0) {
+        if (mid_launch(h->mid_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat))
+            return fail(-2, "mid kernel launch failed");
     } else if (h->kernel == TBNN_KERNEL_FAST) {
         int rc = h->fast_ver == 3 ? fast3_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat)
                                   : fast_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat);
@@ -673,7 +693,7 @@ extern "C" int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* et
 // the narrow family's forward-only kernel exists for fast3 shapes (registry or run-time compiled)
 static inline bool narrow_fwd_ok(const tbnn_ctx* h) {
     if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0) return false;
-    return h->jit ? h->jit->nforward != nullptr : h->fast_ver == 3;
+    return h->jit ? h->jit->nforward != nullptr : (h->mid_id >= 0 || h->fast_ver == 3);
 }
 // `nets` networks whose images lie img_stride floats apart -> outputs out_stride floats apart
 static int narrow_forward(tbnn_ctx* h, int nets, const float* imgs, long img_stride, const float* dX, long n, float* dOut, long out_stride) {
@@ -681,8 +701,9 @@ static int narrow_forward(tbnn_ctx* h, int nets, const float* imgs, long img_str
     // one network: fill the chip; an ensemble: the networks (grid.y) do that, fewer workgroups each re-use the image more
     const long cap = nets >= 64 ? 16 : (nets >= 8 ? 64 : 256);
     const int gx = (int)std::max<long>(1, std::min<long>(wgs, cap));
-    return h->jit ? h->jit->nforward(gx, nets, h->stream, imgs, img_stride, dX, n, dOut, out_stride)
-                  : fast3_forward(h->fast_id, gx, nets, h->stream, imgs, img_stride, dX, n, dOut, out_stride);
+    if (h->jit) return h->jit->nforward(gx, nets, h->stream, imgs, img_stride, dX, n, dOut, out_stride);
+    if (h->mid_id >= 0) return mid_forward(h->mid_id, gx, nets, h->stream, imgs, img_stride, dX, n, dOut, out_stride);
+    return fast3_forward(h->fast_id, gx, nets, h->stream, imgs, img_stride, dX, n, dOut, out_stride);
 }
 
 // forward pass of the network at the weights q (device) over dX[n][d_in] -> dOut[d_out][n], on h->stream
@@ -1065,7 +1086,7 @@ extern "C" int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, 
 extern "C" int tbnn_debug_stamps(tbnn_handle h, uint64_t* out5) {
     if (!out5) return fail(-1, "null out16");
     NEED(h);
-    if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0 || h->jit || !h->dX) return fail(-1, "debug_stamps: narrow fast kernel + data required");
+    if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0 || h->mid_id >= 0 || h->jit || !h->dX) return fail(-1, "debug_stamps: narrow fast kernel + data required");
     HIPCHK(hipSetDevice(h->device));
     unsigned long long* d = nullptr;
     HIPCHK(hipMalloc(&d, 16 * sizeof(unsigned long long)));

@@ -12,6 +12,8 @@ Family choice (first that compiles wins; a shape no family accepts is remembered
 runs on the generic kernel):
   * narrow (`k_fwd_bwd_fast3`, else `k_fwd_bwd_fast`): every dW accumulator in one wave's registers --
     fan-in <= 16, at most NARROW_TILES 16x16 dW tiles in total;
+  * mid (`k_fwd_bwd_mid`): >= 3 dense layers, <= 2 outputs, fan-in <= 32, at most 63 dW tiles over the MFMA
+    layers and weight images + operand blocks within 160 KB of LDS (`mid_fits`): one fused kernel, nothing through HBM;
   * wide (`k_chain_wide` + `k_dw_wide`): >= 3 dense layers, <= 2 outputs, fan-in <= 32,
     hidden widths <= 256.
 Requirements common to both: one activation for all hidden layers; dense layers only.
@@ -76,9 +78,29 @@ def families(dims) -> list:
         if dims[-1] <= 2 and nl >= 2:
             out.append("fast3")
         out.append("fast")
+    if nl >= 3 and dims[-1] <= 2 and dims[0] <= 32 and mid_fits(dims):
+        out.append("mid")
     if nl >= 3 and dims[-1] <= 2 and dims[0] <= 32 and max(dims[1:-1]) <= 256:
         out.append("wide")
-    return out
+    skip = {f for f in os.environ.get("TBNN_JIT_SKIP", "").split(",") if f}      # diagnostic / tests: e.g. "mid" forces the wide path
+    return [f for f in out if f not in skip]
+
+
+def mid_fits(dims) -> bool:
+    """the mid-width fused kernel (kernels_mid.hpp, MidCfg): every dW tile of the MFMA layers in one wave's AccVGPRs (<= 63
+    tiles) and the weight images + per-wave operand blocks in 160 KB of LDS"""
+    nl = len(dims) - 1
+    tr = lambda l: _cdiv(dims[l], 16)           # tiles of a_l (input of layer l)
+    ta = lambda l: _cdiv(dims[l] + 1, 16)
+    tiles = tr(1) * ta(0) + sum(tr(l + 1) * ta(l) for l in range(1, nl - 1))
+    if tiles > 63:
+        return False
+    r4 = lambda a: (a + 3) & ~3
+    perm = r4(tr(1) * _cdiv(dims[0], 16) * 256 + sum(16 * tr(l + 1) for l in range(nl - 1)) + dims[-1] * 16 * tr(nl - 1) + dims[-1])
+    img = r4(perm + sum(16 * tr(l + 1) * (16 * tr(l) + 4) for l in range(1, nl - 1)))
+    maxt = max(tr(l) for l in range(1, nl))
+    wave = (ta(0) + sum(ta(l) for l in range(1, nl - 1)) + maxt) * 256
+    return (img + 4 * wave) * 4 + 64 <= 160 * 1024
 
 
 def source(dims, hact, lact, bern, family) -> str:
@@ -86,6 +108,9 @@ def source(dims, hact, lact, bern, family) -> str:
     if family == "wide":
         return (f'#include "{CSRC}/jit_wide.hpp"\nusing S = {shape};\n'
                 'extern "C" int tbnn_jit_ops(FusedOps* o) { JitWide<S>::fill(o); return 0; }\n')
+    if family == "mid":
+        return (f'#include "{CSRC}/jit_mid.hpp"\nusing S = {shape};\n'
+                'extern "C" int tbnn_jit_ops(FusedOps* o) { JitMid<S>::fill(o); return 0; }\n')
     f3 = "true" if family == "fast3" else "false"
     return (f'#include "{CSRC}/jit_narrow.hpp"\nusing S = {shape};\n'
             f'extern "C" int tbnn_jit_ops(FusedOps* o) {{ JitNarrow<S, {f3}>::fill(o); return 0; }}\n')
@@ -106,7 +131,7 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
         return None
     dims, hact, lact, bern = sh
     extra = os.environ.get("TBNN_JIT_FLAGS", "").split()          # diagnostic builds (-DTBNN_WPAD=8 ...); part of the cache key
-    key = hashlib.sha1(f"{dims}|{hact}|{lact}|{bern}|{_sources_stamp()}|{extra}".encode()).hexdigest()[:20]
+    key = hashlib.sha1(f"{dims}|{hact}|{lact}|{bern}|{_sources_stamp()}|{extra}|{families(dims)}".encode()).hexdigest()[:20]
     d = cache_dir()
     so, failed = os.path.join(d, f"tbnn_{key}.so"), os.path.join(d, f"tbnn_{key}.fail")
     if os.path.exists(so):

@@ -75,7 +75,7 @@ def test_configs3_full_size_vs_c_restatement(native):
 
 def test_configs4_full_size_vs_c_restatement(native):
     """BASELINE configs[4]: 20->100->100->2 + Sigmoid, BernoulliLikelihood, n = 5e5 on the wide path"""
-    check_full_size(native, [20, 100, 100, 2], 500_000, o.LIK_BERNOULLI, eps=5e-5, L=3, family="wide<")
+    check_full_size(native, [20, 100, 100, 2], 500_000, o.LIK_BERNOULLI, eps=5e-5, L=3, family="mid<")
 
 
 def away_from(rng, lar, margin=0.05):

@@ -17,16 +17,22 @@ CASES = {
     "narrow_fringe2_sigmoid": dict(dims=[3, 34, 18, 1], n=600, act=o.ACT_SIGMOID, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN, name="jit-fast3<"),
     # narrow family, 3 outputs on the MFMA path (k_fwd_bwd_fast)
     "narrow_out3": dict(dims=[5, 20, 3], n=500, act=o.ACT_ELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN, name="jit-fast<"),
-    # wide family, image resident in LDS
-    "wide_resident": dict(dims=[8, 80, 80, 2], n=1200, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_BERNOULLI, name="jit-wide(resident)<"),
+    # mid-width fused kernel (k_fwd_bwd_mid): 5 x 6 + 5 dW tiles in one wave's AccVGPRs
+    "mid": dict(dims=[8, 80, 80, 2], n=1200, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_BERNOULLI, name="jit-mid<"),
+    # ... two middle layers, tanh
+    "mid_two_middle": dict(dims=[12, 40, 72, 24, 1], n=1000, act=o.ACT_TANH, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN, name="jit-mid<"),
+    # wide family, image resident in LDS (the mid family, which would take this shape first, switched off)
+    "wide_resident": dict(dims=[8, 80, 72, 2], n=1200, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_BERNOULLI, name="jit-wide(resident)<", skip="mid"),
     # wide family, streamed weights (3 x 128-wide)
     "wide_stream": dict(dims=[8, 128, 128, 128, 1], n=2000, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN, name="jit-wide<"),
 }
 
 
 @pytest.mark.parametrize("case", list(CASES))
-def test_jit_kernel_parity(native, case):
+def test_jit_kernel_parity(native, case, monkeypatch):
     c = CASES[case]
+    if "skip" in c:
+        monkeypatch.setenv("TBNN_JIT_SKIP", c["skip"])
     spec, X, Y, theta, eta = o.synth_problem(c["dims"], c["n"], c["act"], c["prior"], c["lik"])
     layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
     ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, kernel=native.KERNEL_FAST, jit=True)

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 CASES = {
     "narrow": ([5, 50, 50, 50, 1], 2000, o.ACT_RELU, o.LIK_GAUSSIAN),          # k_forward_fast3 (forward-only MFMA kernel)
     "generic": ([3, 7, 5, 2], 900, o.ACT_TANH, o.LIK_GAUSSIAN),                  # k_forward_generic
-    "wide_resident": ([20, 100, 100, 2], 1500, o.ACT_RELU, o.LIK_BERNOULLI),   # k_chain_wide<S, FWD>, weights in LDS
+    "mid": ([20, 100, 100, 2], 1500, o.ACT_RELU, o.LIK_BERNOULLI),             # k_fwd_bwd_mid<S, FWD>
+    "mid_two_middle": ([7, 33, 18, 50, 2], 800, o.ACT_RELU, o.LIK_GAUSSIAN),
     "wide_stream": ([10, 200, 200, 200, 1], 1100, o.ACT_RELU, o.LIK_GAUSSIAN), # k_chain_wide<S, FWD>, streamed weights
     "wide_ring_small": ([20, 32, 16, 48, 2], 700, o.ACT_SIGMOID, o.LIK_BERNOULLI),
 }
@@ -57,7 +58,8 @@ def test_predict_and_metrics(native, case):
 ENSEMBLE = {
     "narrow_batched": ([5, 50, 50, 50, 1], 1777, o.ACT_RELU, o.LIK_GAUSSIAN, 37),     # one launch, grid.y = network
     "narrow_tanh": ([1, 10, 10, 10, 1], 333, o.ACT_TANH, o.LIK_GAUSSIAN, 5),
-    "wide": ([20, 100, 100, 2], 900, o.ACT_RELU, o.LIK_BERNOULLI, 4),                 # per-network k_chain_wide<S, FWD>
+    "mid": ([20, 100, 100, 2], 900, o.ACT_RELU, o.LIK_BERNOULLI, 4),                  # one launch of k_fwd_bwd_mid<S, FWD>, grid.y = network
+    "wide": ([20, 32, 16, 48, 2], 700, o.ACT_SIGMOID, o.LIK_BERNOULLI, 3),            # per-network k_chain_wide<S, FWD>
     "generic": ([3, 7, 5, 2], 500, o.ACT_SIGMOID, o.LIK_GAUSSIAN, 6),
 }
 

@@ -61,6 +61,10 @@ CASES = {
     # wide-path test shapes (kernels_wide.hpp): ragged widths / widths that are multiples of 16
     "wide_t1": dict(dims=[3, 20, 36, 2], n=517, act=o.ACT_TANH, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN),
     "wide_t2": dict(dims=[20, 32, 16, 48, 2], n=1030, act=o.ACT_SIGMOID, prior=o.PRIOR_CAUCHY, lik=o.LIK_BERNOULLI),
+    # mid-width fused kernel's test shapes (kernels_mid.hpp): ragged widths / multiples of 16 / two middle layers
+    "mid_t1": dict(dims=[4, 24, 40, 1], n=517, act=o.ACT_TANH, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN),
+    "mid_t2": dict(dims=[20, 32, 48, 2], n=1030, act=o.ACT_SIGMOID, prior=o.PRIOR_CAUCHY, lik=o.LIK_BERNOULLI),
+    "mid_t3": dict(dims=[7, 33, 18, 50, 2], n=900, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN),
 }
 
 
@@ -89,13 +93,59 @@ WIDE_CASES = ["wide_t1", "wide_t2", "c5_small", "c4_small"]
 
 
 @pytest.mark.parametrize("case", WIDE_CASES)
-def test_logp_grad_wide(native, case):
-    """the two-kernel wide-layer path (k_chain_wide + k_dw_wide) must cover these shapes"""
+def test_logp_grad_wide(native, case, monkeypatch):
+    """the two-kernel wide-layer path (k_chain_wide + k_dw_wide) must cover these shapes (TBNN_MID=0: configs[4]'s shape,
+    which the mid-width fused kernel takes by default, stays covered as the wide family's resident-weights case)"""
+    monkeypatch.setenv("TBNN_MID", "0")
     spec, X, Y, theta, eta = problem(case)
     ch = make_chain(native, spec, native.KERNEL_FAST)
     assert ch.kernel_name.startswith("wide<"), ch.kernel_name
     ch.close()
     check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+
+
+MID_CASES = ["mid_t1", "mid_t2", "mid_t3", "c5_small"]
+
+
+@pytest.mark.parametrize("case", MID_CASES)
+def test_logp_grad_mid(native, case):
+    """the mid-width fused kernel (k_fwd_bwd_mid: dW of every layer in one wave's AccVGPRs, W^T read from the W image)"""
+    spec, X, Y, theta, eta = problem(case)
+    ch = make_chain(native, spec, native.KERNEL_FAST)
+    assert ch.kernel_name.startswith("mid<"), ch.kernel_name
+    ch.close()
+    check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 129, 5000 + 3])
+def test_logp_grad_mid_ragged_rows(native, n):
+    spec, X, Y, theta, eta = o.synth_problem([7, 33, 18, 50, 2], n, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN)
+    check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+
+
+@pytest.mark.parametrize("case", ["mid_t1", "mid_t2", "mid_t3", "c5_small"])
+def test_transition_mid(native, case):
+    """a whole transition through the mid-width kernel: log-prob trace, log accept ratio, decision, new state vs the fp64 oracle;
+    several tiles per wave through a small grid (TBNN_FAST_GRID), so that the accumulators carry over tiles"""
+    spec, X, Y, theta, eta = problem(case)
+    rng = np.random.default_rng(3)
+    p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+    import os
+    os.environ["TBNN_FAST_GRID"] = "3"
+    try:
+        ch = make_chain(native, spec, native.KERNEL_FAST)
+        ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    finally:
+        del os.environ["TBNN_FAST_GRID"]
+    eps = 2e-5
+    out = ch.hmc_step(eps, 4, p0=p0, log_u=float(np.log(0.5)), trace=True)
+    ref = o.weight_step(spec, theta, eta, X, Y, eps, 4, p0, float(np.log(0.5)), np.float64)
+    np.testing.assert_allclose(out["trace_logp"], ref.trace_logp, rtol=LOGP_RTOL, atol=2e-3)
+    assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-4 * abs(ref.log_accept_ratio)
+    assert bool(out["accepted"]) == ref.accepted
+    th = ch.get_state()
+    np.testing.assert_allclose(th, ref.theta, rtol=0, atol=2e-6 * max(1.0, np.abs(ref.theta).max()))
+    ch.close()
 
 
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 129, 5000 + 3])

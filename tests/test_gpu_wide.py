@@ -1,4 +1,5 @@
-"""GPU: the wide-layer path (k_chain_wide + k_dw_wide) at BASELINE configs[3]/[4] full size.
+"""GPU: the wide-layer path (k_chain_wide + k_dw_wide; configs[3]) and the mid-width fused kernel (k_fwd_bwd_mid;
+configs[4]) at BASELINE's full size.
 
 The fp64 oracle cannot evaluate 1e6 x 200-wide rows in seconds, so full-size parity is checked
 through size-independent properties: agreement with the (oracle-verified) generic kernel on a
@@ -28,7 +29,7 @@ def test_wide_vs_generic_large(native, cfg, n):
     for name, k in (("wide", native.KERNEL_FAST), ("generic", native.KERNEL_GENERIC)):
         ch = chain(native, spec, k)
         if name == "wide":
-            assert ch.kernel_name.startswith("wide<")
+            assert ch.kernel_name.startswith("wide<" if cfg is C4 else "mid<"), ch.kernel_name
         ch.set_data(X, Y)
         res[name] = ch.logp_grad(theta, eta)
         ch.close()

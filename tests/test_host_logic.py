@@ -219,12 +219,17 @@ def test_jit_family_choice_and_source():
     assert jit.families([5, 50, 50, 50, 1])[0] == "fast3"
     assert jit.families([5, 20, 3]) == ["fast"]                    # 3 outputs: MFMA last layer
     assert jit.families([10, 200, 200, 200, 1]) == ["wide"]
+    assert jit.families([20, 100, 100, 2]) == ["mid", "wide"]      # 63 dW tiles: one wave's AccVGPRs, 134 KB of LDS
+    assert jit.families([8, 80, 80, 2]) == ["mid", "wide"]
+    assert jit.families([20, 111, 100, 2]) == ["mid", "wide"] and jit.families([20, 112, 112, 2]) == ["wide"]   # 7 x 8 + 14 tiles do not fit
+    assert jit.families([8, 64, 64, 64, 2]) == ["mid", "wide"] and jit.families([8, 64, 64, 64, 64, 2]) == ["wide"]
     assert jit.families([40, 300, 3]) == []                        # fan-in 40, 300-wide: generic kernel
     layers = [(8, 64, nat.ACT_RELU, nat.PRIOR_CAUCHY), (64, 48, nat.ACT_RELU, nat.PRIOR_CAUCHY), (48, 2, nat.ACT_SIGMOID, nat.PRIOR_CAUCHY)]
     dims, hact, lact, bern = jit.shape_of(layers, nat.LIK_BERNOULLI)
     assert (dims, hact, lact, bern) == ([8, 64, 48, 2], nat.ACT_RELU, nat.ACT_SIGMOID, 1)
     src = jit.source(dims, hact, lact, bern, "wide")
     assert "Shape<1, 3, true, 8, 64, 48, 2>" in src and "JitWide<S>::fill" in src and "tbnn_jit_ops" in src
+    assert "JitMid<S>::fill" in jit.source(dims, hact, lact, bern, "mid")
     mixed = [(4, 8, nat.ACT_RELU, 0), (8, 8, nat.ACT_TANH, 0), (8, 1, nat.ACT_NONE, 0)]
     assert jit.shape_of(mixed, nat.LIK_GAUSSIAN) is None
 
