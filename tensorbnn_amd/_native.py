@@ -14,7 +14,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtbnn.so")
+# TBNN_LIB: a diagnostic build of the library next to the product one (tools/: stamped / variant builds)
+LIB_PATH = os.environ.get("TBNN_LIB") or os.path.join(_HERE, "libtbnn.so")
 
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_EXP, ACT_ELU = 0, 1, 2, 3, 4, 5
 PRIOR_CAUCHY, PRIOR_GAUSSIAN = 0, 1

@@ -14,8 +14,11 @@ PER_SOURCE_FLAGS = {"tbnn_api.hip": NARROW_FLAGS,
                     "tbnn_wide.hip": ([] if os.environ.get("TBNN_WIDE_AGPR_FORM") == "1" else NARROW_FLAGS)
                                      + os.environ.get("TBNN_WIDE_FLAGS", "").split(),
                     "tbnn_mid.hip": NARROW_FLAGS + os.environ.get("TBNN_MID_FLAGS", "").split()}
-OBJ_DIR = os.path.join(HERE, "_obj")
-OUT = os.path.join(HERE, "libtbnn.so")
+# TBNN_BUILD_TAG=<tag>: a diagnostic variant (TBNN_EXTRA_FLAGS / TBNN_*_FLAGS) built side by side as libtbnn_<tag>.so with its
+# own object directory; load it with TBNN_LIB=<path>
+_TAG = os.environ.get("TBNN_BUILD_TAG", "")
+OBJ_DIR = os.path.join(HERE, "_obj" + ("_" + _TAG if _TAG else ""))
+OUT = os.path.join(HERE, "libtbnn" + ("_" + _TAG if _TAG else "") + ".so")
 
 
 def _deps():

@@ -243,11 +243,15 @@ __device__ __forceinline__ float mul_legacy(float s, float x) {
 // v_mfma_f32_16x16x4_f32 -> VALU read requirement of 10).
 template <int N>
 __device__ __forceinline__ void mfma_settle(f32x4 (&acc)[N]) {
-    static_assert(N >= 1 && N <= 4, "one asm statement ties up to 4 tiles");
+    static_assert(N >= 1 && N <= 8, "one asm statement ties up to 8 tiles");
     if constexpr (N == 1) asm volatile("s_nop 10" : "+v"(acc[0]));
     if constexpr (N == 2) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]));
     if constexpr (N == 3) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
     if constexpr (N == 4) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    if constexpr (N == 5) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
+    if constexpr (N == 6) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]));
+    if constexpr (N == 7) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]));
+    if constexpr (N == 8) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
 }
 // acc * act'(a) for the 4 registers of a tile; SETTLED: the caller has called mfma_settle on acc (or acc is a VALU result)
 template <int ACT, bool SETTLED>

@@ -45,6 +45,24 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 #endif
 
+// sum over the 4 lane groups (same lane & 15), every lane gets it: the gfx950 row-swap instructions, VALU only (two
+// ds_bpermute round trips would put ~2 x 100 cycles of LDS latency on the last layer's dependency chain)
+__device__ __forceinline__ float lane_group_sum(float p) {
+    const unsigned a = __float_as_uint(p);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);   // lanes l and l ^ 32
+    const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const unsigned b = __float_as_uint(s);
+    const auto q = __builtin_amdgcn_permlane16_swap(b, b, false, false);   // rows r and r ^ 1
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// Order of issue inside a k-group is fixed by hand with scheduling fences (nothing crosses __builtin_amdgcn_sched_barrier(0)):
+// the LDS reads of the NEXT group's operands go out one per MFMA under the first MFMAs of this group, a whole group ahead
+// of their use.  Left to itself the compiler requests an operand two MFMAs before its first use and stalls on the LDS
+// round trip in every k-group (measured: 18-20 cycles of tile time per LDS instruction); sched_group_barrier pipelines made
+// it serialise the accumulators (one tile's whole K loop at a time, a dependent MFMA chain).
+#define MID_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 #define MID_WAVES 4
 #define MID_THREADS 256
 // pitch padding of the middle layers' row-major images (floats; == 4 mod 8 keeps the strided W^T reads conflict-free)
@@ -79,6 +97,7 @@ struct MidCfg {
     static constexpr int KG(int K) { return cdiv(K, 16); }
     static constexpr int maxT() { int m = 0; for (int l = 1; l <= LL; ++l) m = TR(l) > m ? TR(l) : m; return m; }
     static constexpr int MAXT = maxT();
+    static constexpr int maxTA() { int m = cdiv(in(0) + 1, 16); for (int l = 1; l <= NL - 2; ++l) m = TA(l) > m ? TA(l) : m; return m; }
     // layer 0
     static constexpr int KG0 = KG(d_in), NT0 = cdiv(d_in + 1, 16), MT0 = TR(1);
     // ---- dW accumulator tiles: layer 0: MT0 x NT0, middle layer l: TR(l+1) x TA(l)
@@ -103,8 +122,11 @@ struct MidCfg {
     // ---- per-wave blocks (256 floats = [16 rows][16 slots] each)
     static constexpr int XB_OFF = 0;                                            // x (+ ones slot): NT0 blocks
     static constexpr int aboff(int l) { int o = XB_OFF + NT0 * 256; for (int m = 1; m < l; ++m) o += TA(m) * 256; return o; }   // a_l, l = 1..NM
-    static constexpr int DB_OFF = aboff(NM + 1);                                // delta_l (one layer at a time): MAXT blocks
-    static constexpr int WAVE_FLOATS = DB_OFF + MAXT * 256;
+    // delta_l blocks: two regions, layer parity selects one (delta_{l-1} is written while the operands of dW_l are still
+    // being read from delta_l's region)
+    static constexpr int DB_OFF = aboff(NM + 1);
+    static constexpr int dboff(int l) { return DB_OFF + (l & 1) * MAXT * 256; }
+    static constexpr int WAVE_FLOATS = DB_OFF + 2 * MAXT * 256;
     static constexpr int MIN_LDS = IMG_FLOATS + MID_WAVES * WAVE_FLOATS;
     // epilogue staging: tiles per pass with all 4 waves' copies resident
     static constexpr int EP_TILES = MIN_LDS / (MID_WAVES * 256) < DW_TILES ? MIN_LDS / (MID_WAVES * 256) : DW_TILES;
@@ -130,6 +152,10 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
     float* __restrict__ slabs, int pitch, double* __restrict__ pstat, float* __restrict__ fouts, long out_stride)
 {
     using C = MidCfg<S>;
+    // the opaque packed instructions (pkfma*: no hazard handling by the compiler) may read hidden activations only when those
+    // come out of a plain VALU instruction: relu (v_max), tanh / elu (a select).  A raw MFMA result (no activation) or a
+    // transcendental result (sigmoid: v_rcp, exp: v_exp) would need wait states nobody inserts
+    constexpr bool PKA = S::HACT == TBNN_ACT_RELU || S::HACT == TBNN_ACT_TANH || S::HACT == TBNN_ACT_ELU;
     static_assert(C::LDS_FLOATS * 4 + 64 <= 160 * 1024, "LDS budget");
     static_assert(C::IMG_FLOATS % 4 == 0 && C::WAVE_FLOATS % 4 == 0, "16-B addressable sections");
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
@@ -190,6 +216,37 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
         for (int t = 0; t < C::TR(LL); ++t) LR.acc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // operand registers that are requested ahead of their layer (and, for layer 0, ahead of their tile)
+    f32x4 Apre[C::MAXT], Bpre[C::MAXT];                    // first A group and bias tiles of the next MFMA layer
+    f32x4 wL[d_out][C::TR(LL)];                            // last layer's weights, slot order: lane (r, g) holds slots 16t+4g..+3
+    // slot `slot` of `nslot`: the loads are dealt out over the MFMA slots of the k-group they are issued under
+    auto preload_mid = [&](auto l_, int slot, int nslot) __attribute__((always_inline)) {
+        constexpr int l = decltype(l_)::value;
+        const float* wrow = lds + C::wmoff(l) + i16 * C::LDM(l) + 4 * g;
+#pragma unroll
+        for (int t = 0; t < C::TR(l + 1); ++t)
+            if (t % nslot == slot) {
+                Bpre[t] = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * t + 4 * g);
+                Apre[t] = load_ks(wrow + 16 * t * C::LDM(l), C::ksteps(C::in(l), 0));
+            }
+    };
+    auto preload_l0 = [&](int slot, int nslot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < C::MT0; ++t)
+            if (t % nslot == slot) {
+                Bpre[t] = *reinterpret_cast<const f32x4*>(lds + C::boff(0) + 16 * t + 4 * g);
+                Apre[t] = *reinterpret_cast<const f32x4*>(lds + C::W0_OFF + (t * C::KG0) * 256 + lane * 4);
+            }
+    };
+    auto preload_last = [&](int slot, int nslot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int o = 0; o < d_out; ++o)
+#pragma unroll
+            for (int t = 0; t < C::TR(LL); ++t)
+                if ((o * C::TR(LL) + t) % nslot == slot) wL[o][t] = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
+    };
+    if constexpr (!FWD) preload_l0(0, 1);
+
     for (; tile < ntiles; tile += W) {
 #ifdef MID_STAMPS
         const bool mstamp_on = blockIdx.x == 0 && tid == 0 && tile == W;
@@ -214,23 +271,38 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
             }
         }
 
-        // ---- layer 0
+        // ---- forward.  LDS operand traffic is placed by hand (sched_group_barrier): the A operands of k-group kg+1 are
+        // requested under the first MFMAs of k-group kg, one read per MFMA -- left to itself the compiler issues a read two
+        // MFMAs ahead of its use and stalls on it -- and the first group + bias tiles of the NEXT layer (the last layer's
+        // weights after the last middle layer) under the last k-group of this one.
         f32x4 a[C::MAXT];                  // the current layer's input a_l, D layout: tile t reg j of lane (r, g) = slot 16t+4g+j of row r
+        // ---- layer 0
         {
             constexpr int MT = C::MT0;
-            f32x4 acc[MT];
+            f32x4 acc[MT], An[MT];
+            if constexpr (FWD) preload_l0(0, 1);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(lds + C::boff(0) + 16 * t + 4 * g);
-#pragma unroll
-            for (int kg = 0; kg < C::KG0; ++kg) {
+            for (int t = 0; t < MT; ++t) { acc[t] = Bpre[t]; An[t] = Apre[t]; }
+            sfor<0, C::KG0>(SFOR_LAMBDA(kg) {
+                constexpr int kg = SFOR_VAL(kg);
                 f32x4 A[MT];
 #pragma unroll
-                for (int t = 0; t < MT; ++t) A[t] = *reinterpret_cast<const f32x4*>(lds + C::W0_OFF + (t * C::KG0 + kg) * 256 + lane * 4);
+                for (int t = 0; t < MT; ++t) A[t] = An[t];
+                MID_FENCE();
 #pragma unroll
-                for (int s = 0; s < C::ksteps(d_in, kg); ++s)
+                for (int s = 0; s < C::ksteps(d_in, kg); ++s) {
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) acc[t] = mfma16(A[t][s], x[4 * kg + s], acc[t]);
-            }
+                    for (int t = 0; t < MT; ++t) {
+                        acc[t] = mfma16(A[t][s], x[4 * kg + s], acc[t]);
+                        if (s == 0) {
+                            if constexpr (kg + 1 < C::KG0) An[t] = *reinterpret_cast<const f32x4*>(lds + C::W0_OFF + (t * C::KG0 + kg + 1) * 256 + lane * 4);
+                            else preload_mid(std::integral_constant<int, 1>{}, t, MT);
+                            MID_FENCE();
+                        }
+                    }
+                    MID_FENCE();
+                }
+            });
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -250,21 +322,32 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                     *reinterpret_cast<f32x4*>(wl + C::aboff(l) + t * 256 + i16 * 16 + 4 * g) = v;
                 }
             }
-            constexpr int MT = C::TR(l + 1), K = C::in(l);
-            f32x4 acc[MT];
+            constexpr int MT = C::TR(l + 1), K = C::in(l), KGn = C::KG(K);
+            f32x4 acc[MT], An[MT];
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * t + 4 * g);
+            for (int t = 0; t < MT; ++t) { acc[t] = Bpre[t]; An[t] = Apre[t]; }
             const float* wrow = lds + C::wmoff(l) + i16 * C::LDM(l) + 4 * g;
-#pragma unroll
-            for (int kg = 0; kg < C::KG(K); ++kg) {
+            sfor<0, KGn>(SFOR_LAMBDA(kg) {
+                constexpr int kg = SFOR_VAL(kg);
                 f32x4 A[MT];
 #pragma unroll
-                for (int t = 0; t < MT; ++t) A[t] = load_ks(wrow + 16 * t * C::LDM(l) + 16 * kg, C::ksteps(K, kg));
+                for (int t = 0; t < MT; ++t) A[t] = An[t];
+                MID_FENCE();
 #pragma unroll
-                for (int s = 0; s < C::ksteps(K, kg); ++s)
+                for (int s = 0; s < C::ksteps(K, kg); ++s) {
 #pragma unroll
-                    for (int t = 0; t < MT; ++t) acc[t] = mfma16(A[t][s], a[kg][s], acc[t]);
-            }
+                    for (int t = 0; t < MT; ++t) {
+                        acc[t] = mfma16(A[t][s], a[kg][s], acc[t]);
+                        if (s == 0) {
+                            if constexpr (kg + 1 < KGn) An[t] = load_ks(wrow + 16 * t * C::LDM(l) + 16 * (kg + 1), C::ksteps(K, kg + 1));
+                            else if constexpr (l < NM) preload_mid(std::integral_constant<int, (l < NM ? l + 1 : l)>{}, t, MT);
+                            else preload_last(t, MT);
+                            MID_FENCE();
+                        }
+                    }
+                    MID_FENCE();
+                }
+            });
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -272,22 +355,28 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
         });
         MSTAMP(2);
 
-        // ---- last layer on the VALU: f_o = b_o + sum_u W[o][u] a_LL[u]
+        // ---- last layer on the VALU: f_o = b_o + sum_u W[o][u] a_LL[u] (packed FMAs kept packed: pkfma*, kernels_fast.hpp)
         constexpr int TP = C::TR(LL);
         float dzl[d_out];
         {
 #pragma unroll
             for (int o = 0; o < d_out; ++o) {
-                float p = 0.f;
+                f32x2 p2 = {0.f, 0.f};
 #pragma unroll
                 for (int t = 0; t < TP; ++t) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p = fmaf(w[r], a[t][r], p);
+                    const f32x4 w = wL[o][t];
+                    if constexpr (PKA) {
+                        p2 = pkfma(f32x2{w[0], w[1]}, f32x2{a[t][0], a[t][1]}, p2);
+                        p2 = pkfma(f32x2{w[2], w[3]}, f32x2{a[t][2], a[t][3]}, p2);
+                    } else {                           // compiler-visible arithmetic
+                        p2 = f32x2{w[0], w[1]} * f32x2{a[t][0], a[t][1]} + p2;
+                        p2 = f32x2{w[2], w[3]} * f32x2{a[t][2], a[t][3]} + p2;
+                    }
                 }
-                p += __shfl_xor(p, 16, 64);
-                p += __shfl_xor(p, 32, 64);
-                const float fi = actc_fwd<S::LACT>(p + lds[C::BL_OFF + o]);
+                MSTAMP(16 + 3 * o);
+                const float fsum = lane_group_sum(p2[0] + p2[1]);
+                MSTAMP(17 + 3 * o);
+                const float fi = actc_fwd<S::LACT>(fsum + lds[C::BL_OFF + o]);
                 if constexpr (FWD) {
                     if (rvalid && g == 0) fout[(size_t)o * n + tile * 16 + i16] = fi;      // [d_out][n]
                     dzl[o] = 0.f;
@@ -295,102 +384,182 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                     dzl[o] = rvalid ? lik_delta<S>(fi, y[o], inv_var, g == 0, stat) : 0.f;
                     LR.accb[o] += dzl[o];
                 }
+                MSTAMP(18 + 3 * o);
             }
         }
         if constexpr (!FWD) {
         f32x4 dz[C::MAXT];
         {
+            // dW_LL partial sums and delta_{LL-1} = (W_LL^T dz_LL) * act'(a_LL)
+            const f32x2 dd = {dzl[0], dzl[d_out - 1]};
 #pragma unroll
             for (int t = 0; t < TP; ++t) {
-                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+                f32x2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};
+                sfor<0, d_out>(SFOR_LAMBDA(o) {
+                    constexpr int o = SFOR_VAL(o);
+                    const f32x4 w = wL[o][t];
+                    if constexpr (PKA) {
+                        const f32x2 s01 = pkfma_bc<o>(f32x2{a[t][0], a[t][1]}, dd, f32x2{LR.acc[o][t][0], LR.acc[o][t][1]});
+                        const f32x2 s23 = pkfma_bc<o>(f32x2{a[t][2], a[t][3]}, dd, f32x2{LR.acc[o][t][2], LR.acc[o][t][3]});
+                        LR.acc[o][t] = f32x4{s01[0], s01[1], s23[0], s23[1]};
+                    } else {
 #pragma unroll
-                for (int o = 0; o < d_out; ++o) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        LR.acc[o][t][r] = fmaf(dzl[o], a[t][r], LR.acc[o][t][r]);
-                        d[r] = fmaf(w[r], dzl[o], d[r]);
+                        for (int r = 0; r < 4; ++r) LR.acc[o][t][r] = fmaf(dzl[o], a[t][r], LR.acc[o][t][r]);
                     }
-                }
-                dz[t] = actc_bwd_mul4<S::HACT, true>(d, a[t]);
+                    if constexpr (o == 0) { d01 = pkmul_bc<0>(f32x2{w[0], w[1]}, dd); d23 = pkmul_bc<0>(f32x2{w[2], w[3]}, dd); }
+                    else { d01 = pkfma_bc<o>(f32x2{w[0], w[1]}, dd, d01); d23 = pkfma_bc<o>(f32x2{w[2], w[3]}, dd, d23); }
+                });
+                if constexpr (S::HACT != TBNN_ACT_NONE) dz[t] = actc_bwd_mul4<S::HACT, true>(f32x4{d01[0], d01[1], d23[0], d23[1]}, a[t]);
+                else dz[t] = f32x4{d01[0], d01[1], d23[0], d23[1]};
             }
         }
         MSTAMP(3);
 
-        // ---- backward through the middle layers.  For layer l (NM .. 1), delta_l in `dz` (D layout):
-        //   W(delta_l blocks) R(operands of dW_l) | delta chain: delta_{l-1} = (W_l^T delta_l) * act'(a_l) | dW_l MFMAs
-        // (the operand round trip through LDS lands under the delta-chain MFMAs; the dW MFMAs run from registers)
-        sfor<0, NM>(SFOR_LAMBDA(li) {
-            constexpr int l = NM - SFOR_VAL(li);
-            constexpr int TZ = C::TR(l + 1), TAl = C::TA(l), MU = C::TR(l), K = C::out(l);
-            float* db = wl + C::DB_OFF;
-            const float* ab = wl + C::aboff(l);
-#pragma unroll
-            for (int t = 0; t < TZ; ++t) *reinterpret_cast<f32x4*>(db + t * 256 + i16 * 16 + 4 * g) = dz[t];
-            float Aop[TZ][4], Bop[TAl][4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int t = 0; t < TZ; ++t) Aop[t][s] = db[t * 256 + 64 * s + lane];
-#pragma unroll
-                for (int u = 0; u < TAl; ++u) Bop[u][s] = ab[u * 256 + 64 * s + lane];
-            }
-            // delta chain: A operand = W_l^T from the row-major image (lane (i, g): W[16kg+4g+s][16u+i])
-            f32x4 acc[MU];
-#pragma unroll
-            for (int u = 0; u < MU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- backward through the middle layers.  Every LDS access is placed by hand under MFMAs (one or two per MFMA slot,
+        // a scheduling fence after each slot):
+        //   B(l)  delta chain through W_l: delta_{l-1} = (W_l^T delta_l) * act'(a_l).  A operands straight from the row-major
+        //         image, the next k-group's under this one's first MFMAs.  B(NM) also parks delta_NM in its blocks (first
+        //         k-group); the last k-groups request the k-steps 0, 1 operands of dW_l and a_l (for act').
+        //   D(l)  dW_l += delta_l^T [a_l, 1] from registers (AccVGPR accumulators, asm MFMAs: program order is issue order).
+        //         Under them: the k-steps 2, 3 operands of dW_l, the parking of delta_{l-1} (the other block region), then
+        //         what the next phase starts from: the first k-group of B(l-1), or the k-steps 0, 1 operands of dW_0.
+        //   D(0)  dW_0 += delta_0^T [x, 1]; under it its k-steps 2, 3 operands, then the first A group + bias tiles of the
+        //         NEXT tile's layer 0.
+        constexpr int MAXB = C::maxTA();
+        float Aop[C::MAXT][4], Bop[MAXB][4];        // operands of the dW phase that runs next
+        float Wn[4][C::MAXT];                       // the chain's next k-group: W^T values [k-step][tile]
+        // lane-linear pair read of a block: rows 4s+g and 4(s+1)+g of slot i16 (one ds_read2st64_b32)
+        auto rd2 = [&](const float* blk, int s, float& v0, float& v1) __attribute__((always_inline)) {
+            v0 = blk[64 * s + lane]; v1 = blk[64 * (s + 1) + lane];
+        };
+        auto chain_load = [&](auto l_, int kg, int u) __attribute__((always_inline)) {
+            constexpr int l = decltype(l_)::value;
             const float* wcol = lds + C::wmoff(l) + 4 * g * C::LDM(l) + i16;
 #pragma unroll
-            for (int kg = 0; kg < C::KG(K); ++kg) {
+            for (int s = 0; s < 4; ++s)
+                if (s < C::ksteps(C::out(l), kg)) Wn[s][u] = wcol[(16 * kg + s) * C::LDM(l) + 16 * u];
+        };
+        // first k-group of B(NM): requested here, its round trip hides under nothing but is issued once per tile
+        {
 #pragma unroll
-                for (int s = 0; s < C::ksteps(K, kg); ++s) {
-                    float A[MU];
+            for (int u = 0; u < C::TR(NM); ++u) chain_load(std::integral_constant<int, NM>{}, 0, u);
+        }
+        MID_FENCE();
+        sfor<0, NM>(SFOR_LAMBDA(li) {
+            constexpr int l = NM - SFOR_VAL(li);
+            constexpr int TZ = C::TR(l + 1), TAl = C::TA(l), MU = C::TR(l), K = C::out(l), KGn = C::KG(K);
+            float* dbl = wl + C::dboff(l);
+            const float* ab = wl + C::aboff(l);
+            // ---- B(l)
+            f32x4 acc[MU], al[MU];
 #pragma unroll
-                    for (int u = 0; u < MU; ++u) A[u] = wcol[(16 * kg + s) * C::LDM(l) + 16 * u];
+            for (int u = 0; u < MU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // extra LDS operations threaded through the chain: NW parkings (B(NM) only), then NR reads in the last RG k-groups
+            constexpr int NW = l == NM ? TZ : 0, NR = TZ + TAl + MU, RG = KGn >= 2 ? 2 : 1;
+            auto extra = [&](auto e_) __attribute__((always_inline)) {
+                constexpr int e = decltype(e_)::value;
+                if constexpr (e < NW) *reinterpret_cast<f32x4*>(dbl + e * 256 + i16 * 16 + 4 * g) = dz[e];
+                else if constexpr (e < NW + TZ) rd2(dbl + (e - NW) * 256, 0, Aop[e - NW][0], Aop[e - NW][1]);
+                else if constexpr (e < NW + TZ + TAl) rd2(ab + (e - NW - TZ) * 256, 0, Bop[e - NW - TZ][0], Bop[e - NW - TZ][1]);
+                else al[e - NW - TZ - TAl] = *reinterpret_cast<const f32x4*>(ab + (e - NW - TZ - TAl) * 256 + i16 * 16 + 4 * g);
+            };
+            sfor<0, KGn>(SFOR_LAMBDA(kg) {
+                constexpr int kg = SFOR_VAL(kg), NS = C::ksteps(K, kg);
+                float A[4][MU];
 #pragma unroll
-                    for (int u = 0; u < MU; ++u) acc[u] = mfma16(A[u], dz[kg][s], acc[u]);
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int u = 0; u < MU; ++u) A[s][u] = Wn[s][u];
+                MID_FENCE();
+                // k-step 0: one slot per MFMA
+                sfor<0, MU>(SFOR_LAMBDA(u) {
+                    constexpr int u = SFOR_VAL(u);
+                    acc[u] = mfma16(A[0][u], dz[kg][0], acc[u]);
+                    if constexpr (kg + 1 < KGn) chain_load(std::integral_constant<int, l>{}, kg + 1, u);
+                    if constexpr (kg == 0 && NW > 0) {                // parkings: slot u takes e = u, u + MU, ... (all in slot 0 when there is one k-group)
+                        sfor<0, NW>(SFOR_LAMBDA(e) {
+                            constexpr int e = SFOR_VAL(e);
+                            if constexpr (KGn >= 2 ? (e % MU == u) : (u == 0)) extra(std::integral_constant<int, e>{});
+                        });
+                    }
+                    if constexpr (kg >= KGn - RG) {                   // reads: dealt out over the RG * MU slots of the last k-groups
+                        constexpr int q = (kg - (KGn - RG)) * MU + u;
+                        sfor<0, NR>(SFOR_LAMBDA(r) {
+                            constexpr int r = SFOR_VAL(r);
+                            if constexpr ((r * RG * MU) / NR == q) extra(std::integral_constant<int, NW + r>{});
+                        });
+                    }
+                    MID_FENCE();
+                });
+#pragma unroll
+                for (int s = 1; s < NS; ++s) {
+#pragma unroll
+                    for (int u = 0; u < MU; ++u) acc[u] = mfma16(A[s][u], dz[kg][s], acc[u]);
+                    MID_FENCE();
+                }
+            });
+            MSTAMP(25 + 3 * SFOR_VAL(li));
+            f32x4 dzp[C::MAXT];
+            constexpr bool PKR = S::act(l - 1) == TBNN_ACT_RELU && TBNN_F3_RELU_PK && MU <= 8;
+            if constexpr (PKR) mfma_settle(acc);
+#pragma unroll
+            for (int u = 0; u < MU; ++u) dzp[u] = actc_bwd_mul4<S::act(l - 1), PKR>(acc[u], al[u]);
+            MSTAMP(4 + 2 * SFOR_VAL(li));
+            MID_FENCE();
+            // ---- D(l)
+            {
+                constexpr int NMF = 4 * TZ * TAl;
+                float* dbn = wl + C::dboff(l - 1);
+                // operations under the MFMAs, in this order: k-steps 2, 3 operands (TZ + TAl), parkings of delta_{l-1} (MU),
+                // then the next phase's first requests
+                constexpr int N1 = TZ + TAl, N2 = N1 + MU;
+                constexpr int NX = l > 1 ? C::TR(l > 1 ? l - 1 : 1) : C::MT0 + C::NT0;
+                constexpr int NE = N2 + NX;
+                float An2[C::MAXT][2], Bn2[MAXB][2];
+                auto under = [&](auto e_) __attribute__((always_inline)) {
+                    constexpr int e = decltype(e_)::value;
+                    if constexpr (e < TZ) rd2(dbl + e * 256, 2, Aop[e][2], Aop[e][3]);
+                    else if constexpr (e < N1) rd2(ab + (e - TZ) * 256, 2, Bop[e - TZ][2], Bop[e - TZ][3]);
+                    else if constexpr (e < N2) *reinterpret_cast<f32x4*>(dbn + (e - N1) * 256 + i16 * 16 + 4 * g) = dzp[e - N1];
+                    else if constexpr (l > 1) chain_load(std::integral_constant<int, (l > 1 ? l - 1 : 1)>{}, 0, e - N2);
+                    else if constexpr (e - N2 < C::MT0) rd2(dbn + (e - N2) * 256, 0, An2[e - N2][0], An2[e - N2][1]);
+                    else rd2(wl + C::XB_OFF + (e - N2 - C::MT0) * 256, 0, Bn2[e - N2 - C::MT0][0], Bn2[e - N2 - C::MT0][1]);
+                };
+                sfor<0, NMF>(SFOR_LAMBDA(j) {
+                    constexpr int j = SFOR_VAL(j), sj = j / (TZ * TAl), tj = (j / TAl) % TZ, uj = j % TAl;
+                    mfma16_acc<(TZ * TAl > 1)>(dW[C::dwoff(l) + tj * TAl + uj], Aop[tj][sj], Bop[uj][sj]);
+                    // operation e rides in slot e * NMF / NE
+                    sfor<(j * NE + NMF - 1) / NMF, ((j + 1) * NE + NMF - 1) / NMF>(SFOR_LAMBDA(e) { under(std::integral_constant<int, SFOR_VAL(e)>{}); });
+                    MID_FENCE();
+                });
+                if constexpr (l == 1) {
+#pragma unroll
+                    for (int t = 0; t < C::MT0; ++t) { Aop[t][0] = An2[t][0]; Aop[t][1] = An2[t][1]; }
+#pragma unroll
+                    for (int u = 0; u < C::NT0; ++u) { Bop[u][0] = Bn2[u][0]; Bop[u][1] = Bn2[u][1]; }
                 }
             }
-            // act'(a_l) from the blocks the forward pass wrote (the ones slot multiplies an exact zero: padded W columns)
-            f32x4 dzp[MU];
-#pragma unroll
-            for (int u = 0; u < MU; ++u) {
-                const f32x4 al = *reinterpret_cast<const f32x4*>(ab + u * 256 + i16 * 16 + 4 * g);
-                dzp[u] = actc_bwd_mul4<S::act(l - 1), false>(acc[u], al);
-            }
-            MSTAMP(4 + 2 * SFOR_VAL(li));
-            // dW_l += delta_l^T [a_l, 1]
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < TZ; ++t)
-#pragma unroll
-                    for (int u = 0; u < TAl; ++u) mfma16_acc<(TZ * TAl > 1)>(dW[C::dwoff(l) + t * TAl + u], Aop[t][s], Bop[u][s]);
             MSTAMP(5 + 2 * SFOR_VAL(li));
 #pragma unroll
             for (int u = 0; u < C::MAXT; ++u) if (u < MU) dz[u] = dzp[u];
         });
 
-        // ---- dW_0 += delta_0^T [x, 1]
+        // ---- D(0): dW_0 += delta_0^T [x, 1]
         {
-            float* db = wl + C::DB_OFF;
-            const float* xb = wl + C::XB_OFF;
-#pragma unroll
-            for (int t = 0; t < C::MT0; ++t) *reinterpret_cast<f32x4*>(db + t * 256 + i16 * 16 + 4 * g) = dz[t];
-            float Aop[C::MT0][4], Bop[C::NT0][4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int t = 0; t < C::MT0; ++t) Aop[t][s] = db[t * 256 + 64 * s + lane];
-#pragma unroll
-                for (int u = 0; u < C::NT0; ++u) Bop[u][s] = xb[u * 256 + 64 * s + lane];
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < C::MT0; ++t)
-#pragma unroll
-                    for (int u = 0; u < C::NT0; ++u) mfma16_acc<(C::MT0 * C::NT0 > 1)>(dW[C::dwoff(0) + t * C::NT0 + u], Aop[t][s], Bop[u][s]);
+            constexpr int NMF = 4 * C::MT0 * C::NT0, N1 = C::MT0 + C::NT0, NE = N1 + C::MT0;
+            const float* db0 = wl + C::dboff(0);
+            auto under = [&](auto e_) __attribute__((always_inline)) {
+                constexpr int e = decltype(e_)::value;
+                if constexpr (e < C::MT0) rd2(db0 + e * 256, 2, Aop[e][2], Aop[e][3]);
+                else if constexpr (e < N1) rd2(wl + C::XB_OFF + (e - C::MT0) * 256, 2, Bop[e - C::MT0][2], Bop[e - C::MT0][3]);
+                else preload_l0(e - N1, C::MT0);                      // the next tile's layer 0: bias tiles + first A group
+            };
+            sfor<0, NMF>(SFOR_LAMBDA(j) {
+                constexpr int j = SFOR_VAL(j), sj = j / (C::MT0 * C::NT0), tj = (j / C::NT0) % C::MT0, uj = j % C::NT0;
+                mfma16_acc<(C::MT0 * C::NT0 > 1)>(dW[C::dwoff(0) + tj * C::NT0 + uj], Aop[tj][sj], Bop[uj][sj]);
+                sfor<(j * NE + NMF - 1) / NMF, ((j + 1) * NE + NMF - 1) / NMF>(SFOR_LAMBDA(e) { under(std::integral_constant<int, SFOR_VAL(e)>{}); });
+                MID_FENCE();
+            });
         }
         MSTAMP(4 + 2 * NM);
         }   // !FWD
