@@ -41,13 +41,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SRC:
         obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
         cmd = [hipcc] + flags + PER_SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        if src.endswith(".hip"):
+            cmd[1:1] = ["-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics"]   # per-kernel register / scratch remarks on stderr
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
+        procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
         objs.append(obj)
     for cmd, p in procs:
-        if p.wait() != 0:
+        _, err = p.communicate()
+        remarks = [l for l in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l]
+        other = [l for l in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l and not l.startswith("In file included from")
+                 and "warnings generated" not in l and "warning generated" not in l]
+        if other and verbose:
+            print("\n".join(other), file=sys.stderr, flush=True)
+        if p.returncode != 0:
+            print("\n".join(other), file=sys.stderr, flush=True)
             raise subprocess.CalledProcessError(p.returncode, cmd)
+        # a FUSED kernel (one wave per SIMD, hand-planned register files) that needs scratch has lost its register plan:
+        # accumulators demoted to a stack array are read back without the wait states an MFMA result needs
+        name = None
+        for l in remarks:
+            if "Function Name:" in l:
+                name = l.split("Function Name:")[1].split("[")[0].strip()
+            elif "ScratchSize [bytes/lane]:" in l and name and any(k in name for k in ("k_fwd_bwd_", "k_chain_wide", "k_dw_wide", "k_forward_fast3")):
+                if int(l.split("ScratchSize [bytes/lane]:")[1].split("[")[0]) > 0:
+                    raise RuntimeError(f"{os.path.basename(cmd[-3])}: fused kernel {name} spills to scratch")
     # link next to the target and rename: a rank that waits for the file (bench.py) never maps a half-written library
     tmp = OUT + f".{os.getpid()}.tmp"
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs

@@ -62,6 +62,18 @@ __device__ __forceinline__ float lane_group_sum(float p) {
 // round trip in every k-group (measured: 18-20 cycles of tile time per LDS instruction); sched_group_barrier pipelines made
 // it serialise the accumulators (one tile's whole K loop at a time, a dependent MFMA chain).
 #define MID_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Placement of NE LDS operations under the NMF MFMAs of a dW phase (k-step-major MFMA order): the first N1 of them are the
+// k-steps 2, 3 operands, which must be on their way before the MFMAs of k-step 2 read their registers -- they ride under the
+// MFMAs of k-step 0 (slots [0, NMF / 4)); the others follow in slots [NMF / 4, NMF).  ops_before(j) = operations in slots < j.
+__host__ __device__ constexpr int mid_op_slot(int e, int N1, int NE, int NMF) {
+    const int Q = NMF / 4;
+    return e < N1 ? (e * Q) / N1 : Q + ((e - N1) * (NMF - Q)) / (NE - N1 > 0 ? NE - N1 : 1);
+}
+__host__ __device__ constexpr int mid_ops_before(int j, int N1, int NE, int NMF) {
+    int c = 0;
+    for (int e = 0; e < NE; ++e) c += mid_op_slot(e, N1, NE, NMF) < j ? 1 : 0;
+    return c;
+}
 
 #define MID_WAVES 4
 #define MID_THREADS 256
@@ -455,7 +467,8 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int u = 0; u < MU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             // extra LDS operations threaded through the chain: NW parkings (B(NM) only), then NR reads in the last RG k-groups
-            constexpr int NW = l == NM ? TZ : 0, NR = TZ + TAl + MU, RG = KGn >= 2 ? 2 : 1;
+            // (with two k-groups the reads wait for the second one: every parking must precede every read in program order)
+            constexpr int NW = l == NM ? TZ : 0, NR = TZ + TAl + MU, RG = KGn >= 3 ? 2 : 1;
             auto extra = [&](auto e_) __attribute__((always_inline)) {
                 constexpr int e = decltype(e_)::value;
                 if constexpr (e < NW) *reinterpret_cast<f32x4*>(dbl + e * 256 + i16 * 16 + 4 * g) = dz[e];
@@ -528,8 +541,7 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                 sfor<0, NMF>(SFOR_LAMBDA(j) {
                     constexpr int j = SFOR_VAL(j), sj = j / (TZ * TAl), tj = (j / TAl) % TZ, uj = j % TAl;
                     mfma16_acc<(TZ * TAl > 1)>(dW[C::dwoff(l) + tj * TAl + uj], Aop[tj][sj], Bop[uj][sj]);
-                    // operation e rides in slot e * NMF / NE
-                    sfor<(j * NE + NMF - 1) / NMF, ((j + 1) * NE + NMF - 1) / NMF>(SFOR_LAMBDA(e) { under(std::integral_constant<int, SFOR_VAL(e)>{}); });
+                    sfor<mid_ops_before(j, N1, NE, NMF), mid_ops_before(j + 1, N1, NE, NMF)>(SFOR_LAMBDA(e) { under(std::integral_constant<int, SFOR_VAL(e)>{}); });
                     MID_FENCE();
                 });
                 if constexpr (l == 1) {
@@ -557,14 +569,14 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
             sfor<0, NMF>(SFOR_LAMBDA(j) {
                 constexpr int j = SFOR_VAL(j), sj = j / (C::MT0 * C::NT0), tj = (j / C::NT0) % C::MT0, uj = j % C::NT0;
                 mfma16_acc<(C::MT0 * C::NT0 > 1)>(dW[C::dwoff(0) + tj * C::NT0 + uj], Aop[tj][sj], Bop[uj][sj]);
-                sfor<(j * NE + NMF - 1) / NMF, ((j + 1) * NE + NMF - 1) / NMF>(SFOR_LAMBDA(e) { under(std::integral_constant<int, SFOR_VAL(e)>{}); });
+                sfor<mid_ops_before(j, N1, NE, NMF), mid_ops_before(j + 1, N1, NE, NMF)>(SFOR_LAMBDA(e) { under(std::integral_constant<int, SFOR_VAL(e)>{}); });
                 MID_FENCE();
             });
         }
         MSTAMP(4 + 2 * NM);
         }   // !FWD
     }
-    if constexpr (FWD) return;
+    if constexpr (!FWD) {
     mfma_drain();
 
     // ---- epilogue: every wave stages its dW tiles [wave][tile][lane] (16 B per lane), wave t % 4 sums the 4 copies of
@@ -572,12 +584,13 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
     const double wtot = wave_sum(stat);
     if (lane == 0) red[wave] = wtot;
     float* slab = slabs + (size_t)blockIdx.x * pitch;
-#pragma unroll
-    for (int t0 = 0; t0 < C::DW_TILES; t0 += C::EP_TILES) {
+    // (compile-time pass and tile indices throughout: a run-time index into dW would turn the accumulators into a
+    // scratch array, read back without the wait states an MFMA result needs)
+    sfor<0, (C::DW_TILES + C::EP_TILES - 1) / C::EP_TILES>(SFOR_LAMBDA(pass) {
+        constexpr int t0 = SFOR_VAL(pass) * C::EP_TILES, t1 = t0 + C::EP_TILES < C::DW_TILES ? t0 + C::EP_TILES : C::DW_TILES;
         __syncthreads();                   // images / blocks (or the previous pass) are dead
         f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::EP_TILES * 64);
-#pragma unroll
-        for (int t = t0; t < t0 + C::EP_TILES && t < C::DW_TILES; ++t) mine[(t - t0) * 64 + lane] = dW[t];
+        sfor<t0, t1>(SFOR_LAMBDA(t) { mine[(SFOR_VAL(t) - t0) * 64 + lane] = dW[SFOR_VAL(t)]; });
         __syncthreads();
         sfor<0, NM + 1>(SFOR_LAMBDA(l) {
             constexpr int l = SFOR_VAL(l);
@@ -603,7 +616,7 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                     }
                 }
         });
-    }
+    });
     {
         // last layer: reduce the per-row partials over the 16 lanes of a lane group, then over the 4 waves
         constexpr int TP = C::TR(LL), inL = C::in(LL);
@@ -637,6 +650,7 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
         for (int w = 0; w < MID_WAVES; ++w) t += red[w];
         pstat[blockIdx.x] = t;
     }
+    }   // !FWD
 }
 
 // host: flat parameter index -> offset in the weight image (map[j]); no transposed copy (map[P + j] = -1)

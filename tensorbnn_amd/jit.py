@@ -160,7 +160,7 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                     f.write(source(dims, hact, lact, bern, fam))
                 cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
                 cmd += NARROW_FLAGS + extra      # as build.py compiles the kernels (VGPR-form chain MFMAs)
-                cmd += ["-o", tmp, src]
+                cmd += ["-Rpass-analysis=kernel-resource-usage", "-o", tmp, src]      # the remarks carry each kernel's ScratchSize
                 if verbose:
                     print(" ".join(cmd), flush=True)
                 try:
@@ -168,6 +168,11 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                     rc, err = r.returncode, r.stderr
                 except OSError as e:
                     rc, err = -1, str(e)
+                # a fused kernel that needs scratch memory has lost its register plan (accumulators demoted to a stack array
+                # are read back without the wait states an MFMA result needs): refuse it, the next family takes the shape
+                spills = [int(m) for m in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", err)]
+                if rc == 0 and any(v > 0 for v in spills):
+                    rc, err = 1, f"{src}:1:1: error: kernel family {fam} spills to scratch for this shape ({max(spills)} bytes per lane)\n"
                 for f_ in (src,):
                     if os.path.exists(f_):
                         os.remove(f_)
