@@ -133,6 +133,11 @@ struct WideCfg {
         for (int l = NM; l >= 1; --l) if (c >= cB(l) && c < cB(l) + KG(out(l))) return TR(l);
         return 0;
     }
+    static constexpr int chunk_ksteps(int c) {                 // k-steps of chunk c (the last k-group of a segment may be partial)
+        for (int l = 1; l <= NM; ++l) if (c >= cF(l) && c < cF(l) + KG(in(l))) return ksteps(in(l), c - cF(l));
+        for (int l = NM; l >= 1; --l) if (c >= cB(l) && c < cB(l) + KG(out(l))) return ksteps(out(l), c - cB(l));
+        return 0;
+    }
     static constexpr int maxGran() { int m = 0; for (int c = 0; c < NCH; ++c) m = chunk_gran(c) > m ? chunk_gran(c) : m; return m; }
     // 1-KB granule j of chunk c sits at PERM + (j * GS + c) KB: the granules of ONE chunk -- which every workgroup of
     // the grid reads at about the same time -- are GS KB apart (GS odd), so they spread over the L2 channels
@@ -260,6 +265,67 @@ __device__ __forceinline__ void wide_stage(int base, f32x4 (&stgs)[WIDE_PD][Wide
         }
 }
 
+// ---- hand-scheduled chunk (WIDE_HANDSCHED, default): the compiler issues the 13 A-operand reads of the next chunk in one
+// burst in front of the chunk barrier and drains them there (s_waitcnt lgkmcnt(0) precedes every s_barrier): ~300 of a
+// chunk's ~2,150 cycles at configs[3].  Here the MFMAs of a chunk run in tile GROUPS of two (k-step-major inside a group: an
+// accumulator is revisited every second MFMA, 64 cycles > the 40-cycle dependent latency), so a group's operand registers are
+// dead after 8 MFMAs and take the SAME tiles of chunk c+1 right then -- that slot was parked two barriers ago and is visible
+// to every wave.  Only the last group's operands have no MFMAs behind them in this chunk: they are requested at the top of
+// the next one, where they are needed last.  Scheduling fences (nothing crosses sched_barrier(0)) pin the order.
+#ifndef WIDE_HANDSCHED
+#define WIDE_HANDSCHED 1
+#endif
+#define WIDE_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <class S>
+struct WideSched {
+    using C = WideCfg<S>;
+    static constexpr int ngroups(int nt) { return nt / 2 > 1 ? nt / 2 : 1; }
+    static constexpr int gstart(int nt, int gi) { return 2 * gi; }
+    static constexpr int gend(int nt, int gi) { return gi == ngroups(nt) - 1 ? nt : 2 * gi + 2; }
+    static constexpr int deferred_from(int nt) { return gstart(nt, ngroups(nt) - 1); }   // first tile of the last group
+};
+// address of tile t of chunk cc in ring position rc (compile-time cc; RESIDENT: the image itself)
+template <class S, bool FWD>
+__device__ __forceinline__ const float* wide_tile_ptr(int base, int c, int cc_gran_off, const float* __restrict__ ring, int lane, int t) {
+    using C = WideCfg<S>;
+    return (C::RESIDENT ? ring + cc_gran_off : ring + ((base + c) & (WIDE_RING - 1)) * C::SLOT_FLOATS) + lane * 4 + t * 256;
+}
+// chunk c of the stream: Anx[t] holds (or has in flight) the A operand of tile t for t < deferred_from(tiles of chunk c-1)
+template <class S, int c, bool FWD>
+__device__ __forceinline__ void wide_chunk(int base, f32x4 (&Anx)[WideCfg<S>::MAXT], f32x4* acc, const f32x4& bk, f32x4 (&stgs)[WIDE_PD][WideCfg<S>::NGW],
+                                           float* __restrict__ ring, const float* __restrict__ img, int wave, int lane) {
+    using C = WideCfg<S>;
+    using W = WideSched<S>;
+    constexpr int NCHE = FWD ? C::NCHF : C::NCH;
+    constexpr int cc = c % NCHE, cp = (c + NCHE - 1) % NCHE, cn = (c + 1) % NCHE;
+    constexpr int NT = C::chunk_tiles(cc), NTP = C::chunk_tiles(cp), NTN = C::chunk_tiles(cn);
+    constexpr int K = C::chunk_ksteps(cc);
+    // the operands the previous chunk could not request behind its own MFMAs
+#pragma unroll
+    for (int t = W::deferred_from(NTP); t < NT; ++t) Anx[t] = *reinterpret_cast<const f32x4*>(wide_tile_ptr<S, FWD>(base, c, C::gran_off(cc, 0), ring, lane, t));
+    WIDE_FENCE();
+    constexpr int NG = W::ngroups(NT);
+    sfor<0, NG>(SFOR_LAMBDA(gi) {
+        constexpr int gi = SFOR_VAL(gi), t0 = W::gstart(NT, gi), t1 = W::gend(NT, gi);
+#pragma unroll
+        for (int s = 0; s < K; ++s)
+#pragma unroll
+            for (int t = t0; t < t1; ++t) acc[t] = mfma16(Anx[t][s], bk[s], acc[t]);
+        WIDE_FENCE();
+        if constexpr (gi == 0) {                  // park chunk c+2, fetch chunk c+2+PD: under the second group's MFMAs
+            wide_stage<S, c, FWD>(base, stgs, ring, img, wave, lane);
+            WIDE_FENCE();
+        }
+        if constexpr (gi + 1 < NG) {
+#pragma unroll
+            for (int t = t0; t < t1; ++t)
+                if (t < NTN) Anx[t] = *reinterpret_cast<const f32x4*>(wide_tile_ptr<S, FWD>(base, c + 1, C::gran_off(cn, 0), ring, lane, t));
+            WIDE_FENCE();
+        }
+    });
+    WIDE_CHUNK_BARRIER();
+}
+
 // A operands of chunk c (already visible in its ring slot: parked two chunks earlier, one barrier ago)
 template <class S, int c, bool FWD = false>
 __device__ __forceinline__ void wide_load_A(int base, f32x4 (&A)[WideCfg<S>::MAXT], const float* __restrict__ ring, int lane) {
@@ -317,11 +383,18 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     for (int e = lane; e < C::XIMG_FLOATS; e += 64) ximg[e] = 0.f;
     __syncthreads();
     if (g == 0) ximg[i16 * C::PX + d_in] = 1.f;               // ones column of the x image (db_0)
-#ifdef WIDE_APREFETCH
-    // the A operands of chunk c+1 are read at the top of chunk c (double buffer): the LDS latency sits under
-    // chunk c's MFMAs and the barrier's lgkmcnt(0) finds the queue empty
-    f32x4 Acur[C::MAXT];
-    wide_load_A<S, 0, FWD>(0, Acur, ring, lane);
+#if WIDE_HANDSCHED
+    // operands of chunk 0 that the steady state requests behind the MFMAs of the chunk before it (wide_chunk)
+    f32x4 Anx[C::MAXT];
+    {
+        constexpr int NCHE = FWD ? C::NCHF : C::NCH;
+#pragma unroll
+        for (int t = 0; t < C::MAXT; ++t) {
+            Anx[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < WideSched<S>::deferred_from(C::chunk_tiles(NCHE - 1)) && t < C::chunk_tiles(0))
+                Anx[t] = *reinterpret_cast<const f32x4*>(wide_tile_ptr<S, FWD>(0, 0, C::gran_off(0, 0), ring, lane, t));
+        }
+    }
 #endif
 
     const float sigma = FWD ? 1.f : lik_sigma(nd, eta);
@@ -433,15 +506,13 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             for (int t = 0; t < MT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * t + 4 * g);
             sfor<0, C::KG(C::in(l))>(SFOR_LAMBDA(kg) {
                 constexpr int kg = SFOR_VAL(kg), c = C::cF(l) + kg;
-#ifndef WIDE_APREFETCH
+#if WIDE_HANDSCHED
+                wide_chunk<S, c, FWD>(base, Anx, acc, T.a[kg], stg, ring, img, wave, lane);
+                WSTAMP(9 + 2 * c);
+#else
                 wide_stage<S, c, FWD>(base, stg, ring, img, wave, lane);
                 f32x4 Acur[C::MAXT];
                 wide_load_A<S, c, FWD>(base, Acur, ring, lane);
-#else
-                f32x4 Anext[C::MAXT];
-                wide_load_A<S, c + 1, FWD>(base, Anext, ring, lane);
-                wide_stage<S, c, FWD>(base, stg, ring, img, wave, lane);
-#endif
 #pragma unroll
                 for (int s = 0; s < C::ksteps(C::in(l), kg); ++s)
 #pragma unroll
@@ -449,9 +520,6 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                 WSTAMP(8 + 2 * c);
                 WIDE_CHUNK_BARRIER();
                 WSTAMP(9 + 2 * c);
-#ifdef WIDE_APREFETCH
-#pragma unroll
-                for (int t = 0; t < C::MAXT; ++t) Acur[t] = Anext[t];
 #endif
             });
 #pragma unroll
@@ -532,15 +600,13 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                     for (int u = 0; u < MU; ++u) arel[u] = tvalid ? *reinterpret_cast<const f32x4*>(p + u * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-#ifndef WIDE_APREFETCH
+#if WIDE_HANDSCHED
+                wide_chunk<S, c, false>(base, Anx, acc, dz[kg], stg, ring, img, wave, lane);
+                WSTAMP(9 + 2 * c);
+#else
                 wide_stage<S, c>(base, stg, ring, img, wave, lane);
                 f32x4 Acur[C::MAXT];
                 wide_load_A<S, c>(base, Acur, ring, lane);
-#else
-                f32x4 Anext[C::MAXT];
-                wide_load_A<S, c + 1>(base, Anext, ring, lane);
-                wide_stage<S, c>(base, stg, ring, img, wave, lane);
-#endif
 #pragma unroll
                 for (int s = 0; s < C::ksteps(C::out(l), kg); ++s)
 #pragma unroll
@@ -548,9 +614,6 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                 WSTAMP(8 + 2 * c);
                 WIDE_CHUNK_BARRIER();
                 WSTAMP(9 + 2 * c);
-#ifdef WIDE_APREFETCH
-#pragma unroll
-                for (int u = 0; u < C::MAXT; ++u) Acur[u] = Anext[u];
 #endif
             });
 #pragma unroll
