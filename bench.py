@@ -150,7 +150,7 @@ def rocprof_kernel_us(name):
     """(mean duration in us of the fused pass's kernels by rocprofv3 --kernel-trace --stats, the tracked CSV it comes from)
     from profiles/rocprof_kernel_us.json (written by tools/rocprof_summary.py from the round's committed CSVs), or (None, None)"""
     try:
-        e = json.load(open(os.path.join(ROOT, "profiles", "rocprof_kernel_us.json")))[name]
+        e = json.load(open(os.path.join(ROOT, "profiles", "rocprof_kernel_us.json")))["c5" if name == "c5g" else name]
         return float(e["us"]), e["source"]
     except Exception:
         return None, None
@@ -303,7 +303,8 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get("hbm_bytes_per_launch") if name == "c2" else tj.get(name, {}).get("hbm_bytes_per_launch")
+            key = "c5" if name == "c5g" else name          # (c5g: configs[4]'s kernels on other priors)
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     roofline = None

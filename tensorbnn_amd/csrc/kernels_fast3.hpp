@@ -18,7 +18,17 @@
 // the dW MFMAs (Pipe3), packed instructions kept packed (pkfma*), a 1.5-instruction relu derivative (actc_bwd_mul4).
 // C2: 270 + 67 (4x4x1) + 11 MFMAs, 227 VALU and 148 LDS instructions per 16-row tile.  DESIGN.md section 4.
 #pragma once
+#include <type_traits>
 #include "kernels_fast.hpp"
+
+// compile-time loop (indices usable as template arguments / array subscripts that must stay registers)
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor3(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor3<I + 1, N>(f); }
+}
+#ifndef TBNN_F3_HAND
+#define TBNN_F3_HAND 1
+#endif
 
 // MFMAs per LDS instruction when issue(l) is threaded through dW_{l+1} (0: separate phases, the round-1 schedule).
 // Measured on configs[1]: 54.3 us (0) -> 53.9 us (1..3).
@@ -166,6 +176,151 @@ struct Fwd3 {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) An[mt] = load_ks(wrow + 16 * mt * C::LDW(l), C::ksteps(C::in(l), 0));
         }
+    }
+
+    // ---- hand-scheduled form (TBNN_F3_HAND, default).  Left to itself the compiler requests an LDS operand two MFMAs before
+    // the MFMA that reads it and stalls on the round trip in every k-group, and it gathers the fringe 4x4x1 MFMAs at the end
+    // of the layer, in front of the lane-sum MFMAs that depend on them (ISA of round 2: ~740 of a hidden layer's ~2,150
+    // cycles are not MFMA time).  Here the issue order of a k-group is written out and pinned with scheduling fences
+    // (nothing crosses __builtin_amdgcn_sched_barrier(0)): k-step-major MFMAs, the fringe 4x4x1 behind each k-step, and
+    // under the first MFMAs of the group one LDS read each -- the operands of the NEXT k-group, and in the last full group
+    // the first operands of the next LAYER (A tiles, bias tiles, fringe weights).
+    static constexpr int MTd = C::MTF(l) > 0 ? C::MTF(l) : 1;
+    static constexpr bool M4F = C::NF(l) > 0 && TBNN_F3_M4;                        // fringe dot products on the 4x4x1 MFMA
+    static constexpr int KGl = l == 0 ? 1 : C::KG(l);
+    static constexpr int NFG = (C::MTF(l) == 0 && l > 0) ? KGl : 1;              // fringe-weight k-groups requested ahead (all of them for an all-fringe layer)
+    struct Pre { f32x4 A[MTd]; f32x4 B[MTd]; f32x4 F[NFG]; };
+    static constexpr int NPRE = 2 * C::MTF(l) + (M4F ? NFG : 0);                   // LDS reads of one preload (layer 0: b32 reads, counted per tile)
+    static __device__ __forceinline__ const float* frow(const float* __restrict__ lds, int i16, int g) {
+        return lds + C::woff(l) + (16 * C::MTF(l) + 4 * (i16 & 3)) * C::LDW(l) + (l == 0 ? g : 4 * g);
+    }
+    // read number i of the preload list: A tiles, bias tiles, fringe weights
+    template <int i>
+    static __device__ __forceinline__ void pre_step(Pre& P, const float* __restrict__ lds, int i16, int g) {
+        constexpr int MT = C::MTF(l);
+        if constexpr (i < MT) {
+            if constexpr (l == 0) {
+#pragma unroll
+                for (int t = 0; t < C::KS0; ++t) P.A[i][t] = lds[C::woff(0) + (16 * i + i16) * C::LDW(0) + 4 * t + g];
+            } else {
+                P.A[i] = load_ks(lds + C::woff(l) + i16 * C::LDW(l) + 4 * g + 16 * i * C::LDW(l), C::ksteps(C::in(l), 0));
+            }
+        } else if constexpr (i < 2 * MT) {
+            P.B[i - MT] = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * (i - MT) + 4 * g);
+        } else {
+            constexpr int k = i - 2 * MT;
+            if constexpr (l == 0) {
+                P.F[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < C::KS0; ++t) P.F[0][t] = frow(lds, i16, g)[4 * t];
+            } else {
+                P.F[k] = load_ks(frow(lds, i16, g) + 16 * k, C::ksteps(C::in(l), k));
+            }
+        }
+    }
+    static __device__ __forceinline__ void pre_all(Pre& P, const float* __restrict__ lds, int i16, int g) {
+        sfor3<0, NPRE>([&](auto i_) __attribute__((always_inline)) { pre_step<decltype(i_)::value>(P, lds, i16, g); });
+    }
+
+    static __device__ __forceinline__ void run_h(Tile3<S>& T, const float* __restrict__ lds, float* wl, int i16, int g, const Pre& P0) {
+        constexpr int MT = C::MTF(l), NF = C::NF(l), K = l == 0 ? C::in(0) : C::in(l), KG = KGl;
+        constexpr bool more = l + 1 < C::NL;
+        using NX = Fwd3<S, (more ? l + 1 : l), IMG>;
+        typename NX::Pre Pn;
+        constexpr int NPN = more ? NX::NPRE : 0;
+        constexpr int NA = KG < TBNN_F3_M4ACC ? KG : TBNN_F3_M4ACC;
+        f32x4 acc[MTd], pa[NA];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = P0.B[mt];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) pa[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 An[MTd], Fn = P0.F[0];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) An[mt] = P0.A[mt];
+        // the next layer's preload rides in the last FULL k-group (or the only one)
+        constexpr int PG = (KG >= 2 && (l == 0 ? 4 : C::ksteps(K, KG - 1)) < 4) ? KG - 2 : KG - 1;
+        sfor3<0, KG>([&](auto kt_) __attribute__((always_inline)) {
+            constexpr int kt = decltype(kt_)::value;
+            constexpr int ns = l == 0 ? C::KS0 : C::ksteps(K, kt);
+            f32x4 A4[MTd], F4 = (MT == 0 && l > 0) ? P0.F[kt] : Fn;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) A4[mt] = An[mt];
+            // reads that ride in this group: the next group's operands (MT tiles + fringe weights), then the preload
+            constexpr int NLD1 = (kt + 1 < KG && MT > 0) ? MT + (M4F ? 1 : 0) : 0;
+            constexpr int NLD = NLD1 + (kt == PG ? NPN : 0);
+            auto issue = [&](auto q_) __attribute__((always_inline)) {
+                constexpr int q = decltype(q_)::value;
+                if constexpr (q < NLD1) {
+                    if constexpr (q < MT) An[q] = load_ks(lds + C::woff(l) + i16 * C::LDW(l) + 4 * g + 16 * q * C::LDW(l) + 16 * (kt + 1), C::ksteps(K, kt + 1));
+                    else Fn = load_ks(frow(lds, i16, g) + 16 * (kt + 1), C::ksteps(K, kt + 1));
+                } else if constexpr (q < NLD) {
+                    NX::template pre_step<q - NLD1>(Pn, lds, i16, g);
+                }
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            sfor3<0, ns>([&](auto s_) __attribute__((always_inline)) {
+                constexpr int s = decltype(s_)::value;
+                sfor3<0, MT + (M4F ? 1 : 0)>([&](auto m_) __attribute__((always_inline)) {
+                    constexpr int m = decltype(m_)::value, q = s * (MT + (M4F ? 1 : 0)) + m;
+                    const float bop = l == 0 ? T.x0[s] : T.a[C::aroff(l > 0 ? l - 1 : 0) + kt][s];
+                    if constexpr (m < MT) acc[m] = mfma16(A4[m][s], bop, acc[m]);
+                    else pa[kt % NA] = mfma4(F4[s], bop, pa[kt % NA]);
+                    if constexpr (q < NLD) { issue(std::integral_constant<int, q>{}); __builtin_amdgcn_sched_barrier(0); }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // reads that found no MFMA to ride under (short groups)
+            sfor3<ns * (MT + (M4F ? 1 : 0)), NLD>([&](auto q_) __attribute__((always_inline)) { issue(q_); });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- layer epilogue: fringe lane sums (MFMA), activations, images -- the compiler's order
+        f32x4 pacc = pa[0];
+        if constexpr (M4F) {
+#pragma unroll
+            for (int st = 1; st < NA; st *= 2)
+#pragma unroll
+                for (int a = 0; a + st < NA; a += 2 * st) pa[a] += pa[a + st];
+            pacc = pa[0];
+        }
+        if constexpr (MT > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = actc_fwd<S::act(l)>(acc[mt][r]);
+                T.a[C::aroff(l) + mt] = v;
+            }
+        }
+        if constexpr (NF > 0) {
+            static_assert(TBNN_F3_M4, "the hand-scheduled form computes the fringe units on the 4x4x1 MFMA");
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float z = gsum_mfma(pacc[f]) + lds[C::boff(l) + C::fslot(l, f)];
+                T.af[l][f] = actc_fwd<S::act(l)>(z);
+                if (g == f) v[0] = T.af[l][f];
+            }
+            T.a[C::aroff(l) + MT] = v;
+        }
+        if constexpr (more) {
+            if constexpr (IMG && C::MTF(l + 1 < C::NL ? l + 1 : l) > 0) {
+                constexpr int u1 = C::in(l + 1 < C::NL ? l + 1 : l);
+                float* aimg = wl + C::aoff3(l + 1);
+#pragma unroll
+                for (int mt = 0; mt < C::MT(l); ++mt) {
+                    f32x4 v = T.a[C::aroff(l) + mt];
+                    if constexpr (u1 % 16 != 0) {
+                        constexpr int osl = ones_slot(u1);
+                        if (mt == osl / 16 && g == (osl % 16) / 4) v[osl % 4] = 1.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) aimg[(16 * mt + 4 * g + r) * C::PR + i16] = v[r];
+                }
+            }
+            TSTAMP(1 + l);
+            __builtin_amdgcn_sched_barrier(0);
+            NX::run_h(T, lds, wl, i16, g, Pn);
+        } else { TSTAMP(1 + l); }
     }
 
     static __device__ __forceinline__ void run(Tile3<S>& T, const float* __restrict__ lds, float* wl, int i16, int g,
@@ -447,6 +602,64 @@ struct Bwd3 {
                                                f32x4 (&dzp)[C::MT(l > 0 ? l - 1 : 0)], float (&dzpf)[NFd]) {
         if constexpr (l > 0) {
             constexpr int MTP = C::MTF(l - 1), NFP = C::NF(l - 1), K = C::out(l);
+#if TBNN_F3_HAND
+            if constexpr (MT > 0) {
+                // hand-scheduled chain (see Fwd3::run_h): k-step-major MFMAs, the fringe 4x4x1 behind each k-step, the next
+                // k-group's operands (MTP tiles of W^T + the fringe rows) one read per MFMA under the first MFMAs of the group
+                static_assert(TBNN_F3_M4, "the hand-scheduled form computes the fringe units on the 4x4x1 MFMA");
+                constexpr int KG = C::cdiv(K, 16), MTPd = MTP > 0 ? MTP : 1, NSL = MTP + (NFP > 0 ? 1 : 0);
+                constexpr int NA = KG < TBNN_F3_M4ACC ? KG : TBNN_F3_M4ACC;
+                f32x4 acc[MTPd], pa[NA], An[MTPd], Fn = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < MTP; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a < NA; ++a) pa[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* trow = lds + C::toff(l) + i16 * C::LDT(l) + 4 * g;
+                const float* frow = lds + C::toff(l) + (16 * MTP + 4 * (i16 & 3)) * C::LDT(l) + 4 * g;
+#pragma unroll
+                for (int m = 0; m < MTP; ++m) An[m] = load_ks(trow + 16 * m * C::LDT(l), C::ksteps(K, 0));
+                if constexpr (NFP > 0) Fn = load_ks(frow, C::ksteps(K, 0));
+                sfor3<0, KG>([&](auto kt_) __attribute__((always_inline)) {
+                    constexpr int kt = decltype(kt_)::value, ns = C::ksteps(K, kt);
+                    f32x4 A4[MTPd], F4 = Fn;
+#pragma unroll
+                    for (int m = 0; m < MTP; ++m) A4[m] = An[m];
+                    constexpr int NLD = kt + 1 < KG ? NSL : 0;
+                    auto issue = [&](auto q_) __attribute__((always_inline)) {
+                        constexpr int q = decltype(q_)::value;
+                        if constexpr (q < MTP) An[q] = load_ks(trow + 16 * q * C::LDT(l) + 16 * (kt + 1), C::ksteps(K, kt + 1));
+                        else Fn = load_ks(frow + 16 * (kt + 1), C::ksteps(K, kt + 1));
+                    };
+                    __builtin_amdgcn_sched_barrier(0);
+                    sfor3<0, ns>([&](auto s_) __attribute__((always_inline)) {
+                        constexpr int s = decltype(s_)::value;
+                        sfor3<0, NSL>([&](auto m_) __attribute__((always_inline)) {
+                            constexpr int m = decltype(m_)::value, q = s * NSL + m;
+                            if constexpr (m < MTP) acc[m] = mfma16(A4[m][s], dz[kt][s], acc[m]);
+                            else pa[kt % NA] = mfma4(F4[s], dz[kt][s], pa[kt % NA]);
+                            if constexpr (q < NLD) { issue(std::integral_constant<int, q>{}); __builtin_amdgcn_sched_barrier(0); }
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    sfor3<ns * NSL, NLD>([&](auto q_) __attribute__((always_inline)) { issue(q_); });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                f32x4 pacc = pa[0];
+                if constexpr (NFP > 0) {
+#pragma unroll
+                    for (int st = 1; st < NA; st *= 2)
+#pragma unroll
+                        for (int a = 0; a + st < NA; a += 2 * st) pa[a] += pa[a + st];
+                    pacc = pa[0];
+                }
+                if constexpr (S::act(l - 1) == TBNN_ACT_RELU && TBNN_F3_RELU_PK && MTP >= 1 && MTP <= 4) mfma_settle(acc);
+#pragma unroll
+                for (int m = 0; m < MTP; ++m)
+                    dzp[m] = actc_bwd_mul4<S::act(l - 1), (MTP >= 1 && MTP <= 4)>(acc[m], T.a[C::aroff(l - 1) + m]);
+#pragma unroll
+                for (int f = 0; f < NFP; ++f)
+                    dzpf[f] = actc_bwd_mul<S::act(l - 1)>(gsum_mfma(pacc[f]), T.af[l - 1][f]);
+#else
             // fringe units of layer l-1 first (their shuffles land under the MFMAs)
             float pf[NFP > 0 ? NFP : 1];
             f32x4 pacc = {0.f, 0.f, 0.f, 0.f};
@@ -487,6 +700,7 @@ struct Bwd3 {
 #pragma unroll
                 for (int f = 0; f < NFP; ++f)
                     dzpf[f] = actc_bwd_mul<S::act(l - 1)>(TBNN_F3_M4 ? gsum_mfma(pacc[f]) : gsum(pf[f]), T.af[l - 1][f]);
+#endif
             } else {
                 // all-fringe layer (the VALU last layer): K = NF fringe deltas, weights W_l[o][slot] read per lane
 #pragma unroll
@@ -1064,8 +1278,13 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int l = 1; l < C::NLM3; ++l)
         if (C::in(l) % 16 == 0 && g == 0) wl[C::aoff3(l) + C::in(l) * C::PR + i16] = 1.f;
+#if TBNN_F3_HAND
+    typename Fwd3<S, 0>::Pre P0;                 // layer 0's operands (A, bias, fringe weights): the same for every tile
+    Fwd3<S, 0>::pre_all(P0, lds, i16, g);
+#else
     f32x4 A0[C::MTF(0) > 0 ? C::MTF(0) : 1], B0[C::MTF(0) > 0 ? C::MTF(0) : 1];
     Fwd3<S, 0>::preload(A0, B0, lds, i16, g);
+#endif
 
     bool first = true;
     // the W^T images in flight: every wave of the workgroup must meet ONE barrier behind its own wait.  When all four waves
@@ -1090,7 +1309,11 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         for (int o = 0; o < d_out; ++o) y[o] = yn[o];
         fetch(tile + W);
         TSTAMP(0);
+#if TBNN_F3_HAND
+        Fwd3<S, 0>::run_h(T, lds, wl, i16, g, P0);
+#else
         Fwd3<S, 0>::run(T, lds, wl, i16, g, A0, B0);
+#endif
         if (wt_pending) {                       // first tile only, the same on all four waves
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1229,8 +1452,13 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     constexpr int d_in = C::in(0), d_out = C::out(C::NL - 1), L = C::NL - 1;
     const long ntiles = (n + 15) / 16;
     const long W = (long)gridDim.x * FAST_WAVES;
+#if TBNN_F3_HAND
+    typename Fwd3<S, 0, false>::Pre P0;
+    Fwd3<S, 0, false>::pre_all(P0, lds, i16, g);
+#else
     f32x4 A0[C::MTF(0) > 0 ? C::MTF(0) : 1], B0[C::MTF(0) > 0 ? C::MTF(0) : 1];
     Fwd3<S, 0, false>::preload(A0, B0, lds, i16, g);
+#endif
     for (long tile = (long)blockIdx.x * FAST_WAVES + wave; tile < ntiles; tile += W) {
         Tile3<S> T;
         const long row = tile * 16 + i16;
@@ -1240,7 +1468,11 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             const int u = 4 * t + g;
             T.x0[t] = (ok && u < d_in) ? X[row * d_in + u] : 0.f;
         }
+#if TBNN_F3_HAND
+        Fwd3<S, 0, false>::run_h(T, lds, nullptr, i16, g, P0);
+#else
         Fwd3<S, 0, false>::run(T, lds, nullptr, i16, g, A0, B0);
+#endif
         if (ok && g == 0) {
 #pragma unroll
             for (int o = 0; o < d_out; ++o) fout[(size_t)o * n + row] = T.af[L][o];

@@ -128,6 +128,84 @@ def test_free_running_accept_ratio_parity_configs1(native):
     ch.close()
 
 
+def test_log_accept_ratio_band_against_fp64(native):
+    """Which arm is off when a burned-in log accept ratio differs between the HIP path and oracle/c?  Ten free-running
+    configs[1] epochs (n = 1e5, L = 10) from the burned-in state; every epoch's trajectory is also integrated by the fp64
+    NumPy oracle from the HIP chain's own start state, and both fp32 arms are compared with it SEPARATELY.  The HIP path (fp32
+    rows, every energy summed in fp64) must meet the band BASELINE.md section 5 states, 2e-2 + 1e-4 |lar|, on its own; the
+    1e-6 |logp| term of lar_tol() is what the C restatement needs (its log-prob is an fp32-evaluated sum of magnitude 1e5)."""
+    spec, X, Y, theta, eta = o.synth_problem([5, 50, 50, 50, 1], 100_000)
+    z = np.load(os.path.join(GOLDEN, "c2_burned.npz"))
+    theta, eta, eps = z["theta"].astype(np.float32), z["eta"].astype(np.float32), float(z["eps"])
+    ch = native.Chain(layers_of(spec), likelihood=spec.likelihood)
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    co = c_oracle.COracle(spec, X, Y)
+    rng = np.random.default_rng(31)
+    L, rows = 10, []
+    for ep in range(10):
+        th = ch.get_state()
+        p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+        ref = o.weight_step(spec, th, eta, X, Y, eps, L, p0, 0.0, np.float64)
+        _, lar_c, lp0_c, _ = co.hmc_propose(th, eta, eps, L, p0)
+        lu = away_from(rng, ref.log_accept_ratio)
+        out = ch.hmc_step(eps, L, p0=p0, log_u=lu)
+        assert bool(out["accepted"]) == (lu < ref.log_accept_ratio)
+        rows.append((ref.log_accept_ratio, out["log_accept_ratio"] - ref.log_accept_ratio, lar_c - ref.log_accept_ratio, lp0_c))
+    rows = np.array(rows)
+    band = 2e-2 + 1e-4 * np.abs(rows[:, 0])
+    print("lar (fp64)            :", np.array2string(rows[:, 0], precision=3))
+    print("HIP - fp64            :", np.array2string(rows[:, 1], precision=4), "max / band", float(np.max(np.abs(rows[:, 1]) / band)))
+    print("oracle/c - fp64       :", np.array2string(rows[:, 2], precision=4), "max / band", float(np.max(np.abs(rows[:, 2]) / band)))
+    assert np.all(np.abs(rows[:, 1]) <= band), rows                    # the product path meets the stated band
+    assert np.all(np.abs(rows[:, 2]) <= [lar_tol(r[0], r[3]) for r in rows]), rows
+    ch.close()
+
+
+def free_running_wide(native, name, dims, n, lik, epochs, L, family):
+    """free-running chain at the burned-in state of a wide config against oracle/c: same p0 / log u, each arm carries its own state"""
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, o.ACT_RELU, o.PRIOR_CAUCHY, lik)
+    z = np.load(os.path.join(GOLDEN, f"{name}_burned.npz"))
+    theta, eta, eps = z["theta"].astype(np.float32), z["eta"].astype(np.float32), float(z["eps"])
+    ch = native.Chain(layers_of(spec), likelihood=spec.likelihood)
+    assert ch.kernel_name.startswith(family), ch.kernel_name
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    co = c_oracle.COracle(spec, X, Y)
+    rng = np.random.default_rng(77)
+    th_c = theta.copy()
+    acc_g, acc_c, dlar, agree = [], [], [], 0
+    for ep in range(epochs):
+        p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+        q_c, lar_c, lp0_c, _ = co.hmc_propose(th_c, eta, eps, L, p0)
+        lu = away_from(rng, lar_c)
+        if lu < lar_c:
+            th_c = q_c
+        out = ch.hmc_step(eps, L, p0=p0, log_u=lu)
+        agree += int(bool(out["accepted"]) == (lu < lar_c))
+        dlar.append(abs(out["log_accept_ratio"] - lar_c) / lar_tol(lar_c, lp0_c))
+        acc_g.append(out["accept_prob"]); acc_c.append(min(1.0, float(np.exp(min(lar_c, 0.0)))))
+    mg, mc = float(np.mean(acc_g)), float(np.mean(acc_c))
+    err = float(np.abs(ch.get_state() - th_c).max() / np.abs(th_c).max())
+    print(f"free-running {name}: accept ratio HIP {mg:.4f} oracle/c {mc:.4f}; decisions {agree}/{epochs}; max |dlar| / lar_tol {max(dlar):.3f}; "
+          f"relative state distance at the end {err:.1e}")
+    assert abs(mg - mc) <= 0.02, (mg, mc)
+    assert agree == epochs, (agree, max(dlar))
+    assert max(dlar) <= 1.0, max(dlar)
+    assert err <= 1e-4
+    ch.close()
+
+
+def test_free_running_configs4_burned_in(native):
+    """BASELINE configs[4] (20->100->100->2 Bernoulli, n = 5e5) on the kernel bench.py times (k_fwd_bwd_mid) at the state it
+    times: 50 free-running epochs of L = 10 from the burned-in fixture at its step size, against oracle/c"""
+    free_running_wide(native, "c5", [20, 100, 100, 2], 500_000, o.LIK_BERNOULLI, epochs=50, L=10, family="mid<")
+
+
+def test_free_running_configs3_burned_in(native):
+    """BASELINE configs[3] (10->200->200->200->1, n = 1e6) on k_chain_wide + k_dw_wide at the burned-in state: 10 free-running
+    epochs of L = 5 at the fixture's step size, against oracle/c"""
+    free_running_wide(native, "c4", [10, 200, 200, 200, 1], 1_000_000, o.LIK_GAUSSIAN, epochs=10, L=5, family="wide<")
+
+
 @pytest.mark.parametrize("prior", ["cauchy", "gaussian"])
 def test_free_running_hyper_chain_full_parameter_count(native, prior):
     """configs[4]'s P = 12,402 (20->100->100->2): 100 free-running hyper transitions of L_h = 100 with the step size driven by

@@ -2,11 +2,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ctypes as C, numpy as np, os, sys
 import tensorbnn_amd._native as nat
-# load the diagnostic build instead
-dbg = C.CDLL(os.path.join(os.path.dirname(nat.__file__), 'libtbnn_dbg.so'))
-for name, res, args in nat.SYMBOLS:
-    fn = getattr(dbg, name); fn.restype = res; fn.argtypes = args
-nat.lib = dbg
+# the diagnostic build: TBNN_BUILD_TAG=tstamps TBNN_EXTRA_FLAGS=-DTBNN_TILE_STAMPS python -m tensorbnn_amd.build, then
+# TBNN_LIB=tensorbnn_amd/libtbnn_tstamps.so python tools/experiments/tilestamps.py
+dbg = nat.lib
 from tensorbnn_amd.workloads import synth_problem
 layers, lik, X, Y, th, eta = synth_problem([5,50,50,50,1], 114688)
 ch = nat.Chain(layers, likelihood=lik); ch.set_data(X, Y); ch.set_state(th); ch.set_hypers(eta)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One round's rocprofv3 evidence for profiles/: kernel trace + stats and separate PMC passes (never combined with a trace
+# domain) for BASELINE configs[1] (bench.py --workload c2), configs[3] and configs[4] (tools/widetime.py at full size).
+#   tools/profile_round.sh r03b        -> gpurun_out/r03b/{c2,c4,c5}_kernel_stats.csv, *_pmc_summary.json,
+#                                         rocprof_kernel_us.json, pmc_traffic.json   (copy the ones to be judged into profiles/)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+R=${1:-r03}
+OUT=gpurun_out/$R
+mkdir -p $OUT
+declare -A CMD
+CMD[c2]="python3 bench.py --workload c2 --steps 40 --warmup 10 --no-cpu-baseline"
+CMD[c4]="python3 tools/widetime.py c4 10"
+CMD[c5]="python3 tools/widetime.py c5 10"
+for W in ${PROFILE_WORKLOADS:-c2 c4 c5}; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- ${CMD[$W]} > $OUT/trace_$W.log 2>&1 || echo "trace $W failed"
+  f=$(find $OUT/trace_$W -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${W}_kernel_stats.csv
+  i=0
+  for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc_${W}_$i -- ${CMD[$W]} > $OUT/pmc_${W}_$i.log 2>&1 || echo "pmc pass $i ($SET) of $W failed"
+  done
+done
+python3 tools/rocprof_summary.py $OUT
+# keep only the small summaries (the per-dispatch CSVs are large)
+find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
+ls $OUT | head -40
