@@ -373,7 +373,9 @@ def compact_line(line):
     cfg["workload"] = cfg["workload"].split(":")[0] + ":" + cfg["workload"].split(":", 1)[1].split("(")[0].rstrip() \
         if ":" in cfg["workload"] else cfg["workload"]
     cfg.pop("eps_warmup", None)
+    cfg.pop("parallelism", None)
     out["config"] = cfg
+    out.pop("accepted_fraction", None)
     if "secondary" in line:
         sec = {}
         for key, r in line["secondary"].items():
