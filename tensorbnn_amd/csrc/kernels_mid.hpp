@@ -484,32 +484,36 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                     for (int u = 0; u < MU; ++u) A[s][u] = Wn[s][u];
                 MID_FENCE();
-                // k-step 0: one slot per MFMA
-                sfor<0, MU>(SFOR_LAMBDA(u) {
-                    constexpr int u = SFOR_VAL(u);
-                    acc[u] = mfma16(A[0][u], dz[kg][0], acc[u]);
-                    if constexpr (kg + 1 < KGn) chain_load(std::integral_constant<int, l>{}, kg + 1, u);
-                    if constexpr (kg == 0 && NW > 0) {                // parkings: slot u takes e = u, u + MU, ... (all in slot 0 when there is one k-group)
-                        sfor<0, NW>(SFOR_LAMBDA(e) {
-                            constexpr int e = SFOR_VAL(e);
-                            if constexpr (KGn >= 2 ? (e % MU == u) : (u == 0)) extra(std::integral_constant<int, e>{});
-                        });
-                    }
-                    if constexpr (kg >= KGn - RG) {                   // reads: dealt out over the RG * MU slots of the last k-groups
-                        constexpr int q = (kg - (KGn - RG)) * MU + u;
-                        sfor<0, NR>(SFOR_LAMBDA(r) {
-                            constexpr int r = SFOR_VAL(r);
-                            if constexpr ((r * RG * MU) / NR == q) extra(std::integral_constant<int, NW + r>{});
-                        });
-                    }
-                    MID_FENCE();
+                // LDS operations that ride in this k-group, in program order: parkings (first k-group of B(NM)), the next
+                // k-group's W^T values (two k-steps = one ds_read2_b32 per operation), the dW / act' operand reads (last RG
+                // k-groups).  Operation k goes behind MFMA k * SPAN / NOPS: one per MFMA, never in the last k-step (its
+                // results are needed MU MFMAs later at the earliest).
+                constexpr int NWg = kg == 0 ? NW : 0;
+                constexpr int NCg = kg + 1 < KGn ? 2 * MU : 0;
+                constexpr int rg = kg - (KGn - RG);                                         // index among the read groups (< 0: none)
+                constexpr int r0 = rg >= 0 ? (rg * NR) / RG : 0, r1 = rg >= 0 ? ((rg + 1) * NR) / RG : 0;
+                constexpr int NOPS = NWg + NCg + (r1 - r0);
+                constexpr int NMFg = NS * MU, SPAN = NS > 1 ? (NS - 1) * MU : MU;
+                auto op = [&](auto k_) __attribute__((always_inline)) {
+                    constexpr int k = decltype(k_)::value;
+                    if constexpr (k < NWg) extra(std::integral_constant<int, k>{});
+                    else if constexpr (k < NWg + NCg) {
+                        constexpr int c = k - NWg, u = c / 2, h = c % 2;
+                        const float* wcol = lds + C::wmoff(l) + 4 * g * C::LDM(l) + i16;
+#pragma unroll
+                        for (int s2 = 2 * h; s2 < 2 * h + 2; ++s2)
+                            if (s2 < C::ksteps(K, kg + 1)) Wn[s2][u] = wcol[(16 * (kg + 1) + s2) * C::LDM(l) + 16 * u];
+                    } else extra(std::integral_constant<int, NW + r0 + (k - NWg - NCg)>{});
+                };
+                sfor<0, NMFg>(SFOR_LAMBDA(j) {
+                    constexpr int j = SFOR_VAL(j), sj = j / MU, uj = j % MU;
+                    acc[uj] = mfma16(A[sj][uj], dz[kg][sj], acc[uj]);
+                    // operations k with k * SPAN / NOPS == j
+                    constexpr int k0 = NOPS > 0 ? (j * NOPS + SPAN - 1) / SPAN : 0, k1 = NOPS > 0 ? ((j + 1) * NOPS + SPAN - 1) / SPAN : 0;
+                    constexpr int ka = k0 < NOPS ? k0 : NOPS, kb = j + 1 >= NMFg ? NOPS : (k1 < NOPS ? k1 : NOPS);
+                    sfor<ka, kb>(SFOR_LAMBDA(k) { op(std::integral_constant<int, SFOR_VAL(k)>{}); });
+                    if constexpr (kb > ka || uj == MU - 1) MID_FENCE();
                 });
-#pragma unroll
-                for (int s = 1; s < NS; ++s) {
-#pragma unroll
-                    for (int u = 0; u < MU; ++u) acc[u] = mfma16(A[s][u], dz[kg][s], acc[u]);
-                    MID_FENCE();
-                }
             });
             MSTAMP(25 + 3 * SFOR_VAL(li));
             f32x4 dzp[C::MAXT];
