@@ -64,7 +64,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             if "Function Name:" in l:
                 name = l.split("Function Name:")[1].split("[")[0].strip()
             elif "ScratchSize [bytes/lane]:" in l and name and any(k in name for k in ("k_fwd_bwd_", "k_chain_wide", "k_dw_wide", "k_forward_fast3")):
-                if int(l.split("ScratchSize [bytes/lane]:")[1].split("[")[0]) > 0:
+                if int(l.split("ScratchSize [bytes/lane]:")[1].split("[")[0]) > 0 and os.environ.get("TBNN_ALLOW_SPILL") != "1":   # (stamped diagnostic builds)
                     raise RuntimeError(f"{os.path.basename(cmd[-3])}: fused kernel {name} spills to scratch")
     # link next to the target and rename: a rank that waits for the file (bench.py) never maps a half-written library
     tmp = OUT + f".{os.getpid()}.tmp"

@@ -14,8 +14,6 @@ nat.lib.tbnn_debug_wide_stamps.argtypes = [C.POINTER(C.c_uint64)]
 nat.lib.tbnn_debug_wide_stamps(out)
 t = np.array(list(out), dtype=np.float64)
 print("phases: L0 %d | fwd mid %d | last %d | bwd mid %d | dW0 %d | total %d" % (t[1]-t[0], t[2]-t[1], t[3]-t[2], t[4]-t[3], t[5]-t[4], t[5]-t[0]))
-nch = int((np.count_nonzero(t[8:]) ) // 2)
-comp = [t[8+2*c] - (t[9+2*(c-1)] if c > 0 else t[1]) for c in range(nch)]
-bar = [t[9+2*c] - t[8+2*c] for c in range(nch)]
-print("chunk compute cycles:", " ".join("%d" % x for x in comp))
-print("chunk barrier cycles:", " ".join("%d" % x for x in bar))
+ends = [t[9 + 2 * c] for c in range(120) if t[9 + 2 * c] > 0]
+print("chunk-to-chunk cycles (end of barrier to end of barrier; segment boundaries include the layer epilogues):")
+print(" ".join("%d" % (b - a) for a, b in zip(ends[:-1], ends[1:])))
