@@ -285,15 +285,37 @@ struct WideSched {
     static constexpr int deferred_from(int nt) { return gstart(nt, ngroups(nt) - 1); }   // first tile of the last group
 };
 // address of tile t of chunk cc in ring position rc (compile-time cc; RESIDENT: the image itself)
+// WIDE_DIRECT (default; streamed shapes only): the A operands do not go through LDS at all.  The image k_update maintains is
+// already in MFMA A-operand order -- granule t of a chunk is [lane][4], exactly the 16 bytes lane needs for tile t -- so every
+// wave loads its operands straight from L2 (the 4 waves of a workgroup walk the same chunks: the later ones hit the CU's L1)
+// into the registers the hand-scheduled chunk frees, ONE CHUNK (~1,700 cycles) ahead of their use.  No ring, no parking writes,
+// no chunk barrier, no staging registers; the waves of a workgroup no longer wait for each other.  WIDE_DIRECT=0: the 4-slot
+// LDS ring of rounds 1-2.
+#ifndef WIDE_DIRECT
+#define WIDE_DIRECT 1
+#endif
+template <class S> struct WideDirect { static constexpr bool value = WIDE_DIRECT && WIDE_HANDSCHED && !WideCfg<S>::RESIDENT; };
 template <class S, bool FWD>
 __device__ __forceinline__ const float* wide_tile_ptr(int base, int c, int cc_gran_off, const float* __restrict__ ring, int lane, int t) {
     using C = WideCfg<S>;
     return (C::RESIDENT ? ring + cc_gran_off : ring + ((base + c) & (WIDE_RING - 1)) * C::SLOT_FLOATS) + lane * 4 + t * 256;
 }
+// direct mode: tile t of stream chunk cc in the global image (granules of one chunk are GS KB apart: L2-channel spreading).
+// A buffer load: resource descriptor in SGPRs, the granule's byte offset an SGPR (+ `opq`, an opaque zero renewed every row
+// tile so that the loads are not hoisted out of the row loop), the lane's 16 bytes the only VGPR -- no address arithmetic on
+// the VALU (global_load with 64-bit pointers cost two VALU adds per load: +280 instructions per 16-row tile).
+struct WideImg { __amdgpu_buffer_rsrc_t rs; int opq; };
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <class S>
+__device__ __forceinline__ f32x4 wide_tile_direct(const WideImg& im, int cc, int lane, int t) {
+    using C = WideCfg<S>;
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(im.rs, lane * 16, im.opq + (int)((C::PERM_FLOATS + (t * C::GS + cc) * 256) * 4), 0);
+    return __builtin_bit_cast(f32x4, v);
+}
 // chunk c of the stream: Anx[t] holds (or has in flight) the A operand of tile t for t < deferred_from(tiles of chunk c-1)
 template <class S, int c, bool FWD>
 __device__ __forceinline__ void wide_chunk(int base, f32x4 (&Anx)[WideCfg<S>::MAXT], f32x4* acc, const f32x4& bk, f32x4 (&stgs)[WIDE_PD][WideCfg<S>::NGW],
-                                           float* __restrict__ ring, const float* __restrict__ img, int wave, int lane) {
+                                           float* __restrict__ ring, const float* __restrict__ img, const WideImg& im, int wave, int lane) {
     using C = WideCfg<S>;
     using W = WideSched<S>;
     constexpr int NCHE = FWD ? C::NCHF : C::NCH;
@@ -301,8 +323,10 @@ __device__ __forceinline__ void wide_chunk(int base, f32x4 (&Anx)[WideCfg<S>::MA
     constexpr int NT = C::chunk_tiles(cc), NTP = C::chunk_tiles(cp), NTN = C::chunk_tiles(cn);
     constexpr int K = C::chunk_ksteps(cc);
     // the operands the previous chunk could not request behind its own MFMAs
+    constexpr bool DIRECT = WideDirect<S>::value;
 #pragma unroll
-    for (int t = W::deferred_from(NTP); t < NT; ++t) Anx[t] = *reinterpret_cast<const f32x4*>(wide_tile_ptr<S, FWD>(base, c, C::gran_off(cc, 0), ring, lane, t));
+    for (int t = W::deferred_from(NTP); t < NT; ++t)
+        Anx[t] = DIRECT ? wide_tile_direct<S>(im, cc, lane, t) : *reinterpret_cast<const f32x4*>(wide_tile_ptr<S, FWD>(base, c, C::gran_off(cc, 0), ring, lane, t));
     WIDE_FENCE();
     constexpr int NG = W::ngroups(NT);
     sfor<0, NG>(SFOR_LAMBDA(gi) {
@@ -312,18 +336,20 @@ __device__ __forceinline__ void wide_chunk(int base, f32x4 (&Anx)[WideCfg<S>::MA
 #pragma unroll
             for (int t = t0; t < t1; ++t) acc[t] = mfma16(Anx[t][s], bk[s], acc[t]);
         WIDE_FENCE();
-        if constexpr (gi == 0) {                  // park chunk c+2, fetch chunk c+2+PD: under the second group's MFMAs
+        if constexpr (gi == 0 && !DIRECT) {       // park chunk c+2, fetch chunk c+2+PD: under the second group's MFMAs
             wide_stage<S, c, FWD>(base, stgs, ring, img, wave, lane);
             WIDE_FENCE();
         }
         if constexpr (gi + 1 < NG) {
 #pragma unroll
             for (int t = t0; t < t1; ++t)
-                if (t < NTN) Anx[t] = *reinterpret_cast<const f32x4*>(wide_tile_ptr<S, FWD>(base, c + 1, C::gran_off(cn, 0), ring, lane, t));
+                if (t < NTN)
+                    Anx[t] = DIRECT ? wide_tile_direct<S>(im, cn, lane, t)
+                                    : *reinterpret_cast<const f32x4*>(wide_tile_ptr<S, FWD>(base, c + 1, C::gran_off(cn, 0), ring, lane, t));
             WIDE_FENCE();
         }
     });
-    WIDE_CHUNK_BARRIER();
+    if constexpr (!DIRECT) WIDE_CHUNK_BARRIER();
 }
 
 // A operands of chunk c (already visible in its ring slot: parked two chunks earlier, one barrier ago)
@@ -362,11 +388,12 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         reinterpret_cast<float4*>(lds)[e] = reinterpret_cast<const float4*>(qimg)[e];
     float* ring = C::RESIDENT ? lds : lds + C::RING_OFF;
     f32x4 stg[WIDE_PD][C::NGW];
+    constexpr bool DIRECT = WideDirect<S>::value;
     sfor<0, 2>(SFOR_LAMBDA(c) {
         constexpr int c = SFOR_VAL(c);
 #pragma unroll
         for (int j = 0; j < C::NGW; ++j)
-            if (!C::RESIDENT && j < C::chunk_gran(c) / WIDE_WAVES)
+            if (!C::RESIDENT && !DIRECT && j < C::chunk_gran(c) / WIDE_WAVES)
                 *reinterpret_cast<f32x4*>(ring + c * C::SLOT_FLOATS + (wave + j * WIDE_WAVES) * 256 + lane * 4) =
                     *reinterpret_cast<const f32x4*>(qimg + C::gran_off(c, 0) + (wave + j * WIDE_WAVES) * C::gran_step(c) + lane * 4);
     });
@@ -374,7 +401,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         constexpr int k = SFOR_VAL(k), c = (2 + k) % (FWD ? C::NCHF : C::NCH);
 #pragma unroll
         for (int j = 0; j < C::NGW; ++j)
-            stg[k][j] = (!C::RESIDENT && j < C::chunk_gran(c) / WIDE_WAVES)
+            stg[k][j] = (!C::RESIDENT && !DIRECT && j < C::chunk_gran(c) / WIDE_WAVES)
                             ? *reinterpret_cast<const f32x4*>(qimg + C::gran_off(c, 0) + (wave + j * WIDE_WAVES) * C::gran_step(c) + lane * 4)
                             : f32x4{0.f, 0.f, 0.f, 0.f};
     });
@@ -392,7 +419,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         for (int t = 0; t < C::MAXT; ++t) {
             Anx[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t < WideSched<S>::deferred_from(C::chunk_tiles(NCHE - 1)) && t < C::chunk_tiles(0))
-                Anx[t] = *reinterpret_cast<const f32x4*>(wide_tile_ptr<S, FWD>(0, 0, C::gran_off(0, 0), ring, lane, t));
+                Anx[t] = DIRECT ? wide_tile_direct<S>(WideImg{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qimg), 0, C::IMG_FLOATS * 4, 0x00020000), 0}, 0, lane, t) : *reinterpret_cast<const f32x4*>(wide_tile_ptr<S, FWD>(0, 0, C::gran_off(0, 0), ring, lane, t));
         }
     }
 #endif
@@ -437,6 +464,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         int opaque0 = 0;
         asm volatile("" : "+s"(opaque0));
         const float* img = qimg + opaque0;
+        const WideImg im = {__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qimg), 0, C::IMG_FLOATS * 4, 0x00020000), opaque0};
         const long tile = blk * WIDE_WAVES + wave;
         const bool tvalid = tile < ntiles;
 #ifdef WIDE_DBG_STORE0
@@ -507,7 +535,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             sfor<0, C::KG(C::in(l))>(SFOR_LAMBDA(kg) {
                 constexpr int kg = SFOR_VAL(kg), c = C::cF(l) + kg;
 #if WIDE_HANDSCHED
-                wide_chunk<S, c, FWD>(base, Anx, acc, T.a[kg], stg, ring, img, wave, lane);
+                wide_chunk<S, c, FWD>(base, Anx, acc, T.a[kg], stg, ring, img, im, wave, lane);
                 WSTAMP(9 + 2 * c);
 #else
                 wide_stage<S, c, FWD>(base, stg, ring, img, wave, lane);
@@ -601,7 +629,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                     for (int u = 0; u < MU; ++u) arel[u] = tvalid ? *reinterpret_cast<const f32x4*>(p + u * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
 #if WIDE_HANDSCHED
-                wide_chunk<S, c, false>(base, Anx, acc, dz[kg], stg, ring, img, wave, lane);
+                wide_chunk<S, c, false>(base, Anx, acc, dz[kg], stg, ring, img, im, wave, lane);
                 WSTAMP(9 + 2 * c);
 #else
                 wide_stage<S, c>(base, stg, ring, img, wave, lane);
