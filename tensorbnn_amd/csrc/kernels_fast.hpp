@@ -198,6 +198,18 @@ __device__ __forceinline__ void mfma_drain() {
     asm volatile("s_nop 15\n\ts_nop 15");
 #endif
 }
+// ... and every later read of the accumulators ordered BEHIND the drain: volatile asm statements keep their order, and an
+// empty one that "modifies" acc[t] makes each later use of acc[t] depend on it.  (mfma_drain() alone orders nothing that has
+// no side effect: in k_dw_wide the compiler placed a v_accvgpr_read of the last accumulator straight behind the MFMA that
+// wrote it, ahead of the drain -- garbage in the last tiles.)
+template <int N>
+__device__ __forceinline__ void mfma_drain_acc(f32x4 (&acc)[N]) {
+    mfma_drain();
+#if TBNN_ACC_AGPR
+#pragma unroll
+    for (int t = 0; t < N; ++t) asm volatile("" : "+a"(acc[t]));
+#endif
+}
 
 // ---- instruction-level helpers shared by the narrow (kernels_fast3.hpp) and wide (kernels_wide.hpp) kernels ----
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -786,7 +798,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         if (first) { TB_STAMP(2); first = false; }
     }
     TB_STAMP(3);
-    mfma_drain();
+    mfma_drain_acc(dW);
     if (stamps && blockIdx.x == 0 && lane == 0) stamps[12 + wave] = wall_clock64();
 
     // ---- epilogue: every wave stages its dW tiles [wave][tile][lane] (16 B per lane), wave t%4 sums the

@@ -1353,7 +1353,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         if (first) { TB_STAMP(2); first = false; }
     }
     TB_STAMP(3);
-    mfma_drain();
+    mfma_drain_acc(dW);
     f32x4 dWc[CO::DWC];
 #pragma unroll
     for (int t = 0; t < CO::DWC; ++t) dWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
         }   // !FWD
     }
     if constexpr (!FWD) {
-    mfma_drain();
+    mfma_drain_acc(dW);
 
     // ---- epilogue: every wave stages its dW tiles [wave][tile][lane] (16 B per lane), wave t % 4 sums the 4 copies of
     // tile t in fixed order and writes the dense slab (theta order); EP_TILES per pass.  Deterministic.

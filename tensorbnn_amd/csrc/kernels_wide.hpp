@@ -193,8 +193,14 @@ struct WideCfg {
 #ifndef WIDE_DW_OCC_MAX
 #define WIDE_DW_OCC_MAX 2
 #endif
+#if !defined(WIDE_TBLOCK) || WIDE_TBLOCK
+    // (transposed blocks, operands straight into registers: no LDS; two waves per SIMD when accumulators + operand sets fit)
+    static constexpr int maxSmall() { int m = 0; for (int l = 1; l <= NM; ++l) { int v = TA(l) + 2 * QM(l) + 4 * QP(l); m = v > m ? v : m; } return m; }
+    static constexpr int DW_OCC = (WIDE_DW_OCC_MAX >= 2 && 4 * maxDWT() + 4 * maxSmall() + 40 <= 232) ? 2 : 1;
+#else
     static constexpr int DW_OCC = (WIDE_DW_OCC_MAX >= 2 && 2 * WIDE_RING * DW_SLOT_FLOATS * 4 <= 150 * 1024 &&
                                    4 * maxDWT() + 4 * DW_NGW * WIDE_DW_PD + 48 <= 232) ? 2 : 1;
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -305,6 +311,34 @@ __device__ __forceinline__ const float* wide_tile_ptr(int base, int c, int cc_gr
 // tile so that the loads are not hoisted out of the row loop), the lane's 16 bytes the only VGPR -- no address arithmetic on
 // the VALU (global_load with 64-bit pointers cost two VALU adds per load: +280 instructions per 16-row tile).
 struct WideImg { __amdgpu_buffer_rsrc_t rs; int opq; };
+// ---- stored blocks, transposed layout (WIDE_TBLOCK, default).  A 1-KB block holds [16 rows][16 slots] of a_l or delta_l.
+// k_dw_wide contracts over the ROWS: its MFMA operand for lane (i, g) and k-step s is (row 4s+g, slot i).  Round 1-2 stored a
+// block row-major (one 16-B store per lane of the D layout) and k_dw_wide re-read it lane-linearly through an LDS ring.  Here
+// element (row, slot) sits at slot*16 + (row % 4)*4 + row / 4: a lane's four k-steps are 16 contiguous bytes, so k_dw_wide
+// loads its operands straight from L2 into registers with ONE 16-B buffer load per block (no LDS ring, no parking, no barrier),
+// and the chain kernel pays four 4-B stores per block instead of one 16-B store.
+#ifndef WIDE_TBLOCK
+#define WIDE_TBLOCK 1
+#endif
+#define WIDE_RSRC_FLAGS 0x00020000
+// byte offset of this lane's component j in a block: writer lane (r = i16, g) holds (row r, slot 4g+j)
+__device__ __forceinline__ int tblk_wr_off(int i16, int g) { return ((4 * g) * 16 + (i16 & 3) * 4 + (i16 >> 2)) * 4; }   // + j * 64
+// reader lane (i = slot, g = row % 4): 16 bytes = rows g, 4+g, 8+g, 12+g of slot i
+__device__ __forceinline__ int tblk_rd_off(int lane) { return ((lane & 15) * 16 + (lane >> 4) * 4) * 4; }
+// store the D-layout tile v as block `blk` of the array behind `rs` (one row tile's blocks)
+__device__ __forceinline__ void tblk_store(__amdgpu_buffer_rsrc_t rs, int voff, int blk, const f32x4& v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float f = v[j];                       // (__builtin_bit_cast applied to v[j] itself reads element 0 of the vector)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(f), rs, voff, blk * 1024 + j * 64, 0);
+    }
+}
+__device__ __forceinline__ f32x4 tblk_load_d(__amdgpu_buffer_rsrc_t rs, int voff, int blk) {      // back in the D layout (4 x 4-B loads)
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, blk * 1024 + j * 64, 0));
+    return v;
+}
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <class S>
 __device__ __forceinline__ f32x4 wide_tile_direct(const WideImg& im, int cc, int lane, int t) {
@@ -523,9 +557,16 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                     if (t == os / 16 && g == (os % 16) / 4) v[t][os % 4] = 1.f;
                 }
                 if (!FWD && tvalid) {
+#if WIDE_TBLOCK
+                    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(store + C::act_off(l, ntiles) + ((size_t)stile * C::TA(l)) * 256, 0,
+                                                                                         C::TA(l) * 1024, WIDE_RSRC_FLAGS);
+#pragma unroll
+                    for (int t = 0; t < C::TA(l); ++t) tblk_store(rsw, tblk_wr_off(i16, g), t, v[t]);
+#else
                     float* p = store + C::act_off(l, ntiles) + ((size_t)stile * C::TA(l)) * 256 + i16 * 16 + g * 4;
 #pragma unroll
                     for (int t = 0; t < C::TA(l); ++t) *reinterpret_cast<f32x4*>(p + t * 256) = v[t];
+#endif
                 }
             }
             constexpr int MT = C::TR(l + 1);
@@ -606,10 +647,18 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         sfor<0, NM>(SFOR_LAMBDA(li) {
             constexpr int l = NM - SFOR_VAL(li);
             if (tvalid) {       // delta_l -> HBM
+#if WIDE_TBLOCK
+                const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(store + C::dz_off(l, ntiles) + ((size_t)stile * C::TZ(l)) * 256, 0,
+                                                                                     C::TZ(l) * 1024, WIDE_RSRC_FLAGS);
+#pragma unroll
+                for (int t = 0; t < C::MAXT; ++t)
+                    if (t < C::TZ(l)) tblk_store(rsw, tblk_wr_off(i16, g), t, dz[t]);
+#else
                 float* p = store + C::dz_off(l, ntiles) + ((size_t)stile * C::TZ(l)) * 256 + i16 * 16 + g * 4;
 #pragma unroll
                 for (int t = 0; t < C::MAXT; ++t)
                     if (t < C::TZ(l)) *reinterpret_cast<f32x4*>(p + t * 256) = dz[t];
+#endif
             }
             constexpr int MU = C::TR(l);
             // a_l (for act') comes back from the block this lane stored in the forward pass: nothing but the
@@ -624,9 +673,16 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             sfor<0, C::KG(C::out(l))>(SFOR_LAMBDA(kg) {
                 constexpr int kg = SFOR_VAL(kg), c = C::cB(l) + kg;
                 if constexpr (!RELU && kg == KG_RELOAD) {
+#if WIDE_TBLOCK
+                    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(store + C::act_off(l, ntiles) + ((size_t)(tvalid ? stile : 0) * C::TA(l)) * 256,
+                                                                                         0, C::TA(l) * 1024, WIDE_RSRC_FLAGS);
+#pragma unroll
+                    for (int u = 0; u < MU; ++u) arel[u] = tvalid ? tblk_load_d(rsr, tblk_wr_off(i16, g), u) : f32x4{0.f, 0.f, 0.f, 0.f};
+#else
                     const float* p = store + C::act_off(l, ntiles) + ((size_t)(tvalid ? stile : 0) * C::TA(l)) * 256 + i16 * 16 + g * 4;
 #pragma unroll
                     for (int u = 0; u < MU; ++u) arel[u] = tvalid ? *reinterpret_cast<const f32x4*>(p + u * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
                 }
 #if WIDE_HANDSCHED
                 wide_chunk<S, c, false>(base, Anx, acc, dz[kg], stg, ring, img, im, wave, lane);
@@ -690,7 +746,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 
     if constexpr (FWD) return;
 #if WIDE_DW0_AGPR
-    mfma_drain();
+    mfma_drain_acc(dW0);
 #endif
     // ---- epilogue: compact slab [layer 0][last layer] of this workgroup
     const double wtot = wave_sum(stat);
@@ -771,6 +827,121 @@ struct WideDwArgs {
     int wg_lo[TBNN_MAX_LAYERS + 1];      // first workgroup of middle layer l (index l-1); [NM] = total
 };
 
+#if WIDE_TBLOCK
+// k_dw_wide on transposed blocks: every operand one 16-B buffer load straight into registers.  Loop order inside a row tile:
+// N-tile-major -- for a-block u the QM x 4 MFMAs of this wave's M tiles (an accumulator is revisited every QM-th MFMA), after
+// which B[u]'s registers are dead and take block u of the NEXT row tile (a whole row tile, ~170 MFMAs, ahead of its use); the
+// few A operands (delta blocks of the wave's M tiles, left-over pairs) are double-buffered, the row loop unrolled by two so
+// that the buffers swap by renaming.  Accumulators pinned to AccVGPRs (asm MFMAs: program order is issue order).
+template <class S, int l>
+__device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, long ntiles, long rt0, long rt1,
+                                              float* __restrict__ slab, float* lds, int wave, int lane) {
+    using C = WideCfg<S>;
+    constexpr int TAl = C::TA(l), TZl = C::TZ(l), QM = C::QM(l), RM = C::RM(l), QP = C::QP(l);
+    constexpr int NT = QM * TAl + QP, QMd = QM > 0 ? QM : 1, QPd = QP > 0 ? QP : 1;
+    const float* abase = store + C::act_off(l, ntiles);
+    const float* zbase = store + C::dz_off(l, ntiles);
+    f32x4 acc[NT > 0 ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // left-over pairs of this wave: p = wave + 4q -> (m = 4 QM + p / TA, u = p % TA); invalid ones recompute pair 0
+    int pm[QPd], pu[QPd];
+    bool pv[QPd];
+#pragma unroll
+    for (int q = 0; q < QP; ++q) {
+        const int p = wave + 4 * q;
+        pv[q] = p < RM * TAl;
+        const int pp = pv[q] ? p : 0;
+        pm[q] = 4 * QM + pp / TAl; pu[q] = pp % TAl;
+    }
+    const int voff = tblk_rd_off(lane);
+    auto rsa = [&](long rt) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(abase) + (size_t)rt * TAl * 256, 0, TAl * 1024, WIDE_RSRC_FLAGS);
+    };
+    auto rsz = [&](long rt) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zbase) + (size_t)rt * TZl * 256, 0, TZl * 1024, WIDE_RSRC_FLAGS);
+    };
+    auto ld = [&](__amdgpu_buffer_rsrc_t rs, int blk) __attribute__((always_inline)) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, blk * 1024, 0));
+    };
+    if (rt0 >= rt1) {                                               // an empty row range still owes its slab: zeros
+        constexpr int np = C::in(l) * C::out(l) + C::out(l);
+        for (int e = wave * 64 + lane; e < np; e += WIDE_THREADS) slab[e] = 0.f;
+        return;
+    }
+    // operand registers: B[u] = a-block u (refreshed in place), A = delta blocks of this wave's M tiles {w, w+4, ..}, Z = the
+    // RM left-over delta blocks (their (m, u) pairs are dealt over the waves: pair p = u + k TA belongs to wave p % 4, its
+    // accumulator is number p / 4 of that wave's left-over set -- all compile-time once the wave is known, so the pair MFMAs
+    // sit in wave-uniform branches inside the u-groups and read B[u] while it is still there).  The asm MFMAs must not get
+    // operands that the VALU has just written (an operand parked in an AccVGPR comes back through v_accvgpr_read, and an MFMA
+    // issued right behind it read the OLD register): the operand set is kept small enough to stay in ArchVGPRs.
+    constexpr int RMd = RM > 0 ? RM : 1;
+    f32x4 B[TAl], A0[QMd], A1[QMd], Z0[RMd], Z1[RMd];
+    auto load_small = [&](long rt, f32x4 (&A)[QMd], f32x4 (&Z)[RMd]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rz = rsz(rt);
+#pragma unroll
+        for (int j = 0; j < QM; ++j) A[j] = ld(rz, wave + 4 * j);
+#pragma unroll
+        for (int k = 0; k < RM; ++k) Z[k] = ld(rz, 4 * QM + k);
+    };
+    {
+        const __amdgpu_buffer_rsrc_t ra = rsa(rt0);
+#pragma unroll
+        for (int u = 0; u < TAl; ++u) B[u] = ld(ra, u);
+        load_small(rt0, A0, Z0);
+    }
+    // one row tile: operands of `rt` in (A, Z) and B; requests those of rt + 1 (clamped) into (An, Zn) and B
+    auto body = [&](long rt, f32x4 (&A)[QMd], f32x4 (&Z)[RMd], f32x4 (&An)[QMd], f32x4 (&Zn)[RMd]) __attribute__((always_inline)) {
+        const long rn = rt + 1 < rt1 ? rt + 1 : rt;
+        load_small(rn, An, Zn);
+        const __amdgpu_buffer_rsrc_t ran = rsa(rn);
+        WIDE_FENCE();
+        sfor<0, TAl>(SFOR_LAMBDA(u) {
+            constexpr int u = SFOR_VAL(u);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < QM; ++j) mfma16_acc<(QM > 1)>(acc[j * TAl + u], A[j][s], B[u][s]);
+            sfor<0, RM>(SFOR_LAMBDA(k) {                              // left-over pairs on a-block u
+                constexpr int pp = u + SFOR_VAL(k) * TAl;
+                if (wave == pp % 4) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) mfma16_acc<false>(acc[QM * TAl + pp / 4], Z[SFOR_VAL(k)][s], B[u][s]);
+                }
+            });
+            WIDE_FENCE();
+            B[u] = ld(ran, u);
+            WIDE_FENCE();
+        });
+    };
+    for (long rt = rt0; rt < rt1; rt += 2) {
+        body(rt, A0, Z0, A1, Z1);
+        if (rt + 1 < rt1) body(rt + 1, A1, Z1, A0, Z0);
+        else break;
+    }
+    mfma_drain_acc(acc);
+    // write-out in theta order: D layout lane (n = lane & 15, g) reg j = dW[out 16m+4g+j][in 16u+n]
+    const int nn = lane & 15, gg = lane >> 4;
+    constexpr int inl = C::in(l), outl = C::out(l);
+    auto put = [&](int m, int u, const f32x4& v) {
+        const int col = unit_of(inl, 16 * u + nn, true);          // inl: the ones pseudo-unit (bias column)
+        if (col >= 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = unit_of(outl, 16 * m + 4 * gg + j, false);
+                if (row >= 0) slab[col < inl ? row * inl + col : inl * outl + row] = v[j];
+            }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < QM; ++j)
+#pragma unroll
+        for (int u = 0; u < TAl; ++u) put(wave + 4 * j, u, acc[j * TAl + u]);
+#pragma unroll
+    for (int q = 0; q < QP; ++q)
+        if (pv[q]) put(pm[q], pu[q], acc[QM * TAl + q]);
+}
+#else
 template <class S, int l>
 __device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, long ntiles, long rt0, long rt1,
                                               float* __restrict__ slab, float* lds, int wave, int lane) {
@@ -868,13 +1039,19 @@ __device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, l
         if (pv[q]) put(pm[q], pu[q], acc[QM * TAl + q]);
 }
 
+#endif  // WIDE_TBLOCK
+
 template <class S>
 __global__ __launch_bounds__(WIDE_THREADS, WideCfg<S>::DW_OCC) void k_dw_wide(
     WideDwArgs args, const float* __restrict__ store, long n, float* __restrict__ slabB)
 {
     using C = WideCfg<S>;
+#if WIDE_TBLOCK
+    float* lds = nullptr;                                // operands come straight from L2 (dw_wide_layer)
+#else
     static_assert(WIDE_RING * C::DW_SLOT_FLOATS * 4 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) float lds[WIDE_RING * C::DW_SLOT_FLOATS];
+#endif
     // wave index as a SCALAR (the compiler does not know threadIdx.x >> 6 is wave-uniform: every `b = wave + 4j < SB` below
     // would become an exec-mask branch with zero-filled else arms, and the block addresses vector arithmetic)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

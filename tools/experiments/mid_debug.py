@@ -8,9 +8,10 @@ from tensorbnn_amd import _native as nat
 dims = [int(v) for v in sys.argv[1].split(",")]
 n = int(sys.argv[2])
 bern = len(sys.argv) > 3 and sys.argv[3] == "bern"
-spec, X, Y, theta, eta = o.synth_problem(dims, n, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI if bern else o.LIK_GAUSSIAN)
+act = {"relu": o.ACT_RELU, "tanh": o.ACT_TANH, "sigmoid": o.ACT_SIGMOID}[sys.argv[4]] if len(sys.argv) > 4 else o.ACT_RELU
+spec, X, Y, theta, eta = o.synth_problem(dims, n, act, o.PRIOR_GAUSSIAN if act == o.ACT_TANH else o.PRIOR_CAUCHY, o.LIK_BERNOULLI if bern else o.LIK_GAUSSIAN)
 layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
-ch = nat.Chain(layers, likelihood=spec.likelihood, kernel=nat.KERNEL_FAST, jit=True)
+ch = nat.Chain(layers, likelihood=spec.likelihood, kernel=nat.KERNEL_FAST, jit=os.environ.get("TBNN_JIT", "1") != "0")
 print(ch.kernel_name)
 ch.set_data(X, Y)
 lp, g, st = ch.logp_grad(theta, eta)
