@@ -9,41 +9,8 @@
 // and the weight priors layer.py:166-197 / :346-377 with BNN_functions.py:7-57.
 #pragma once
 #include "common.hpp"
+#include "update_ops.hpp"
 
-enum { UPD_GRAD_ONLY = 0, UPD_FIRST = 1, UPD_MID = 2, UPD_LAST = 3 };
-
-// which (layer, W-or-b) group a flat parameter index belongs to -> (loc, scale)
-__device__ __forceinline__ void prior_params(const NetDev& nd, const float* __restrict__ eta, int j,
-                                             int& prior, float& loc, float& scale) {
-    int l = 0;
-#pragma unroll 1
-    for (int m = 1; m < nd.nl; ++m) if (j >= nd.offW[m]) l = m;
-    const bool isb = j >= nd.offB[l];
-    prior = nd.prior[l];
-    loc = eta[4 * l + (isb ? 2 : 0)];
-    const float g = eta[4 * l + (isb ? 3 : 1)];
-    scale = g * g;                                   // layer.py:178,180 / :358,360 (Q3)
-}
-
-// d/dx of the reference's prior log-density (Q1 sign kept)
-__device__ __forceinline__ float prior_grad(int prior, float loc, float scale, float x) {
-    if (prior == TBNN_PRIOR_CAUCHY) {
-        const float z = (x - loc) / scale;           // BNN_functions.py:51
-        return 2.f * z / (scale * (1.f + z * z));
-    }
-    const float s = fminf(fmaxf(scale, 1e-8f), 1e8f);   // BNN_functions.py:23-24
-    return -(x - loc) / (s * s);
-}
-
-// Reduce the per-workgroup gradient slabs, add the prior gradient, then kick /
-// drift.  One thread column = 4 consecutive parameters (float4 slab reads; the
-// slab pitch is a multiple of 4), 16 slab groups per block, every thread keeps
-// 4 independent 16-B loads in flight; fixed-order LDS tree => deterministic.
-// When imgmap != null the new position is also scattered into the padded
-// weight image (W_l and, for l >= 1, W_l^T: imgmap[j] / imgmap[P+j]) the
-// shape-specialised kernel stages into LDS.
-#define UPD_COLS 8     // float4 columns per block (32 parameters)
-#define UPD_GROUPS 32  // slab groups per block
 __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     NetDev nd, int mode, float eps, const float* __restrict__ eta,
     const float* __restrict__ slabs, int nslab, int pitch,
@@ -59,47 +26,13 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     __shared__ float4 part[UPD_GROUPS][UPD_COLS];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int c4 = blockIdx.x * UPD_COLS + tx;          // float4 column
-    const int j0 = c4 * 4;
-    // the finishing threads (ty < 4: one parameter each) fetch everything they need that does not depend on the reduced
-    // gradient BEFORE the slab loads: one memory round trip instead of two on the critical path of a leapfrog step
-    const int jf = j0 + ty;
+    const int jf = c4 * 4 + ty;                         // ty < 4 selects which of the column's 4 parameters this thread finishes
     const bool fin = ty < 4 && jf < nd.P;
-    float q_j = 0.f, p_j = 0.f, gc_j = 0.f, qc_j = 0.f, loc = 0.f, scale = 1.f;
-    int prior = 0, m0 = -1, m1 = -1;
-    if (fin) {
-        if (mode != UPD_FIRST) { prior_params(nd, eta, jf, prior, loc, scale); q_j = q[jf]; }
-        if (mode == UPD_FIRST) { gc_j = g_cur[jf]; qc_j = q_cur[jf]; }
-        if (mode != UPD_GRAD_ONLY) p_j = p[jf];
-        if (imgmap && (mode == UPD_FIRST || mode == UPD_MID)) { m0 = imgmap[jf]; m1 = imgmap[nd.P + jf]; }
-    }
+    UpdPre u;
+    if (fin) upd_prefetch(u, nd, mode, eta, jf, q_cur, g_cur, q, p, imgmap);
     float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mode != UPD_FIRST) {
-        float4 s0 = gs, s1 = gs, s2 = gs, s3 = gs;
-        if (j0 < pitch) {
-            const float4* base = reinterpret_cast<const float4*>(slabs) + c4;
-            const int p4 = pitch >> 2;
-            int w = ty;
-            for (; w + 7 * UPD_GROUPS < nslab; w += 8 * UPD_GROUPS) {          // 8 independent 16-B loads in flight
-                float4 v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(w + k * UPD_GROUPS) * p4];
-#pragma unroll
-                for (int k = 0; k < 8; k += 4) {
-                    s0.x += v[k].x; s0.y += v[k].y; s0.z += v[k].z; s0.w += v[k].w;
-                    s1.x += v[k + 1].x; s1.y += v[k + 1].y; s1.z += v[k + 1].z; s1.w += v[k + 1].w;
-                    s2.x += v[k + 2].x; s2.y += v[k + 2].y; s2.z += v[k + 2].z; s2.w += v[k + 2].w;
-                    s3.x += v[k + 3].x; s3.y += v[k + 3].y; s3.z += v[k + 3].z; s3.w += v[k + 3].w;
-                }
-            }
-            for (; w < nslab; w += UPD_GROUPS) {
-                const float4 a = base[(size_t)w * p4];
-                s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-            }
-        }
-        float4 s;
-        s.x = (s0.x + s1.x) + (s2.x + s3.x); s.y = (s0.y + s1.y) + (s2.y + s3.y);
-        s.z = (s0.z + s1.z) + (s2.z + s3.z); s.w = (s0.w + s1.w) + (s2.w + s3.w);
-        part[ty][tx] = s;
+        part[ty][tx] = upd_column_partial(slabs, nslab, pitch, c4, ty);
         __syncthreads();
 #pragma unroll
         for (int h = UPD_GROUPS / 2; h > 0; h >>= 1) {
@@ -111,33 +44,9 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
         }
         gs = part[0][tx];
     }
-    // ty selects which of the 4 parameters of the column this thread finishes
     if (!fin) return;
-    const int j = jf;
-    float gj = ty == 0 ? gs.x : ty == 1 ? gs.y : ty == 2 ? gs.z : gs.w;
-    if (mode != UPD_FIRST && gd) {
-        const float sg = nd.lik == TBNN_LIK_GAUSSIAN ? lik_sigma(nd, eta) : 1.f;
-        gd[j] = gj * (sg * sg);
-    }
-    if (mode != UPD_FIRST) gj += prior_grad(prior, loc, scale, q_j);
-    if (mode == UPD_GRAD_ONLY) { g[j] = gj; return; }
-    if (mode == UPD_FIRST) {
-        const float pj = p_j + 0.5f * eps * gc_j;            // half kick
-        const float qj = qc_j + eps * pj;                     // drift
-        p[j] = pj; q[j] = qj;
-        if (imgmap) { qimg[m0] = qj; if (m1 >= 0) qimg[m1] = qj; }
-        return;
-    }
-    float pj = p_j + eps * gj;                                // full kick
-    g[j] = gj;
-    if (mode == UPD_MID) {
-        const float qj = q_j + eps * pj;                      // drift
-        p[j] = pj; q[j] = qj;
-        if (imgmap) { qimg[m0] = qj; if (m1 >= 0) qimg[m1] = qj; }
-    } else {
-        pj = pj - 0.5f * eps * gj;                            // undo half kick
-        p[j] = pj;
-    }
+    const float gj = ty == 0 ? gs.x : ty == 1 ? gs.y : ty == 2 ? gs.z : gs.w;
+    upd_finish(u, nd, mode, eps, eta, jf, gj, q, p, g, imgmap, qimg, gd);
 }
 
 // row-sharded chains: sum the per-workgroup slabs into ONE dense row (the all-reduce operand: doubles when outd is given);
