@@ -8,17 +8,20 @@
 //   k_chain_wide   one wave = one 16-row tile through forward, likelihood and the delta chain with
 //                  every activation in registers (the C/D layout of layer l-1 is the B-operand layout
 //                  of layer l, kernels_fast.hpp).  The middle layers' weights do not fit in LDS
-//                  (200x200 fp32 = 160 KB): all four waves of the workgroup consume ONE weight stream
-//                  (W_1 .. W_NM, then W_NM^T .. W_1^T, pre-swizzled into MFMA A-operand order by
-//                  k_update) through a 4-slot LDS ring, one k-group (16 input slots x all output
-//                  tiles) per slot, refilled from L2 two chunks ahead.  dW of the FIRST layer (fan-in
-//                  <= 32) and of the LAST layer (<= 2 outputs, VALU) are accumulated in registers as
-//                  in the narrow kernel.  For every middle layer l the wave stores a_l (+ ones slot)
-//                  and delta_l to HBM in 1-KB [16 rows][16 slots] blocks.
+//                  (200x200 fp32 = 160 KB): every wave walks ONE weight stream (W_1 .. W_NM, then
+//                  W_NM^T .. W_1^T, pre-swizzled into MFMA A-operand order by k_update; it lives in
+//                  L2) and fetches the next k-group's operands itself with buffer loads, one chunk
+//                  ahead of use (WIDE_DIRECT, round 3; WIDE_DIRECT=0 and shapes whose weights fit in
+//                  LDS: the round-1 design, one stream per workgroup through a 4-slot LDS ring).
+//                  dW of the FIRST layer (fan-in <= 32) and of the LAST layer (<= 2 outputs, VALU) are
+//                  accumulated in registers as in the narrow kernel.  For every middle layer l the wave
+//                  stores a_l (+ ones slot) and delta_l to HBM in 1-KB [16 rows][16 slots] blocks,
+//                  already transposed for their consumer (WIDE_TBLOCK, round 3).
 //   k_dw_wide      dW_l = delta_l^T a_l (contraction over ALL rows) for the middle layers: each
 //                  workgroup owns a row range and the whole 13x13-tile output (43 tiles per wave),
-//                  streams the 1-KB blocks through a 4-slot LDS ring and writes its partial dW to a
-//                  private slab; k_reduce_wide sums the slabs in fixed order (deterministic).
+//                  reads every operand with one 16-byte buffer load (no LDS; WIDE_TBLOCK=0: the blocks
+//                  go through a 4-slot LDS ring to be turned) and writes its partial dW to a private
+//                  slab; k_reduce_wide sums the slabs in fixed order (deterministic).
 //
 // Algorithmic HBM traffic of the split: 2 arrays (a_l, delta_l) x n x 4 B x padded width per middle
 // layer, written once and read once (C4: 3.3 GB each way per gradient ~ 1 ms of HBM time against
