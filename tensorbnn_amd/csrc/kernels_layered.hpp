@@ -1,0 +1,310 @@
+// The LAYERED family: forward + likelihood + backward for ANY dense architecture the C ABI can describe, on the f32 MFMA,
+// with run-time shapes -- what a network runs on when no shape-specialised fused kernel covers it (fan-in above 32, hidden
+// widths above 256, more than two outputs, ... -- e.g. the reference's own MNIST example, 784 -> 20 -> 20 -> 1,
+// docs/ClassificationExample.md) and no compiler is around to instantiate one (tensorbnn_amd/jit.py).  It replaces the
+// thread-per-row scalar kernel (kernels_generic.hpp: ~0.1-0.7 % of the MFMA peak) as the fallback; that one stays as the
+// on-device cross-check (TBNN_KERNEL_GENERIC).
+//
+// Layer by layer, activations through HBM (the fused families keep them in registers; this one trades that for generality):
+//   k_lay_pack_x   once per data set: X[n][d_in] -> a_0 blocks
+//   k_lay_gemm<0>  per layer, forward:  a_{l+1} = act_l(W_l [a_l, 1])            (the bias rides as the weight of a constant-1 slot)
+//   k_lay_lik      likelihood: statistic + dL/dz of the last layer
+//   k_lay_gemm<1>  per layer, backward: dz_{l-1} = (W_l^T dz_l) * act_{l-1}'(a_l)
+//   k_lay_dw       every layer's dW_l = dz_l^T [a_l, 1] over a workgroup's rows -> one gradient slab per workgroup
+//                  (k_update reduces the slabs, as for every other family: deterministic)
+// Storage: 1-KB blocks [16 rows][16 slots] row-major, [row tile][slot tile]; a_l carries a constant-1 slot behind its last
+// unit.  The GEMM reads both MFMA operands with ONE 16-byte load per lane and k-group (lane (i, g): W[16t + i][16kg + 4g ..],
+// a[row i][16kg + 4g ..]: the four values are the lane's k-steps -- the k order inside a k-group is permuted the same way
+// for both operands) and stores a result tile with one 16-byte store; k_lay_dw reads a block lane-linearly (float 64 s + lane =
+// row 4s + g, slot i: exactly the operand of k-step s).  Weights come from the padded image k_update maintains
+// (W_l row-major [out slots][in slots + 1], and W_l^T for the delta chain), straight from L2.
+//
+// Reference math: layer.py:278 (W@a+b), activationFunctions.py:23-75, likelihood.py:88-94 + BNN_functions.py:23-32,
+// likelihood.py:226-236; reverse mode SURVEY A12; the path: network.py:394-408.
+#pragma once
+#include <vector>
+#include <algorithm>
+#include "kernels_fast.hpp"
+
+struct LayPlan {
+    int nl;
+    int TK[TBNN_MAX_LAYERS];    // slot tiles of a_l (units + the ones slot): ceil((in + 1) / 16)
+    int TM[TBNN_MAX_LAYERS];    // unit tiles of z_l / dz_l: ceil(out / 16)
+    int TO[TBNN_MAX_LAYERS];    // tiles the forward GEMM of layer l writes: TK[l + 1] (units + ones slot), last layer TM[l]
+    int wOff[TBNN_MAX_LAYERS];  // image: W_l   [16 TO[l]][16 TK[l]]
+    int tOff[TBNN_MAX_LAYERS];  // image: W_l^T [16 TM[l - 1]][16 TM[l]]   (l >= 1)
+    int img_floats;
+    // per data set (ntiles row tiles): float offsets of the block arrays in the activation store
+    long ntiles;
+    long aOff[TBNN_MAX_LAYERS + 1];   // a_l, l = 0 .. nl (a_nl = the network output f)
+    long dOff[TBNN_MAX_LAYERS];       // dz_l
+    long store_floats;
+    int NS;                           // gradient slabs = workgroups of k_lay_dw (x) = workgroups of k_lay_lik
+    int NY;                           // k_lay_dw grid.y: splits the tile-block list
+    int dw_items;
+};
+
+static inline int lay_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+static inline void lay_plan_shape(const NetDev& nd, LayPlan& p) {
+    p.nl = nd.nl;
+    int o = 0;
+    for (int l = 0; l < nd.nl; ++l) { p.TK[l] = lay_cdiv(nd.in[l] + 1, 16); p.TM[l] = lay_cdiv(nd.out[l], 16); }
+    for (int l = 0; l < nd.nl; ++l) p.TO[l] = l + 1 < nd.nl ? p.TK[l + 1] : p.TM[l];
+    for (int l = 0; l < nd.nl; ++l) { p.wOff[l] = o; o += 256 * p.TO[l] * p.TK[l]; }
+    for (int l = 0; l < nd.nl; ++l) { p.tOff[l] = o; if (l >= 1) o += 256 * p.TM[l - 1] * p.TM[l]; }
+    p.img_floats = (o + 3) & ~3;
+    p.ntiles = 0; p.store_floats = 0; p.NS = 1; p.NY = 1; p.dw_items = 0;
+}
+static inline void lay_plan_rows(const NetDev& nd, long n, LayPlan& p) {
+    p.ntiles = (n + 15) / 16;
+    long o = 0;
+    for (int l = 0; l <= nd.nl; ++l) { p.aOff[l] = o; o += p.ntiles * 256 * (l < nd.nl ? p.TK[l] : p.TM[nd.nl - 1]); }
+    for (int l = 0; l < nd.nl; ++l) { p.dOff[l] = o; o += p.ntiles * 256 * p.TM[l]; }
+    p.store_floats = o;
+    p.NS = (int)std::max<long>(1, std::min<long>(256, p.ntiles / 8));
+    p.dw_items = 0;
+    for (int l = 0; l < nd.nl; ++l) p.dw_items += lay_cdiv(p.TM[l], 2) * lay_cdiv(p.TK[l], 2);
+    p.NY = std::max(1, std::min(8, lay_cdiv(p.dw_items, 4)));
+}
+// theta index j -> image positions: map[j] (W_l, biases in the ones-slot column), map[P + j] (W_l^T; -1: none)
+static inline void lay_image_map(const NetDev& nd, const LayPlan& p, int* map) {
+    for (int l = 0; l < nd.nl; ++l) {
+        const int in = nd.in[l], out = nd.out[l], wp = 16 * p.TK[l];
+        for (int u = 0; u < out; ++u) {
+            for (int k = 0; k < in; ++k) {
+                const int j = nd.offW[l] + u * in + k;
+                map[j] = p.wOff[l] + u * wp + k;
+                map[nd.P + j] = l >= 1 ? p.tOff[l] + k * (16 * p.TM[l]) + u : -1;
+            }
+            map[nd.offB[l] + u] = p.wOff[l] + u * wp + in;
+            map[nd.P + nd.offB[l] + u] = -1;
+        }
+    }
+}
+
+// X[n][d_in] -> a_0 blocks [row tile][TK0][16][16]: units, a 1 in slot d_in, zeros behind; rows past n: zeros, slot d_in = 1
+__global__ __launch_bounds__(256) void k_lay_pack_x(const float* __restrict__ X, long n, int d_in, int TK0, long ntiles, float* __restrict__ a0) {
+    const long total = ntiles * TK0 * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long blk = e >> 8; const int r = (int)(e & 255) >> 4, c = (int)(e & 15);
+        const long rt = blk / TK0; const int kt = (int)(blk - rt * TK0);
+        const long row = rt * 16 + r; const int slot = 16 * kt + c;
+        float v = 0.f;
+        if (slot < d_in) v = row < n ? X[row * d_in + slot] : 0.f;
+        else if (slot == d_in) v = 1.f;
+        a0[e] = v;
+    }
+}
+
+// OUT[rt][t] = epilogue( sum over k-groups  IMG[16 t + i][16 kg + ..] x IN[rt][kg] ),  one wave = RB row tiles x up to 4 output tiles.
+// MODE 0 (forward): v = act(acc) for the n_units real units, 1 in the ones slot, 0 behind.
+// MODE 1 (backward): v = acc * act'(AUX[rt][t]) for the n_units real units (AUX = the activations those units produced), 0 behind.
+#define LAY_TB 4
+template <int MODE, int RB>
+__global__ __launch_bounds__(256) void k_lay_gemm(
+    const float* __restrict__ img, int wpitch, const float* __restrict__ in, int KG, float* __restrict__ outb, int MT,
+    const float* __restrict__ aux, int auxT, long ntiles, int act, int n_units, int ones_slot)
+{
+    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+    const int TG = (MT + LAY_TB - 1) / LAY_TB;
+    const long RP = (ntiles + RB - 1) / RB;
+    const long items = RP * TG, nw = (long)gridDim.x * 4;
+    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += nw) {
+        const long rp = it / TG; const int t0 = (int)(it - rp * TG) * LAY_TB;
+        const long rt0 = rp * RB;
+        f32x4 acc[RB][LAY_TB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int t = 0; t < LAY_TB; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* wrow = img + (size_t)(16 * t0 + i16) * wpitch + 4 * g;
+        const float* brow = in + (size_t)rt0 * KG * 256 + i16 * 16 + 4 * g;
+#pragma unroll 2
+        for (int kg = 0; kg < KG; ++kg) {
+            f32x4 A[LAY_TB], B[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                B[r] = rt0 + r < ntiles ? *reinterpret_cast<const f32x4*>(brow + ((size_t)r * KG + kg) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < LAY_TB; ++t)
+                A[t] = t0 + t < MT ? *reinterpret_cast<const f32x4*>(wrow + (size_t)(16 * t) * wpitch + 16 * kg) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < LAY_TB; ++t)
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) acc[r][t] = mfma16(A[t][j], B[r][j], acc[r][t]);
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (rt0 + r >= ntiles) continue;
+#pragma unroll
+            for (int t = 0; t < LAY_TB; ++t) {
+                if (t0 + t >= MT) continue;
+                f32x4 v;
+                const int u0 = 16 * (t0 + t) + 4 * g;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = u0 + j < n_units ? act_fwd(acc[r][t][j], act) : (u0 + j == ones_slot ? 1.f : 0.f);
+                } else {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(aux + ((size_t)(rt0 + r) * auxT + t0 + t) * 256 + i16 * 16 + 4 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = u0 + j < n_units ? acc[r][t][j] * act_bwd(a[j], act) : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(outb + ((size_t)(rt0 + r) * MT + t0 + t) * 256 + i16 * 16 + 4 * g) = v;
+            }
+        }
+    }
+}
+
+// likelihood (restated as in kernels_generic.hpp): statistic (Gaussian: sum of squared residuals; Bernoulli: log-prob) and
+// dz of the last layer = dL/df * act'(f).  f, dz: blocks [row tile][TMl][16][16]; one thread per (row, slot) of a block.
+__global__ __launch_bounds__(256) void k_lay_lik(NetDev nd, const float* __restrict__ eta, const float* __restrict__ f, const float* __restrict__ Y,
+                                                  long n, long ntiles, int TMl, float* __restrict__ dz, double* __restrict__ pstat) {
+    __shared__ double red[4];
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const float sigma = lik_sigma(nd, eta);
+    const float inv_var = 1.f / (sigma * sigma);
+    const int lact = nd.act[nd.nl - 1];
+    double stat = 0.0;
+    for (long rt = blockIdx.x; rt < ntiles; rt += gridDim.x) {
+        const long row = rt * 16 + r;
+        for (int tt = 0; tt < TMl; ++tt) {
+            const int o = 16 * tt + c;
+            const size_t e = ((size_t)rt * TMl + tt) * 256 + threadIdx.x;
+            float d = 0.f;
+            if (row < n && o < nd.d_out) {
+                const float fi = f[e], y = Y[row * nd.d_out + o];
+                float da;
+                if (nd.lik == TBNN_LIK_BERNOULLI) {
+                    const float p = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);     // likelihood.py:226-231
+                    const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
+                    const float t1 = (y == 0.f) ? 0.f : y * logf(p);          // tfd.Bernoulli.log_prob = xlogy(y,p) + xlog1py(1-y,-p)
+                    const float t2 = (1.f - y == 0.f) ? 0.f : (1.f - y) * log1pf(-p);
+                    stat += (double)(t1 + t2);
+                    da = inside ? (y / p - (1.f - y) / (1.f - p)) : 0.f;
+                } else {
+                    const float res = y - fi;                                   // likelihood.py:88-94
+                    stat += (double)res * (double)res;
+                    da = res * inv_var;
+                }
+                d = da * act_bwd(fi, lact);
+            }
+            dz[e] = d;
+        }
+    }
+    const double tot = block_sum(stat, red);
+    if (threadIdx.x == 0) pstat[blockIdx.x] = tot;
+}
+
+// dW_l[u][k] = sum over rows dz_l[row][u] [a_l, 1][row][k], every layer, over this workgroup's row tiles; output tiles in
+// blocks of 2 x 2, dealt out over the waves (and over grid.y); every entry of the slab is written by exactly one wave.
+__global__ __launch_bounds__(256) void k_lay_dw(NetDev nd, LayPlan p, const float* __restrict__ store, float* __restrict__ slabs, int pitch) {
+    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const long per = (p.ntiles + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per, hi = lo + per < p.ntiles ? lo + per : p.ntiles;
+    float* slab = slabs + (size_t)blockIdx.x * pitch;
+    for (int item = wave + 4 * blockIdx.y; item < p.dw_items; item += 4 * gridDim.y) {
+        int l = 0, rem = item;
+        for (; l < p.nl; ++l) { const int c = ((p.TM[l] + 1) / 2) * ((p.TK[l] + 1) / 2); if (rem < c) break; rem -= c; }
+        const int KB = (p.TK[l] + 1) / 2;
+        const int tu0 = 2 * (rem / KB), tk0 = 2 * (rem % KB);
+        const int TMl = p.TM[l], TKl = p.TK[l];
+        const bool u1 = tu0 + 1 < TMl, k1 = tk0 + 1 < TKl;
+        const float* dzb = store + p.dOff[l] + lane;
+        const float* ab = store + p.aOff[l] + lane;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (long rt = lo; rt < hi; ++rt) {
+            const float* d0 = dzb + ((size_t)rt * TMl + tu0) * 256;
+            const float* a0 = ab + ((size_t)rt * TKl + tk0) * 256;
+            float A[2][4], B[2][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                A[0][s] = d0[64 * s]; A[1][s] = u1 ? d0[256 + 64 * s] : 0.f;
+                B[0][s] = a0[64 * s]; B[1][s] = k1 ? a0[256 + 64 * s] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = mfma16(A[a][s], B[b][s], acc[a][b]);
+        }
+        // D[m][n]: lane (i, g) reg j = dW[unit 16 tu + 4 g + j][slot 16 tk + i]
+        const int in = nd.in[l], out = nd.out[l];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int k = 16 * (tk0 + b) + i16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int u = 16 * (tu0 + a) + 4 * g + j;
+                    if (u < out) {
+                        if (k < in) slab[nd.offW[l] + u * in + k] = acc[a][b][j];
+                        else if (k == in) slab[nd.offB[l] + u] = acc[a][b][j];
+                    }
+                }
+            }
+    }
+}
+
+// network output f blocks -> fout[d_out][n] (network.predict, network.py:141-171)
+__global__ __launch_bounds__(256) void k_lay_unpack_f(const float* __restrict__ f, long n, long ntiles, int TMl, int d_out, float* __restrict__ fout) {
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+    for (long rt = blockIdx.x; rt < ntiles; rt += gridDim.x) {
+        const long row = rt * 16 + r;
+        for (int tt = 0; tt < TMl; ++tt) {
+            const int o = 16 * tt + c;
+            if (row < n && o < d_out) fout[(size_t)o * n + row] = f[((size_t)rt * TMl + tt) * 256 + threadIdx.x];
+        }
+    }
+}
+
+static inline int lay_gemm_grid(long ntiles, int MT, int RB) {
+    const long items = ((ntiles + RB - 1) / RB) * ((MT + LAY_TB - 1) / LAY_TB);
+    return (int)std::max<long>(1, std::min<long>((items + 3) / 4, 8192));
+}
+// the forward chain: a_0 (packed) -> ... -> f
+static inline void lay_forward_chain(const NetDev& nd, const LayPlan& p, hipStream_t st, const float* img, float* store) {
+    for (int l = 0; l < nd.nl; ++l) {
+        const bool last = l + 1 == nd.nl;
+        const int MT = p.TO[l];
+        const bool two = p.ntiles * ((MT + LAY_TB - 1) / LAY_TB) >= 4096;
+        if (two)
+            hipLaunchKernelGGL((k_lay_gemm<0, 2>), dim3(lay_gemm_grid(p.ntiles, MT, 2)), dim3(256), 0, st, img + p.wOff[l], 16 * p.TK[l],
+                               (const float*)(store + p.aOff[l]), p.TK[l], store + p.aOff[l + 1], MT, (const float*)nullptr, 0, p.ntiles, nd.act[l], nd.out[l],
+                               last ? -1 : nd.out[l]);
+        else
+            hipLaunchKernelGGL((k_lay_gemm<0, 1>), dim3(lay_gemm_grid(p.ntiles, MT, 1)), dim3(256), 0, st, img + p.wOff[l], 16 * p.TK[l],
+                               (const float*)(store + p.aOff[l]), p.TK[l], store + p.aOff[l + 1], MT, (const float*)nullptr, 0, p.ntiles, nd.act[l], nd.out[l],
+                               last ? -1 : nd.out[l]);
+    }
+}
+// one gradient: forward chain, likelihood, delta chain, dW slabs (p.NS slabs of `pitch` floats; pstat[p.NS])
+static inline int lay_launch(const NetDev& nd, const LayPlan& p, hipStream_t st, const float* img, const float* eta, const float* Y, long n,
+                             float* store, float* slabs, int pitch, double* pstat) {
+    lay_forward_chain(nd, p, st, img, store);
+    const int L = nd.nl - 1;
+    hipLaunchKernelGGL(k_lay_lik, dim3(p.NS), dim3(256), 0, st, nd, eta, (const float*)(store + p.aOff[nd.nl]), Y, n, p.ntiles, p.TM[L], store + p.dOff[L], pstat);
+    for (int l = L; l >= 1; --l) {
+        const int MT = p.TM[l - 1];
+        const bool two = p.ntiles * ((MT + LAY_TB - 1) / LAY_TB) >= 4096;
+        if (two)
+            hipLaunchKernelGGL((k_lay_gemm<1, 2>), dim3(lay_gemm_grid(p.ntiles, MT, 2)), dim3(256), 0, st, img + p.tOff[l], 16 * p.TM[l],
+                               (const float*)(store + p.dOff[l]), p.TM[l], store + p.dOff[l - 1], MT, (const float*)(store + p.aOff[l]), p.TK[l], p.ntiles,
+                               nd.act[l - 1], nd.out[l - 1], -1);
+        else
+            hipLaunchKernelGGL((k_lay_gemm<1, 1>), dim3(lay_gemm_grid(p.ntiles, MT, 1)), dim3(256), 0, st, img + p.tOff[l], 16 * p.TM[l],
+                               (const float*)(store + p.dOff[l]), p.TM[l], store + p.dOff[l - 1], MT, (const float*)(store + p.aOff[l]), p.TK[l], p.ntiles,
+                               nd.act[l - 1], nd.out[l - 1], -1);
+    }
+    hipLaunchKernelGGL(k_lay_dw, dim3(p.NS, p.NY), dim3(256), 0, st, nd, p, (const float*)store, slabs, pitch);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -18,6 +18,7 @@
 #include "kernels_hyper.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_fast3.hpp"
+#include "kernels_layered.hpp"
 #include "wide_api.hpp"
 #include "mid_api.hpp"
 #include "fused_ops.hpp"
@@ -53,6 +54,7 @@ struct tbnn_ctx {
     int fast_id = -1;
     int fast_ver = 1;                     // 1: kernels_fast.hpp, 3: kernels_fast3.hpp (fringe units off the 16x16 tiles)
     int mid_id = -1;                      // >= 0: kernels_mid.hpp (mid-width fused kernel; narrow-family workspace and launch signature)
+    bool lay = false; LayPlan lplan{}; float* lstore = nullptr;   // kernels_layered.hpp: run-time-shape MFMA kernels, activations through HBM
     std::string kernel_name;
     // data
     float* dX = nullptr; float* dY = nullptr; bool own_data = false; long n = 0;
@@ -192,6 +194,7 @@ extern "C" int tbnn_destroy(tbnn_handle h) {
     if (h->qimg_cur) hipFree(h->qimg_cur);
     if (h->sc) hipFree(h->sc);
     if (h->sc_out) hipFree(h->sc_out);
+    if (h->lstore) hipFree(h->lstore);
     if (h->trace) hipFree(h->trace);
     if (h->d_recs) hipFree(h->d_recs);
     if (h->h_recs) hipHostFree(h->h_recs);
@@ -317,6 +320,25 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
         HIPB(hipMemset(h->qimg, 0, (size_t)h->img_floats * sizeof(float)));       // padding stays zero for ever
         HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
     }
+    // no shape-specialised kernel (and none registered at run time): the layered MFMA family takes any architecture
+    // (TBNN_LAYERED=0: the thread-per-row kernel, as before round 3)
+    const bool lay_on = !(getenv("TBNN_LAYERED") && atoi(getenv("TBNN_LAYERED")) == 0);
+    if (want == TBNN_KERNEL_AUTO && fid < 0 && mid < 0 && wid < 0 && !jo && lay_on) {
+        h->kernel = TBNN_KERNEL_FAST; h->lay = true;
+        lay_plan_shape(nd, h->lplan);
+        h->kernel_name = "layered<" + std::to_string(nd.in[0]);
+        for (int l = 0; l < nd.nl; ++l) h->kernel_name += "," + std::to_string(nd.out[l]);
+        h->kernel_name += ">";
+        h->img_floats = h->lplan.img_floats;
+        std::vector<int> map(2 * (size_t)nd.P);
+        lay_image_map(nd, h->lplan, map.data());
+        HIPB(hipMalloc(&h->imgmap, map.size() * sizeof(int)));
+        HIPB(hipMemcpy(h->imgmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPB(hipMalloc(&h->qimg, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg_cur, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg, 0, (size_t)h->img_floats * sizeof(float)));       // padding stays zero for ever
+        HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
+    }
     { const char* e1 = getenv("TBNN_FAST_SINGLE"); if (e1 && atoi(e1)) h->nd.reserved_flags |= 1; }
     const char* env = getenv("TBNN_PROFILE_FWDBWD");
     h->profile = env ? atoi(env) : 0;
@@ -348,7 +370,18 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
     if (h->scratch) { hipFree(h->scratch); h->scratch = nullptr; }
     for (float** b : {&h->wstore, &h->wslabA, &h->wslabB}) if (*b) { hipFree(*b); *b = nullptr; }
     int grid;
-    if (h->wide_id >= 0) {
+    if (h->lstore) { hipFree(h->lstore); h->lstore = nullptr; }
+    if (h->lay) {
+        lay_plan_rows(nd, n, h->lplan);
+        grid = h->lplan.NS;
+        h->scratchPerWG = 0;
+        HIPCHK(hipMalloc(&h->lstore, (size_t)h->lplan.store_floats * sizeof(float)));
+        // a_0 = the rows in block form, once per data set
+        const long tot = h->lplan.ntiles * h->lplan.TK[0];
+        hipLaunchKernelGGL(k_lay_pack_x, dim3((int)std::min<long>(tot, 4096)), dim3(256), 0, h->stream, (const float*)h->dX, n, nd.d_in, h->lplan.TK[0],
+                           h->lplan.ntiles, h->lstore + h->lplan.aOff[0]);
+        HIPCHK(hipGetLastError());
+    } else if (h->wide_id >= 0) {
         if (h->jit) h->jit->plan(n, &h->wplan); else wide_plan(h->wide_id, n, h->wplan);
         grid = h->wplan.gridA;
         h->scratchPerWG = 0;
@@ -583,7 +616,10 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
         a = h->pev[h->pev_used]; b = h->pev[h->pev_used + 1]; h->pev_used += 2;
         hipEventRecord(a, h->stream);
     }
-    if (h->wide_id >= 0) {
+    if (h->lay) {
+        if (lay_launch(h->nd, h->lplan, h->stream, img, eta, h->dY, h->n, h->lstore, h->slabs, h->pitch, h->pstat))
+            return fail(-2, "layered kernel launch failed");
+    } else if (h->wide_id >= 0) {
         const int rc = h->jit ? h->jit->wlaunch(&h->wplan, h->stream, &h->nd, img, eta, h->dX, h->dY, h->n, h->wstore, h->wslabA, h->wslabB, h->pstat, h->slabs)
                               : wide_launch(h->wplan, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->wstore, h->wslabA, h->wslabB, h->pstat, h->slabs);
         if (rc) return fail(-2, "wide kernel launch failed");
@@ -717,6 +753,23 @@ static int launch_forward(tbnn_ctx* h, const float* q, const float* dX, long n, 
                               : wide_forward(h->wide_id, h->stream, h->nd, h->qimg_cur, dX, n, dOut);
         if (rc) return fail(-2, "wide forward launch failed");
         HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (h->lay) {
+        // the layered family's forward chain on a store of its own for these n rows
+        LayPlan pp = h->lplan;
+        lay_plan_rows(nd, n, pp);
+        float* st = nullptr;
+        HIPCHK(hipMalloc(&st, (size_t)(pp.aOff[nd.nl] + pp.ntiles * 256 * pp.TM[nd.nl - 1]) * sizeof(float)));
+        hipLaunchKernelGGL(k_make_image, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, q, h->imgmap, h->qimg_cur, 0L, 0L);
+        hipLaunchKernelGGL(k_lay_pack_x, dim3((int)std::min<long>(pp.ntiles * pp.TK[0], 4096)), dim3(256), 0, h->stream, dX, n, nd.d_in, pp.TK[0], pp.ntiles, st + pp.aOff[0]);
+        lay_forward_chain(nd, pp, h->stream, h->qimg_cur, st);
+        hipLaunchKernelGGL(k_lay_unpack_f, dim3((int)std::min<long>(pp.ntiles, 2048)), dim3(256), 0, h->stream, (const float*)(st + pp.aOff[nd.nl]), n, pp.ntiles,
+                           pp.TM[nd.nl - 1], nd.d_out, dOut);
+        const hipError_t le = hipGetLastError();
+        hipStreamSynchronize(h->stream);
+        hipFree(st);
+        if (le != hipSuccess) return fail(-2, "layered forward launch failed");
         return 0;
     }
     if (narrow_fwd_ok(h)) {
@@ -1086,7 +1139,7 @@ extern "C" int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, 
 extern "C" int tbnn_debug_stamps(tbnn_handle h, uint64_t* out5) {
     if (!out5) return fail(-1, "null out16");
     NEED(h);
-    if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0 || h->mid_id >= 0 || h->jit || !h->dX) return fail(-1, "debug_stamps: narrow fast kernel + data required");
+    if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0 || h->mid_id >= 0 || h->jit || h->lay || !h->dX) return fail(-1, "debug_stamps: narrow fast kernel + data required");
     HIPCHK(hipSetDevice(h->device));
     unsigned long long* d = nullptr;
     HIPCHK(hipMalloc(&d, 16 * sizeof(unsigned long long)));

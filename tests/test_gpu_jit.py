@@ -78,12 +78,13 @@ def test_jit_kernel_cooperative_tail(native, monkeypatch, case, grid):
 
 
 def test_jit_unsupported_shape_falls_back(native):
-    """mixed hidden activations: no fused family -> AUTO runs on the generic kernel, FAST fails loudly"""
+    """mixed hidden activations: no fused family -> AUTO runs on the layered MFMA kernels (TBNN_LAYERED=0: the thread-per-row
+    kernel), FAST fails loudly"""
     layers = [(4, 8, native.ACT_RELU, native.PRIOR_CAUCHY), (8, 8, native.ACT_TANH, native.PRIOR_CAUCHY),
               (8, 1, native.ACT_NONE, native.PRIOR_CAUCHY)]
     assert jit.shape_of(layers, native.LIK_GAUSSIAN) is None
     ch = native.Chain(layers, kernel=native.KERNEL_AUTO, jit=True)
-    assert ch.kernel_name == "generic"
+    assert ch.kernel_name == "layered<4,8,8,1>"
     ch.close()
     with pytest.raises(native.TbnnError):
         native.Chain(layers, kernel=native.KERNEL_FAST, jit=True)

@@ -1,0 +1,121 @@
+"""GPU: the layered MFMA family (kernels_layered.hpp) -- what an architecture runs on when no shape-specialised fused kernel
+covers it: fan-in above 32 (the reference's MNIST example, docs/ClassificationExample.md: 784 -> 20 -> 20 -> 1), mixed hidden
+activations, more than two outputs, widths above 256.  Value, gradient and statistic against the fp64 oracle and the
+thread-per-row kernel; transitions against the oracle; forward against the oracle."""
+import numpy as np
+import pytest
+
+import tbnn_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+LOGP_RTOL = 4e-6
+
+
+def scaled_problem(dims, n, acts, prior, lik, seed=0):
+    """synth_problem's recipe with per-layer activations and inputs scaled so that wide fan-ins do not saturate"""
+    final = o.ACT_SIGMOID if lik == o.LIK_BERNOULLI else o.ACT_NONE
+    spec = o.make_spec(dims, acts[0], prior, lik, final)
+    for l, a in zip(spec.layers[:-1], acts):
+        l.act = a
+    rng = np.random.Generator(np.random.PCG64(100 + seed))
+    X = (rng.standard_normal((n, dims[0])) / np.sqrt(dims[0])).astype(np.float32)
+    parts = []
+    for l in spec.layers:
+        sd = (2.0 / l.out_dim) ** 0.5
+        parts.append(((rng.standard_normal((l.out_dim, l.in_dim)) * sd).astype(np.float32),
+                      (rng.standard_normal((l.out_dim, 1)) * sd).astype(np.float32)))
+    theta = o.flatten(parts).astype(np.float32)
+    f = o.forward(spec, theta, X, np.float64).T
+    if lik == o.LIK_BERNOULLI:
+        Y = (rng.random(f.shape) < f).astype(np.float32)
+    else:
+        Y = (f + 0.3 * rng.standard_normal(f.shape)).astype(np.float32)
+    theta0 = (theta + 0.1 * rng.standard_normal(theta.shape)).astype(np.float32)
+    eta = o.default_hypers(spec, 0.1)
+    return spec, X, Y, theta0, eta
+
+
+CASES = {
+    "mnist_like": ([784, 20, 20, 1], 1500, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_BERNOULLI),
+    "tabular100": ([100, 50, 50, 1], 3000 + 5, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
+    "mixed_acts": ([4, 8, 8, 1], 777, [o.ACT_RELU, o.ACT_TANH], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
+    "three_out": ([6, 33, 17, 3], 1000, [o.ACT_TANH, o.ACT_SIGMOID], o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN),
+    "wide300": ([8, 300, 300, 1], 640, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
+    "exact16": ([16, 32, 16, 2], 333, [o.ACT_ELU, o.ACT_ELU], o.PRIOR_CAUCHY, o.LIK_BERNOULLI),     # ones slots open a tile of their own
+    "one_layer": ([40, 1], 500, [], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
+    "deep": ([5, 12, 12, 12, 12, 12, 12, 1], 900, [o.ACT_TANH] * 6, o.PRIOR_CAUCHY, o.LIK_FIXED_GAUSSIAN),
+}
+
+
+def make_chain(native, spec, kernel, **kw):
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    return native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, kernel=kernel, jit=False, **kw)
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_logp_grad_layered(native, case):
+    dims, n, acts, prior, lik = CASES[case]
+    spec, X, Y, theta, eta = scaled_problem(dims, n, acts or [o.ACT_RELU], prior, lik)
+    ch = make_chain(native, spec, native.KERNEL_AUTO)
+    assert ch.kernel_name.startswith("layered<"), ch.kernel_name
+    ch.set_data(X, Y)
+    lp, g, st = ch.logp_grad(theta, eta)
+    lp2, g2, st2 = ch.logp_grad(theta, eta)
+    assert lp == lp2 and st == st2 and np.array_equal(g, g2)                  # deterministic
+    ch.close()
+    lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)[:2]
+    assert abs(lp - lp64) <= LOGP_RTOL * abs(lp64) + 1e-3
+    for l, (ow, ob) in zip(spec.layers, spec.offsets()):
+        for a, b in ((ow, ob), (ob, ob + l.out_dim)):
+            assert np.abs(g[a:b] - g64[a:b]).max() <= 1e-4 * max(np.abs(g64[a:b]).max(), 1e-3), (case, a, b)
+    gen = make_chain(native, spec, native.KERNEL_GENERIC)
+    gen.set_data(X, Y)
+    lpg, gg, stg = gen.logp_grad(theta, eta)
+    gen.close()
+    assert abs(st - stg) <= 2e-6 * abs(stg) + 1e-4
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 129, 2048 + 3])
+def test_logp_grad_layered_ragged_rows(native, n):
+    spec, X, Y, theta, eta = scaled_problem([40, 24, 3], n, [o.ACT_TANH], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN)
+    ch = make_chain(native, spec, native.KERNEL_AUTO)
+    assert ch.kernel_name.startswith("layered<")
+    ch.set_data(X, Y)
+    lp, g, st = ch.logp_grad(theta, eta)
+    ch.close()
+    lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)[:2]
+    assert abs(lp - lp64) <= LOGP_RTOL * abs(lp64) + 1e-3
+    assert np.abs(g - g64).max() <= 1e-4 * np.abs(g64).max()
+
+
+@pytest.mark.parametrize("case", ["mnist_like", "mixed_acts", "three_out"])
+def test_transition_layered(native, case):
+    dims, n, acts, prior, lik = CASES[case]
+    spec, X, Y, theta, eta = scaled_problem(dims, n, acts, prior, lik)
+    rng = np.random.default_rng(3)
+    p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+    eps, L = 2e-3, 5
+    ch = make_chain(native, spec, native.KERNEL_AUTO)
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    out = ch.hmc_step(eps, L, p0=p0, log_u=float(np.log(0.5)), trace=True)
+    ref = o.weight_step(spec, theta, eta, X, Y, eps, L, p0, float(np.log(0.5)), np.float64)
+    np.testing.assert_allclose(out["trace_logp"], ref.trace_logp, rtol=LOGP_RTOL, atol=2e-3)
+    assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-4 * abs(ref.log_accept_ratio)
+    assert bool(out["accepted"]) == ref.accepted
+    np.testing.assert_allclose(ch.get_state(), ref.theta, rtol=2e-4, atol=2e-5)
+    # a free-running stretch (no trace: the image k_update maintains is the one the GEMMs read)
+    outs = ch.hmc_run(eps, L, 4)
+    assert all(np.isfinite(o_["log_accept_ratio"]) for o_ in outs)
+    ch.close()
+
+
+@pytest.mark.parametrize("case", ["mnist_like", "three_out", "exact16"])
+def test_forward_layered(native, case):
+    dims, n, acts, prior, lik = CASES[case]
+    spec, X, Y, theta, eta = scaled_problem(dims, n, acts, prior, lik)
+    ch = make_chain(native, spec, native.KERNEL_AUTO)
+    f = ch.forward(X[:301], theta)
+    ch.close()
+    ref = o.forward(spec, theta, X[:301], np.float64)
+    np.testing.assert_allclose(f, ref, rtol=2e-5, atol=2e-6)
