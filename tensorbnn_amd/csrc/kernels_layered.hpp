@@ -64,7 +64,7 @@ static inline void lay_plan_rows(const NetDev& nd, long n, LayPlan& p) {
     p.store_floats = o;
     p.NS = (int)std::max<long>(1, std::min<long>(256, p.ntiles / 8));
     p.dw_items = 0;
-    for (int l = 0; l < nd.nl; ++l) p.dw_items += lay_cdiv(p.TM[l], 2) * lay_cdiv(p.TK[l], 2);
+    for (int l = 0; l < nd.nl; ++l) p.dw_items += lay_cdiv(p.TM[l], 4) * lay_cdiv(p.TK[l], 4);       // LAY_DB x LAY_DB tile blocks (k_lay_dw)
     p.NY = std::max(1, std::min(8, lay_cdiv(p.dw_items, 4)));
 }
 // theta index j -> image positions: map[j] (W_l, biases in the ones-slot column), map[P + j] (W_l^T; -1: none)
@@ -159,39 +159,34 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
 }
 
 // likelihood (restated as in kernels_generic.hpp): statistic (Gaussian: sum of squared residuals; Bernoulli: log-prob) and
-// dz of the last layer = dL/df * act'(f).  f, dz: blocks [row tile][TMl][16][16]; one thread per (row, slot) of a block.
+// dz of the last layer = dL/df * act'(f).  f, dz: blocks [row tile][TMl][16][16]; one thread per data row.  Only the real
+// (row, output) entries of dz are written: the padding was zeroed when the store was allocated and nothing else writes it.
 __global__ __launch_bounds__(256) void k_lay_lik(NetDev nd, const float* __restrict__ eta, const float* __restrict__ f, const float* __restrict__ Y,
-                                                  long n, long ntiles, int TMl, float* __restrict__ dz, double* __restrict__ pstat) {
+                                                  long n, int TMl, float* __restrict__ dz, double* __restrict__ pstat) {
     __shared__ double red[4];
-    const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     const float sigma = lik_sigma(nd, eta);
     const float inv_var = 1.f / (sigma * sigma);
     const int lact = nd.act[nd.nl - 1];
     double stat = 0.0;
-    for (long rt = blockIdx.x; rt < ntiles; rt += gridDim.x) {
-        const long row = rt * 16 + r;
-        for (int tt = 0; tt < TMl; ++tt) {
-            const int o = 16 * tt + c;
-            const size_t e = ((size_t)rt * TMl + tt) * 256 + threadIdx.x;
-            float d = 0.f;
-            if (row < n && o < nd.d_out) {
-                const float fi = f[e], y = Y[row * nd.d_out + o];
-                float da;
-                if (nd.lik == TBNN_LIK_BERNOULLI) {
-                    const float p = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);     // likelihood.py:226-231
-                    const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
-                    const float t1 = (y == 0.f) ? 0.f : y * logf(p);          // tfd.Bernoulli.log_prob = xlogy(y,p) + xlog1py(1-y,-p)
-                    const float t2 = (1.f - y == 0.f) ? 0.f : (1.f - y) * log1pf(-p);
-                    stat += (double)(t1 + t2);
-                    da = inside ? (y / p - (1.f - y) / (1.f - p)) : 0.f;
-                } else {
-                    const float res = y - fi;                                   // likelihood.py:88-94
-                    stat += (double)res * (double)res;
-                    da = res * inv_var;
-                }
-                d = da * act_bwd(fi, lact);
+    for (long row = (long)blockIdx.x * 256 + threadIdx.x; row < n; row += (long)gridDim.x * 256) {
+        const size_t base = (size_t)(row >> 4) * TMl * 256 + (row & 15) * 16;
+        for (int o = 0; o < nd.d_out; ++o) {
+            const size_t e = base + (size_t)(o >> 4) * 256 + (o & 15);
+            const float fi = f[e], y = Y[row * nd.d_out + o];
+            float da;
+            if (nd.lik == TBNN_LIK_BERNOULLI) {
+                const float p = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);     // likelihood.py:226-231
+                const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
+                const float t1 = (y == 0.f) ? 0.f : y * logf(p);          // tfd.Bernoulli.log_prob = xlogy(y,p) + xlog1py(1-y,-p)
+                const float t2 = (1.f - y == 0.f) ? 0.f : (1.f - y) * log1pf(-p);
+                stat += (double)(t1 + t2);
+                da = inside ? (y / p - (1.f - y) / (1.f - p)) : 0.f;
+            } else {
+                const float res = y - fi;                                   // likelihood.py:88-94
+                stat += (double)res * (double)res;
+                da = res * inv_var;
             }
-            dz[e] = d;
+            dz[e] = da * act_bwd(fi, lact);
         }
     }
     const double tot = block_sum(stat, red);
@@ -199,49 +194,61 @@ __global__ __launch_bounds__(256) void k_lay_lik(NetDev nd, const float* __restr
 }
 
 // dW_l[u][k] = sum over rows dz_l[row][u] [a_l, 1][row][k], every layer, over this workgroup's row tiles; output tiles in
-// blocks of 2 x 2, dealt out over the waves (and over grid.y); every entry of the slab is written by exactly one wave.
+// blocks of up to LAY_DB x LAY_DB (an operand block feeds LAY_DB MFMAs), dealt out over the waves (and over grid.y); every
+// entry of the slab is written by exactly one wave.
+#define LAY_DB 4
+static inline int lay_dw_items(const LayPlan& p) {
+    int c = 0;
+    for (int l = 0; l < p.nl; ++l) c += ((p.TM[l] + LAY_DB - 1) / LAY_DB) * ((p.TK[l] + LAY_DB - 1) / LAY_DB);
+    return c;
+}
 __global__ __launch_bounds__(256) void k_lay_dw(NetDev nd, LayPlan p, const float* __restrict__ store, float* __restrict__ slabs, int pitch) {
-    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long per = (p.ntiles + gridDim.x - 1) / gridDim.x;
     const long lo = (long)blockIdx.x * per, hi = lo + per < p.ntiles ? lo + per : p.ntiles;
     float* slab = slabs + (size_t)blockIdx.x * pitch;
     for (int item = wave + 4 * blockIdx.y; item < p.dw_items; item += 4 * gridDim.y) {
         int l = 0, rem = item;
-        for (; l < p.nl; ++l) { const int c = ((p.TM[l] + 1) / 2) * ((p.TK[l] + 1) / 2); if (rem < c) break; rem -= c; }
-        const int KB = (p.TK[l] + 1) / 2;
-        const int tu0 = 2 * (rem / KB), tk0 = 2 * (rem % KB);
+        for (; l < p.nl; ++l) { const int c = ((p.TM[l] + LAY_DB - 1) / LAY_DB) * ((p.TK[l] + LAY_DB - 1) / LAY_DB); if (rem < c) break; rem -= c; }
+        const int KB = (p.TK[l] + LAY_DB - 1) / LAY_DB;
+        const int tu0 = LAY_DB * (rem / KB), tk0 = LAY_DB * (rem % KB);
         const int TMl = p.TM[l], TKl = p.TK[l];
-        const bool u1 = tu0 + 1 < TMl, k1 = tk0 + 1 < TKl;
+        const int nu = TMl - tu0 < LAY_DB ? TMl - tu0 : LAY_DB, nk = TKl - tk0 < LAY_DB ? TKl - tk0 : LAY_DB;     // wave-uniform
         const float* dzb = store + p.dOff[l] + lane;
         const float* ab = store + p.aOff[l] + lane;
-        f32x4 acc[2][2];
+        f32x4 acc[LAY_DB][LAY_DB];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < LAY_DB; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+            for (int b = 0; b < LAY_DB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (long rt = lo; rt < hi; ++rt) {
             const float* d0 = dzb + ((size_t)rt * TMl + tu0) * 256;
             const float* a0 = ab + ((size_t)rt * TKl + tk0) * 256;
-            float A[2][4], B[2][4];
+            float A[LAY_DB][4], B[LAY_DB][4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                A[0][s] = d0[64 * s]; A[1][s] = u1 ? d0[256 + 64 * s] : 0.f;
-                B[0][s] = a0[64 * s]; B[1][s] = k1 ? a0[256 + 64 * s] : 0.f;
-            }
+            for (int a = 0; a < LAY_DB; ++a)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    A[a][s] = a < nu ? d0[256 * a + 64 * s] : 0.f;
+                    B[a][s] = a < nk ? a0[256 * a + 64 * s] : 0.f;
+                }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < LAY_DB; ++a) {
+                    if (a >= nu) continue;
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[a][b] = mfma16(A[a][s], B[b][s], acc[a][b]);
+                    for (int b = 0; b < LAY_DB; ++b)
+                        if (b < nk) acc[a][b] = mfma16(A[a][s], B[b][s], acc[a][b]);
+                }
         }
         // D[m][n]: lane (i, g) reg j = dW[unit 16 tu + 4 g + j][slot 16 tk + i]
         const int in = nd.in[l], out = nd.out[l];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < LAY_DB; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < LAY_DB; ++b) {
+                if (a >= nu || b >= nk) continue;
                 const int k = 16 * (tk0 + b) + i16;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -292,7 +299,7 @@ static inline int lay_launch(const NetDev& nd, const LayPlan& p, hipStream_t st,
                              float* store, float* slabs, int pitch, double* pstat) {
     lay_forward_chain(nd, p, st, img, store);
     const int L = nd.nl - 1;
-    hipLaunchKernelGGL(k_lay_lik, dim3(p.NS), dim3(256), 0, st, nd, eta, (const float*)(store + p.aOff[nd.nl]), Y, n, p.ntiles, p.TM[L], store + p.dOff[L], pstat);
+    hipLaunchKernelGGL(k_lay_lik, dim3(p.NS), dim3(256), 0, st, nd, eta, (const float*)(store + p.aOff[nd.nl]), Y, n, p.TM[L], store + p.dOff[L], pstat);
     for (int l = L; l >= 1; --l) {
         const int MT = p.TM[l - 1];
         const bool two = p.ntiles * ((MT + LAY_TB - 1) / LAY_TB) >= 4096;

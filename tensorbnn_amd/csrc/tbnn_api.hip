@@ -376,6 +376,7 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
         grid = h->lplan.NS;
         h->scratchPerWG = 0;
         HIPCHK(hipMalloc(&h->lstore, (size_t)h->lplan.store_floats * sizeof(float)));
+        HIPCHK(hipMemsetAsync(h->lstore, 0, (size_t)h->lplan.store_floats * sizeof(float), h->stream));     // dz padding: written once, here
         // a_0 = the rows in block form, once per data set
         const long tot = h->lplan.ntiles * h->lplan.TK[0];
         hipLaunchKernelGGL(k_lay_pack_x, dim3((int)std::min<long>(tot, 4096)), dim3(256), 0, h->stream, (const float*)h->dX, n, nd.d_in, h->lplan.TK[0],
@@ -742,6 +743,30 @@ static int narrow_forward(tbnn_ctx* h, int nets, const float* imgs, long img_str
     return fast3_forward(h->fast_id, gx, nets, h->stream, imgs, img_stride, dX, n, dOut, out_stride);
 }
 
+// the layered family's forward chain (network.predict) on a store of its own: the rows are packed once, then any number of
+// networks run over them
+struct LayFwd { LayPlan pp{}; float* st = nullptr; long n = 0; };
+static int lay_fwd_prepare(tbnn_ctx* h, const float* dX, long n, LayFwd& lf) {
+    const NetDev& nd = h->nd;
+    lf.pp = h->lplan; lf.n = n;
+    lay_plan_rows(nd, n, lf.pp);
+    HIPCHK(hipMalloc(&lf.st, (size_t)(lf.pp.aOff[nd.nl] + lf.pp.ntiles * 256 * lf.pp.TM[nd.nl - 1]) * sizeof(float)));
+    hipLaunchKernelGGL(k_lay_pack_x, dim3((int)std::min<long>(lf.pp.ntiles * lf.pp.TK[0], 4096)), dim3(256), 0, h->stream, dX, n, nd.d_in, lf.pp.TK[0],
+                       lf.pp.ntiles, lf.st + lf.pp.aOff[0]);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int lay_fwd_run(tbnn_ctx* h, const LayFwd& lf, const float* q, float* dOut) {
+    const NetDev& nd = h->nd;
+    hipLaunchKernelGGL(k_make_image, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, q, h->imgmap, h->qimg_cur, 0L, 0L);
+    lay_forward_chain(nd, lf.pp, h->stream, h->qimg_cur, lf.st);
+    hipLaunchKernelGGL(k_lay_unpack_f, dim3((int)std::min<long>(lf.pp.ntiles, 2048)), dim3(256), 0, h->stream, (const float*)(lf.st + lf.pp.aOff[nd.nl]), lf.n,
+                       lf.pp.ntiles, lf.pp.TM[nd.nl - 1], nd.d_out, dOut);
+    if (hipGetLastError() != hipSuccess) return fail(-2, "layered forward launch failed");
+    return 0;
+}
+static void lay_fwd_release(LayFwd& lf) { if (lf.st) hipFree(lf.st); lf.st = nullptr; }
+
 // forward pass of the network at the weights q (device) over dX[n][d_in] -> dOut[d_out][n], on h->stream
 static int launch_forward(tbnn_ctx* h, const float* q, const float* dX, long n, float* dOut) {
     const NetDev& nd = h->nd;
@@ -756,21 +781,12 @@ static int launch_forward(tbnn_ctx* h, const float* q, const float* dX, long n, 
         return 0;
     }
     if (h->lay) {
-        // the layered family's forward chain on a store of its own for these n rows
-        LayPlan pp = h->lplan;
-        lay_plan_rows(nd, n, pp);
-        float* st = nullptr;
-        HIPCHK(hipMalloc(&st, (size_t)(pp.aOff[nd.nl] + pp.ntiles * 256 * pp.TM[nd.nl - 1]) * sizeof(float)));
-        hipLaunchKernelGGL(k_make_image, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, q, h->imgmap, h->qimg_cur, 0L, 0L);
-        hipLaunchKernelGGL(k_lay_pack_x, dim3((int)std::min<long>(pp.ntiles * pp.TK[0], 4096)), dim3(256), 0, h->stream, dX, n, nd.d_in, pp.TK[0], pp.ntiles, st + pp.aOff[0]);
-        lay_forward_chain(nd, pp, h->stream, h->qimg_cur, st);
-        hipLaunchKernelGGL(k_lay_unpack_f, dim3((int)std::min<long>(pp.ntiles, 2048)), dim3(256), 0, h->stream, (const float*)(st + pp.aOff[nd.nl]), n, pp.ntiles,
-                           pp.TM[nd.nl - 1], nd.d_out, dOut);
-        const hipError_t le = hipGetLastError();
+        LayFwd lf;
+        int rc = lay_fwd_prepare(h, dX, n, lf);
+        if (!rc) rc = lay_fwd_run(h, lf, q, dOut);
         hipStreamSynchronize(h->stream);
-        hipFree(st);
-        if (le != hipSuccess) return fail(-2, "layered forward launch failed");
-        return 0;
+        lay_fwd_release(lf);
+        return rc;
     }
     if (narrow_fwd_ok(h)) {
         // MFMA forward of the narrow family (k_forward_fast3): image of q, one network
@@ -901,6 +917,12 @@ extern "C" int tbnn_forward_many(tbnn_handle h, const float* thetas, int32_t m, 
                                (long)nd.P, (long)h->img_floats);
             rc = narrow_forward(h, c, dImg, h->img_floats, dX, rows, dOut, (long)per_net);
             if (rc) rc = fail(-2, "fast3 ensemble forward launch failed");
+        } else if (h->lay) {
+            LayFwd lf;
+            rc = lay_fwd_prepare(h, dX, rows, lf);
+            for (int i = 0; i < c && !rc; ++i) rc = lay_fwd_run(h, lf, dTh + (size_t)i * nd.P, dOut + (size_t)i * per_net);
+            hipStreamSynchronize(h->stream);
+            lay_fwd_release(lf);
         } else {
             for (int i = 0; i < c && !rc; ++i) rc = launch_forward(h, dTh + (size_t)i * nd.P, dX, rows, dOut + (size_t)i * per_net);
         }

@@ -19,6 +19,7 @@ SHAPES = {
     "wide": ([3, 20, 36, 2], 1500, o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN),
     "generic": ([4, 9, 2], 700, o.ACT_ELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
     "bern": ([20, 32, 16, 48, 2], 1030, o.ACT_SIGMOID, o.PRIOR_CAUCHY, o.LIK_BERNOULLI),
+    "layered": ([40, 24, 24, 3], 900, o.ACT_TANH, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),       # three outputs: no fused family (kernels_layered.hpp)
 }
 
 

@@ -119,3 +119,52 @@ def test_forward_layered(native, case):
     ch.close()
     ref = o.forward(spec, theta, X[:301], np.float64)
     np.testing.assert_allclose(f, ref, rtol=2e-5, atol=2e-6)
+
+
+def test_forward_many_layered(native):
+    dims, n, acts, prior, lik = CASES["three_out"]
+    spec, X, Y, theta, eta = scaled_problem(dims, n, acts, prior, lik)
+    ch = make_chain(native, spec, native.KERNEL_AUTO)
+    thetas = np.stack([theta, theta * 0.5, theta + 0.25]).astype(np.float32)
+    out = ch.forward_many(thetas, X[:200])
+    ch.set_validation(X[:77], Y[:77])
+    out_v = ch.forward_many(thetas, None, which=1)
+    ch.close()
+    for i in range(3):
+        ref = o.forward(spec, thetas[i], X[:200], np.float64)
+        np.testing.assert_allclose(out[i], ref, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(out_v[i], ref[:, :77], rtol=2e-5, atol=2e-6)
+
+
+def test_mnist_shaped_classification_flow(tmp_path, monkeypatch, native):
+    """docs/ClassificationExample.md's network -- 784 inputs in [0, 1], two hidden layers of 20, one sigmoid output,
+    BernoulliLikelihood -- through the drop-in Python API on synthetic 'images': runs on the layered family (fan-in 784),
+    learns, writes samples the predictor reads back."""
+    from tensorbnn_amd.activationFunctions import Relu, Sigmoid
+    from tensorbnn_amd.layer import DenseLayer
+    from tensorbnn_amd.likelihood import BernoulliLikelihood
+    from tensorbnn_amd.metrics import Accuracy
+    from tensorbnn_amd.network import network
+    from tensorbnn_amd.predictor import predictor
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("TBNN_JIT", "0")
+    rng = np.random.default_rng(11)
+    proto = rng.random((2, 784)).astype(np.float32)                       # two 'digits'
+    lab = (rng.random(1200) < 0.5).astype(np.float32)
+    X = np.clip(proto[lab.astype(int)] * 0.6 + 0.4 * rng.random((1200, 784)), 0, 1).astype(np.float32)
+    net = network(np.float32, 784, X[:1000], lab[:1000, None], X[1000:], lab[1000:, None])
+    net.add(DenseLayer(784, 20, seed=1000)); net.add(Relu())
+    net.add(DenseLayer(20, 20, seed=2000)); net.add(Relu())
+    net.add(DenseLayer(20, 1, seed=3000)); net.add(Sigmoid())
+    net.setupMCMC(stepSizeStart=1e-3, stepSizeMin=2e-4, stepSizeMax=4e-3, stepSizeOptions=10, leapfrogStart=20, leapfogMin=10,
+                  leapFrogMax=40, leapfrogIncrement=5, hyperStepSize=1e-4, hyperLeapfrog=10, burnin=20, averagingSteps=5)
+    rec = net.train(50, 5, BernoulliLikelihood(), metricList=[Accuracy()], adjustHypers=True, folderName="mnist", networksPerFile=2,
+                    displaySkip=25)
+    assert net._chain.kernel_name == "layered<784,20,20,1>"
+    assert len(rec) == 50 and np.mean([r["main"]["accept_prob"] for r in rec]) > 0.2
+    p = predictor(str(tmp_path / "mnist") + "/", likelihood=BernoulliLikelihood())
+    preds = np.array(p.predict(X[1000:]))
+    assert preds.shape[1:] == (1, 200)
+    assert np.mean((preds.mean(axis=0)[0] > 0.5) == (lab[1000:] > 0.5)) > 0.9
+    spec = o.make_spec([784, 20, 20, 1], o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI, final_act=o.ACT_SIGMOID)
+    np.testing.assert_allclose(preds[0], o.forward(spec, p.vectors[0], X[1000:], np.float64), rtol=5e-5, atol=2e-5)
