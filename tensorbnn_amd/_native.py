@@ -156,7 +156,8 @@ class Chain:
         self.d_out = int(layers[-1][1])
         self.n = 0
         if kernel == KERNEL_AUTO and self.kernel_name == "generic" and len(layers) >= 2:
-            # loud, not silent: the generic thread-per-row kernel is ~100x off the MFMA kernels
+            # loud, not silent: the generic thread-per-row kernel is ~100x off the MFMA kernels; only
+            # reached with TBNN_LAYERED=0 -- otherwise tbnn_create picks the layered MFMA family for such shapes
             import warnings
             warnings.warn(f"tensorbnn_amd: network {[int(layers[0][0])] + [int(l[1]) for l in layers]} runs on the generic "
                           "thread-per-row kernel: no MFMA kernel family covers this shape, or hipcc is not available to "
