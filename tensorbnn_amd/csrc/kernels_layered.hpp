@@ -101,16 +101,23 @@ __global__ __launch_bounds__(256) void k_lay_pack_x(const float* __restrict__ X,
 // MODE 0 (forward): v = act(acc) for the n_units real units, 1 in the ones slot, 0 behind.
 // MODE 1 (backward): v = acc * act'(AUX[rt][t]) for the n_units real units (AUX = the activations those units produced), 0 behind.
 #define LAY_TB 4
-template <int MODE, int RB>
+// SK (split K over the workgroup): when the work items do not fill the chip (few rows, long fan-in: 784 -> 20 at n = 12 k is 750
+// items of 50 dependent k-groups each) one item goes to a WORKGROUP, its 4 waves take a quarter of the k-groups each with 8
+// k-groups of loads in flight, and the partial tiles meet in LDS.  Otherwise one item per wave.
+template <int MODE, int RB, bool SK>
 __global__ __launch_bounds__(256) void k_lay_gemm(
     const float* __restrict__ img, int wpitch, const float* __restrict__ in, int KG, float* __restrict__ outb, int MT,
     const float* __restrict__ aux, int auxT, long ntiles, int act, int n_units, int ones_slot)
 {
-    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+    __shared__ f32x4 part[SK ? 4 * RB * LAY_TB * 64 : 1];
+    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int TG = (MT + LAY_TB - 1) / LAY_TB;
     const long RP = (ntiles + RB - 1) / RB;
-    const long items = RP * TG, nw = (long)gridDim.x * 4;
-    for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += nw) {
+    const long items = RP * TG;
+    const long first = SK ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave, stride = SK ? (long)gridDim.x : (long)gridDim.x * 4;
+    const int KQ = SK ? (KG + 3) / 4 : KG;
+    const int k_lo = SK ? wave * KQ : 0, k_hi = SK ? (k_lo + KQ < KG ? k_lo + KQ : KG) : KG;
+    for (long it = first; it < items; it += stride) {
         const long rp = it / TG; const int t0 = (int)(it - rp * TG) * LAY_TB;
         const long rt0 = rp * RB;
         f32x4 acc[RB][LAY_TB];
@@ -118,23 +125,49 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int t = 0; t < LAY_TB; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* wrow = img + (size_t)(16 * t0 + i16) * wpitch + 4 * g;
-        const float* brow = in + (size_t)rt0 * KG * 256 + i16 * 16 + 4 * g;
-#pragma unroll 2
-        for (int kg = 0; kg < KG; ++kg) {
+        // operand pointers: tiles / row tiles past the end are CLAMPED to the last valid one (their accumulators are never stored),
+        // so that every load of the k loop is unconditional -- a guarded load is a branch, and branches between the loads keep
+        // them from being in flight together
+        const float* wp[LAY_TB]; const float* bp[RB];
+#pragma unroll
+        for (int t = 0; t < LAY_TB; ++t) { const int tt = t0 + t < MT ? t0 + t : MT - 1; wp[t] = img + (size_t)(16 * tt + i16) * wpitch + 4 * g; }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) { const long rr = rt0 + r < ntiles ? rt0 + r : ntiles - 1; bp[r] = in + (size_t)rr * KG * 256 + i16 * 16 + 4 * g; }
+        auto kstep = [&](int kg) __attribute__((always_inline)) {
             f32x4 A[LAY_TB], B[RB];
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
-                B[r] = rt0 + r < ntiles ? *reinterpret_cast<const f32x4*>(brow + ((size_t)r * KG + kg) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < RB; ++r) B[r] = *reinterpret_cast<const f32x4*>(bp[r] + (size_t)kg * 256);
 #pragma unroll
-            for (int t = 0; t < LAY_TB; ++t)
-                A[t] = t0 + t < MT ? *reinterpret_cast<const f32x4*>(wrow + (size_t)(16 * t) * wpitch + 16 * kg) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < LAY_TB; ++t) A[t] = *reinterpret_cast<const f32x4*>(wp[t] + 16 * kg);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int t = 0; t < LAY_TB; ++t)
 #pragma unroll
                     for (int r = 0; r < RB; ++r) acc[r][t] = mfma16(A[t][j], B[r][j], acc[r][t]);
+        };
+        if (SK) {
+#pragma unroll 8
+            for (int kg = k_lo; kg < k_hi; ++kg) kstep(kg);
+            // partial tiles -> LDS; wave w finishes the (r, t) pairs with (r * LAY_TB + t) % 4 == w, summing the waves in fixed order
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int t = 0; t < LAY_TB; ++t) part[((wave * RB + r) * LAY_TB + t) * 64 + lane] = acc[r][t];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int t = 0; t < LAY_TB; ++t) {
+                    if ((r * LAY_TB + t) % 4 != wave) continue;
+                    f32x4 s4 = part[((0 * RB + r) * LAY_TB + t) * 64 + lane];
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) { const f32x4 q = part[((w * RB + r) * LAY_TB + t) * 64 + lane]; s4[0] += q[0]; s4[1] += q[1]; s4[2] += q[2]; s4[3] += q[3]; }
+                    acc[r][t] = s4;
+                }
+        } else {
+#pragma unroll 4
+            for (int kg = 0; kg < KG; ++kg) kstep(kg);
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -142,6 +175,7 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
 #pragma unroll
             for (int t = 0; t < LAY_TB; ++t) {
                 if (t0 + t >= MT) continue;
+                if (SK && (r * LAY_TB + t) % 4 != wave) continue;
                 f32x4 v;
                 const int u0 = 16 * (t0 + t) + 4 * g;
                 if (MODE == 0) {
@@ -155,6 +189,26 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
                 *reinterpret_cast<f32x4*>(outb + ((size_t)(rt0 + r) * MT + t0 + t) * 256 + i16 * 16 + 4 * g) = v;
             }
         }
+        if (SK) __syncthreads();            // `part` is free again
+    }
+}
+// launch one GEMM: two row tiles per item when there is plenty of work, one otherwise; split K over the workgroup when even
+// that leaves most of the 1024 SIMDs without a wave and the fan-in is long enough to pay for the LDS round
+template <int MODE>
+static inline void lay_gemm_launch(hipStream_t st, const float* img, int wpitch, const float* in, int KG, float* outb, int MT,
+                                   const float* aux, int auxT, long ntiles, int act, int n_units, int ones_slot) {
+    const int TG = (MT + LAY_TB - 1) / LAY_TB;
+    const long items1 = ntiles * TG;
+    if (items1 >= 4096) {
+        const long items = ((ntiles + 1) / 2) * TG;
+        hipLaunchKernelGGL((k_lay_gemm<MODE, 2, false>), dim3((int)std::min<long>((items + 3) / 4, 8192)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
+                           ntiles, act, n_units, ones_slot);
+    } else if (items1 < 1024 && KG >= 8) {
+        hipLaunchKernelGGL((k_lay_gemm<MODE, 1, true>), dim3((int)std::max<long>(1, items1)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
+                           ntiles, act, n_units, ones_slot);
+    } else {
+        hipLaunchKernelGGL((k_lay_gemm<MODE, 1, false>), dim3((int)std::max<long>(1, (items1 + 3) / 4)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
+                           ntiles, act, n_units, ones_slot);
     }
 }
 
@@ -221,16 +275,18 @@ __global__ __launch_bounds__(256) void k_lay_dw(NetDev nd, LayPlan p, const floa
         for (int a = 0; a < LAY_DB; ++a)
 #pragma unroll
             for (int b = 0; b < LAY_DB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
         for (long rt = lo; rt < hi; ++rt) {
             const float* d0 = dzb + ((size_t)rt * TMl + tu0) * 256;
             const float* a0 = ab + ((size_t)rt * TKl + tk0) * 256;
             float A[LAY_DB][4], B[LAY_DB][4];
+            // unconditional loads (blocks past the end clamped: their MFMAs are skipped, wave-uniformly)
 #pragma unroll
             for (int a = 0; a < LAY_DB; ++a)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    A[a][s] = a < nu ? d0[256 * a + 64 * s] : 0.f;
-                    B[a][s] = a < nk ? a0[256 * a + 64 * s] : 0.f;
+                    A[a][s] = d0[256 * (a < nu ? a : nu - 1) + 64 * s];
+                    B[a][s] = a0[256 * (a < nk ? a : nk - 1) + 64 * s];
                 }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -274,25 +330,11 @@ __global__ __launch_bounds__(256) void k_lay_unpack_f(const float* __restrict__ 
     }
 }
 
-static inline int lay_gemm_grid(long ntiles, int MT, int RB) {
-    const long items = ((ntiles + RB - 1) / RB) * ((MT + LAY_TB - 1) / LAY_TB);
-    return (int)std::max<long>(1, std::min<long>((items + 3) / 4, 8192));
-}
 // the forward chain: a_0 (packed) -> ... -> f
 static inline void lay_forward_chain(const NetDev& nd, const LayPlan& p, hipStream_t st, const float* img, float* store) {
-    for (int l = 0; l < nd.nl; ++l) {
-        const bool last = l + 1 == nd.nl;
-        const int MT = p.TO[l];
-        const bool two = p.ntiles * ((MT + LAY_TB - 1) / LAY_TB) >= 4096;
-        if (two)
-            hipLaunchKernelGGL((k_lay_gemm<0, 2>), dim3(lay_gemm_grid(p.ntiles, MT, 2)), dim3(256), 0, st, img + p.wOff[l], 16 * p.TK[l],
-                               (const float*)(store + p.aOff[l]), p.TK[l], store + p.aOff[l + 1], MT, (const float*)nullptr, 0, p.ntiles, nd.act[l], nd.out[l],
-                               last ? -1 : nd.out[l]);
-        else
-            hipLaunchKernelGGL((k_lay_gemm<0, 1>), dim3(lay_gemm_grid(p.ntiles, MT, 1)), dim3(256), 0, st, img + p.wOff[l], 16 * p.TK[l],
-                               (const float*)(store + p.aOff[l]), p.TK[l], store + p.aOff[l + 1], MT, (const float*)nullptr, 0, p.ntiles, nd.act[l], nd.out[l],
-                               last ? -1 : nd.out[l]);
-    }
+    for (int l = 0; l < nd.nl; ++l)
+        lay_gemm_launch<0>(st, img + p.wOff[l], 16 * p.TK[l], store + p.aOff[l], p.TK[l], store + p.aOff[l + 1], p.TO[l], nullptr, 0, p.ntiles,
+                           nd.act[l], nd.out[l], l + 1 == nd.nl ? -1 : nd.out[l]);
 }
 // one gradient: forward chain, likelihood, delta chain, dW slabs (p.NS slabs of `pitch` floats; pstat[p.NS])
 static inline int lay_launch(const NetDev& nd, const LayPlan& p, hipStream_t st, const float* img, const float* eta, const float* Y, long n,
@@ -300,18 +342,9 @@ static inline int lay_launch(const NetDev& nd, const LayPlan& p, hipStream_t st,
     lay_forward_chain(nd, p, st, img, store);
     const int L = nd.nl - 1;
     hipLaunchKernelGGL(k_lay_lik, dim3(p.NS), dim3(256), 0, st, nd, eta, (const float*)(store + p.aOff[nd.nl]), Y, n, p.TM[L], store + p.dOff[L], pstat);
-    for (int l = L; l >= 1; --l) {
-        const int MT = p.TM[l - 1];
-        const bool two = p.ntiles * ((MT + LAY_TB - 1) / LAY_TB) >= 4096;
-        if (two)
-            hipLaunchKernelGGL((k_lay_gemm<1, 2>), dim3(lay_gemm_grid(p.ntiles, MT, 2)), dim3(256), 0, st, img + p.tOff[l], 16 * p.TM[l],
-                               (const float*)(store + p.dOff[l]), p.TM[l], store + p.dOff[l - 1], MT, (const float*)(store + p.aOff[l]), p.TK[l], p.ntiles,
-                               nd.act[l - 1], nd.out[l - 1], -1);
-        else
-            hipLaunchKernelGGL((k_lay_gemm<1, 1>), dim3(lay_gemm_grid(p.ntiles, MT, 1)), dim3(256), 0, st, img + p.tOff[l], 16 * p.TM[l],
-                               (const float*)(store + p.dOff[l]), p.TM[l], store + p.dOff[l - 1], MT, (const float*)(store + p.aOff[l]), p.TK[l], p.ntiles,
-                               nd.act[l - 1], nd.out[l - 1], -1);
-    }
+    for (int l = L; l >= 1; --l)
+        lay_gemm_launch<1>(st, img + p.tOff[l], 16 * p.TM[l], store + p.dOff[l], p.TM[l], store + p.dOff[l - 1], p.TM[l - 1], store + p.aOff[l], p.TK[l],
+                           p.ntiles, nd.act[l - 1], nd.out[l - 1], -1);
     hipLaunchKernelGGL(k_lay_dw, dim3(p.NS, p.NY), dim3(256), 0, st, nd, p, (const float*)store, slabs, pitch);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

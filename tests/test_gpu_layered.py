@@ -37,8 +37,9 @@ def scaled_problem(dims, n, acts, prior, lik, seed=0):
 
 
 CASES = {
-    "mnist_like": ([784, 20, 20, 1], 1500, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_BERNOULLI),
+    "mnist_like": ([784, 20, 20, 1], 1500, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_BERNOULLI),     # split-K GEMMs
     "tabular100": ([100, 50, 50, 1], 3000 + 5, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
+    "tabular100_big": ([100, 50, 50, 1], 70000 + 9, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),   # two row tiles per wave
     "mixed_acts": ([4, 8, 8, 1], 777, [o.ACT_RELU, o.ACT_TANH], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
     "three_out": ([6, 33, 17, 3], 1000, [o.ACT_TANH, o.ACT_SIGMOID], o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN),
     "wide300": ([8, 300, 300, 1], 640, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
