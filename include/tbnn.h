@@ -46,7 +46,9 @@ enum { TBNN_PRIOR_CAUCHY = 0, TBNN_PRIOR_GAUSSIAN = 1 };
 /* likelihood.py:63 (Gaussian), :136 (FixedGaussian), :205 (Bernoulli) */
 enum { TBNN_LIK_GAUSSIAN = 0, TBNN_LIK_FIXED_GAUSSIAN = 1, TBNN_LIK_BERNOULLI = 2 };
 
-/* kernel selection for the fused forward+backward pass */
+/* kernel selection for the forward+backward pass.  AUTO: a fused shape-specialised MFMA kernel where one covers the network
+ * (built in or registered at run time), else the layered run-time-shape MFMA kernels (any architecture); FAST: a fused kernel or
+ * an error; GENERIC: the thread-per-row kernel (on-device cross-check) */
 enum { TBNN_KERNEL_AUTO = 0, TBNN_KERNEL_GENERIC = 1, TBNN_KERNEL_FAST = 2 };
 
 typedef struct tbnn_layer_desc {
@@ -96,7 +98,7 @@ int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed, uint32_t c
 int tbnn_destroy(tbnn_handle h);
 int tbnn_param_count(tbnn_handle h);  /* P */
 int tbnn_hyper_count(tbnn_handle h);  /* H */
-/* name of the fused kernel variant in use ("generic", "fast<...>") */
+/* name of the kernel variant in use ("fast3<...>", "mid<...>", "wide<...>", "layered<...>", "generic") */
 const char* tbnn_kernel_name(tbnn_handle h);
 
 /* trainX / trainY staging, network.py:41-45.  X [n,d_in] row-major, Y [n,d_out]. */
@@ -184,7 +186,7 @@ int tbnn_metrics(tbnn_handle h, int which, const float* theta, float mean, float
  * TBNN_KERNEL_AUTO / _FAST for that shape use it.  (The reference gets the same effect from
  * tf.function tracing + XLA, network.py:359-362.) ---- */
 int tbnn_register_kernel_lib(const char* path);
-/* 0: only the generic kernel covers the shape; 1 / 2: ahead-of-time narrow / wide MFMA kernels; 3: a registered library */
+/* 0: no fused kernel covers the shape (KERNEL_AUTO then runs the layered run-time-shape MFMA kernels); 1 / 2: ahead-of-time narrow / wide MFMA kernels; 3: a registered library */
 int tbnn_fused_kernel_available(const tbnn_net_desc* desc);
 
 /* ---- RCCL over xGMI.  librccl.so is resolved with dlopen on the first

@@ -4,12 +4,13 @@ The fused forward+backward kernels are C++ templates over the network shape (csr
 csrc/kernels_wide.hpp); libtbnn.so carries ahead-of-time instantiations for BASELINE's configs only.
 For any other network this module writes a ten-line translation unit, compiles it with hipcc for
 gfx950 into a cached shared object and registers it with the library (tbnn_register_kernel_lib), so
-that `Chain(..., kernel=KERNEL_AUTO)` runs on MFMA instead of the generic thread-per-row kernel.
+that `Chain(..., kernel=KERNEL_AUTO)` runs on a FUSED kernel instead of the layered run-time-shape MFMA kernels
+(csrc/kernels_layered.hpp: what any architecture without a fused kernel runs on, 2-3x slower where both apply).
 (The reference gets there through tf.function tracing + XLA, network.py:359-362; here the kernels
 are hand-written and only their *shape parameters* are bound at run time.)
 
 Family choice (first that compiles wins; a shape no family accepts is remembered as `.fail` and
-runs on the generic kernel):
+runs on the layered kernels):
   * narrow (`k_fwd_bwd_fast3`, else `k_fwd_bwd_fast`): every dW accumulator in one wave's registers --
     fan-in <= 16, at most NARROW_TILES 16x16 dW tiles in total;
   * mid (`k_fwd_bwd_mid`): >= 3 dense layers, <= 2 outputs, fan-in <= 32, at most 63 dW tiles over the MFMA
@@ -117,12 +118,12 @@ def source(dims, hact, lact, bern, family) -> str:
 
 
 def _warn_generic(dims, why):
-    print(f"tensorbnn_amd: WARNING: network {dims} runs on the GENERIC thread-per-row kernel (~1 % of the MFMA roofline): "
-          f"{why}", file=sys.stderr, flush=True)
+    print(f"tensorbnn_amd: note: network {dims} runs on the layered run-time-shape MFMA kernels (kernels_layered.hpp), not on a fused "
+          f"kernel: {why}", file=sys.stderr, flush=True)
 
 
 def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Optional[str]:
-    """path of the compiled kernel library for this network, or None (generic kernel, with a warning)"""
+    """path of the compiled kernel library for this network, or None (layered kernels, with a note on stderr)"""
     import fcntl
     sh = shape_of(layers, likelihood)
     if sh is None:
@@ -204,7 +205,7 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
 
 
 def ensure_registered(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> bool:
-    """compile (or fetch from the cache) and register the kernels of this network; False: generic kernel"""
+    """compile (or fetch from the cache) and register the kernels of this network; False: no fused kernel (layered family)"""
     from . import _native as nat
     path = build(layers, likelihood, verbose)
     if path is None:
