@@ -97,14 +97,13 @@ __global__ __launch_bounds__(256) void k_lay_pack_x(const float* __restrict__ X,
     }
 }
 
-// OUT[rt][t] = epilogue( sum over k-groups  IMG[16 t + i][16 kg + ..] x IN[rt][kg] ),  one wave = RB row tiles x up to 4 output tiles.
+// OUT[rt][t] = epilogue( sum over k-groups  IMG[16 t + i][16 kg + ..] x IN[rt][kg] ),  one wave = RB row tiles x up to LAY_TB (1, 2 or 4) output tiles.
 // MODE 0 (forward): v = act(acc) for the n_units real units, 1 in the ones slot, 0 behind.
 // MODE 1 (backward): v = acc * act'(AUX[rt][t]) for the n_units real units (AUX = the activations those units produced), 0 behind.
-#define LAY_TB 4
 // SK (split K over the workgroup): when the work items do not fill the chip (few rows, long fan-in: 784 -> 20 at n = 12 k is 750
 // items of 50 dependent k-groups each) one item goes to a WORKGROUP, its 4 waves take a quarter of the k-groups each with 8
 // k-groups of loads in flight, and the partial tiles meet in LDS.  Otherwise one item per wave.
-template <int MODE, int RB, bool SK>
+template <int MODE, int RB, bool SK, int LAY_TB>
 __global__ __launch_bounds__(256) void k_lay_gemm(
     const float* __restrict__ img, int wpitch, const float* __restrict__ in, int KG, float* __restrict__ outb, int MT,
     const float* __restrict__ aux, int auxT, long ntiles, int act, int n_units, int ones_slot)
@@ -194,22 +193,31 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
 }
 // launch one GEMM: two row tiles per item when there is plenty of work, one otherwise; split K over the workgroup when even
 // that leaves most of the 1024 SIMDs without a wave and the fan-in is long enough to pay for the LDS round
-template <int MODE>
-static inline void lay_gemm_launch(hipStream_t st, const float* img, int wpitch, const float* in, int KG, float* outb, int MT,
-                                   const float* aux, int auxT, long ntiles, int act, int n_units, int ones_slot) {
+template <int MODE, int LAY_TB>
+static inline void lay_gemm_launch_tb(hipStream_t st, const float* img, int wpitch, const float* in, int KG, float* outb, int MT,
+                                      const float* aux, int auxT, long ntiles, int act, int n_units, int ones_slot) {
     const int TG = (MT + LAY_TB - 1) / LAY_TB;
     const long items1 = ntiles * TG;
     if (items1 >= 4096) {
         const long items = ((ntiles + 1) / 2) * TG;
-        hipLaunchKernelGGL((k_lay_gemm<MODE, 2, false>), dim3((int)std::min<long>((items + 3) / 4, 8192)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
+        hipLaunchKernelGGL((k_lay_gemm<MODE, 2, false, LAY_TB>), dim3((int)std::min<long>((items + 3) / 4, 8192)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
                            ntiles, act, n_units, ones_slot);
     } else if (items1 < 1024 && KG >= 8) {
-        hipLaunchKernelGGL((k_lay_gemm<MODE, 1, true>), dim3((int)std::max<long>(1, items1)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
+        hipLaunchKernelGGL((k_lay_gemm<MODE, 1, true, LAY_TB>), dim3((int)std::max<long>(1, items1)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
                            ntiles, act, n_units, ones_slot);
     } else {
-        hipLaunchKernelGGL((k_lay_gemm<MODE, 1, false>), dim3((int)std::max<long>(1, (items1 + 3) / 4)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
+        hipLaunchKernelGGL((k_lay_gemm<MODE, 1, false, LAY_TB>), dim3((int)std::max<long>(1, (items1 + 3) / 4)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
                            ntiles, act, n_units, ones_slot);
     }
+}
+
+// output tiles per item: 4, or all of them when the layer has only 1 or 2 (a 20-unit layer would otherwise issue its MFMAs twice)
+template <int MODE>
+static inline void lay_gemm_launch(hipStream_t st, const float* img, int wpitch, const float* in, int KG, float* outb, int MT,
+                                   const float* aux, int auxT, long ntiles, int act, int n_units, int ones_slot) {
+    if (MT == 1) lay_gemm_launch_tb<MODE, 1>(st, img, wpitch, in, KG, outb, MT, aux, auxT, ntiles, act, n_units, ones_slot);
+    else if (MT == 2) lay_gemm_launch_tb<MODE, 2>(st, img, wpitch, in, KG, outb, MT, aux, auxT, ntiles, act, n_units, ones_slot);
+    else lay_gemm_launch_tb<MODE, 4>(st, img, wpitch, in, KG, outb, MT, aux, auxT, ntiles, act, n_units, ones_slot);
 }
 
 // likelihood (restated as in kernels_generic.hpp): statistic (Gaussian: sum of squared residuals; Bernoulli: log-prob) and
