@@ -356,8 +356,8 @@ def _short_cpu(c):
 def _short_roof(r):
     if not r:
         return None
-    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_rocprof", "rocprof_source", "traffic", "kernel_us",
-            "end_to_end_frac")
+    keep = ("bound", "achieved", "peak", "unit", "frac", "frac_rocprof", "rocprof_source", "traffic", "kernel_us",
+            "end_to_end_frac")          # ("kernel" is config.kernel: not repeated on the short line)
     out = {k: r[k] for k in keep if k in r}
     if "launch latency" in str(out.get("bound", "")):
         out["bound"] = "launch latency"
@@ -395,7 +395,7 @@ def compact_line(line):
                 e["hyper_step"] = float("%.3g" % r["hyper_step_size"]["last"]) if r.get("hyper_step_size") else None
             sec[key.replace(" with GaussianDenseLayer priors", "g")] = e
         out["secondary"] = sec
-        out["secondary_note"] = "configs[4]: Cauchy priors (hyper target improper, Q1); configs[4]g: Gaussian priors; full: gpurun_out/bench_full.json"
+        out["secondary_note"] = "configs[4]: Cauchy priors (improper hyper target, Q1); [4]g: Gaussian priors; full record: gpurun_out/bench_full.json"
     return out
 
 
