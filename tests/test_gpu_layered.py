@@ -44,6 +44,7 @@ CASES = {
     "three_out": ([6, 33, 17, 3], 1000, [o.ACT_TANH, o.ACT_SIGMOID], o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN),
     "wide300": ([8, 300, 300, 1], 640, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
     "exact16": ([16, 32, 16, 2], 333, [o.ACT_ELU, o.ACT_ELU], o.PRIOR_CAUCHY, o.LIK_BERNOULLI),     # ones slots open a tile of their own
+    "many_out": ([9, 30, 20], 450, [o.ACT_TANH], o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN),                  # 20 outputs: two tiles in the likelihood
     "one_layer": ([40, 1], 500, [], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
     "deep": ([5, 12, 12, 12, 12, 12, 12, 1], 900, [o.ACT_TANH] * 6, o.PRIOR_CAUCHY, o.LIK_FIXED_GAUSSIAN),
 }
