@@ -42,6 +42,12 @@ struct LayPlan {
     int NS;                           // gradient slabs = workgroups of k_lay_dw (x) = workgroups of k_lay_lik
     int NY;                           // k_lay_dw grid.y: splits the tile-block list
     int dw_items;
+    // the fused tail (k_lay_tail): layers l0 .. nl-1 (all narrow enough) + likelihood + their delta chain in ONE launch
+    int l0;                           // nl: no tail
+    int TT;                           // its compile-time tile bound: 2 or 4
+    int GT;                           // its grid; NP = entries of the statistic buffer in use = max(NS, GT)
+    int NP;
+    int tail;                         // this data set runs the tail (set per data set: lay_plan_rows)
 };
 
 static inline int lay_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
@@ -55,6 +61,12 @@ static inline void lay_plan_shape(const NetDev& nd, LayPlan& p) {
     for (int l = 0; l < nd.nl; ++l) { p.tOff[l] = o; if (l >= 1) o += 256 * p.TM[l - 1] * p.TM[l]; }
     p.img_floats = (o + 3) & ~3;
     p.ntiles = 0; p.store_floats = 0; p.NS = 1; p.NY = 1; p.dw_items = 0;
+    // the longest suffix of layers whose tile counts all fit the tail kernel's register arrays (<= 4 tiles = 63 units + ones slot)
+    p.l0 = nd.nl; p.TT = 2;
+    while (p.l0 >= 1 && p.TK[p.l0 - 1] <= 4 && p.TO[p.l0 - 1] <= 4 && p.TM[p.l0 - 1] <= 4) --p.l0;
+    for (int l = p.l0; l < nd.nl; ++l) if (p.TK[l] > 2 || p.TO[l] > 2 || p.TM[l] > 2 || (l >= 1 && p.TM[l - 1] > 2)) p.TT = 4;
+    if (const char* e = getenv("TBNN_LAY_TAIL")) if (atoi(e) == 0) p.l0 = nd.nl;       // A/B runs: one launch per layer and direction
+    p.GT = 1; p.NP = 1; p.tail = 0;
 }
 static inline void lay_plan_rows(const NetDev& nd, long n, LayPlan& p) {
     p.ntiles = (n + 15) / 16;
@@ -66,6 +78,11 @@ static inline void lay_plan_rows(const NetDev& nd, long n, LayPlan& p) {
     p.dw_items = 0;
     for (int l = 0; l < nd.nl; ++l) p.dw_items += lay_cdiv(p.TM[l], 4) * lay_cdiv(p.TK[l], 4);       // LAY_DB x LAY_DB tile blocks (k_lay_dw)
     p.NY = std::max(1, std::min(8, lay_cdiv(p.dw_items, 4)));
+    // the tail's grid: at most 512 workgroups, every wave the same number of row tiles
+    const long rounds = std::max<long>(1, (p.ntiles + 2047) / 2048);
+    p.GT = (int)std::max<long>(1, (p.ntiles + 4 * rounds - 1) / (4 * rounds));
+    p.tail = p.l0 < nd.nl && p.ntiles < 2048;      // it saves launches; over many rows the separate GEMMs are as fast (measured: r03_notes)
+    p.NP = p.tail ? std::max(p.NS, p.GT) : p.NS;
 }
 // theta index j -> image positions: map[j] (W_l, biases in the ones-slot column), map[P + j] (W_l^T; -1: none)
 static inline void lay_image_map(const NetDev& nd, const LayPlan& p, int* map) {
@@ -326,6 +343,141 @@ __global__ __launch_bounds__(256) void k_lay_dw(NetDev nd, LayPlan p, const floa
     }
 }
 
+// The fused tail: one wave takes a row tile through layers l0 .. nl-1, the likelihood and the delta chain back to dz_{l0-1}
+// (dz_0 when l0 = 0) with the activations in registers -- the D layout of one layer is the B-operand layout of the next, as in
+// the fused families -- for layers of at most TT tiles.  It stores every a_l / dz_l it produces (k_lay_dw and the remaining
+// backward GEMMs read them) and re-reads a_l for act' (just written: L2).  Register arrays are indexed at compile time only:
+// the k-group / tile loops always run TT x TT, operand tiles past a layer's end are CLAMPED loads multiplied by zero
+// activations, result tiles past the end are zeroed.  Replaces 2 (nl - l0) launches: 784 -> 20 -> 20 -> 1 runs 4 launches per
+// gradient instead of 8.
+template <int TT>
+__global__ __launch_bounds__(256) void k_lay_tail(NetDev nd, LayPlan p, const float* __restrict__ img, const float* __restrict__ eta,
+                                                  const float* __restrict__ Y, long n, float* __restrict__ store, double* __restrict__ pstat) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float sigma = lik_sigma(nd, eta);
+    const float inv_var = 1.f / (sigma * sigma);
+    const int nl = p.nl, l0 = p.l0, lact = nd.act[nl - 1], lane_off = i16 * 16 + 4 * g;
+    double stat = 0.0;
+    for (long rt = (long)blockIdx.x * 4 + wave; rt < p.ntiles; rt += (long)gridDim.x * 4) {
+        f32x4 a[TT];
+        {
+            const int TKl = p.TK[l0];
+            const float* ab = store + p.aOff[l0] + (size_t)rt * TKl * 256 + lane_off;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ab + (t < TKl ? t : TKl - 1) * 256);
+                a[t] = t < TKl ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // ---- forward
+        for (int l = l0; l < nl; ++l) {
+            const int KG = p.TK[l], MT = p.TO[l], wp = 16 * KG, out = nd.out[l], act = nd.act[l];
+            const int ones = l + 1 < nl ? out : -1;
+            const float* w = img + p.wOff[l] + (size_t)i16 * wp + 4 * g;
+            f32x4 A[TT][TT], acc[TT];
+#pragma unroll
+            for (int kg = 0; kg < TT; ++kg)
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    A[kg][t] = *reinterpret_cast<const f32x4*>(w + (size_t)(16 * (t < MT ? t : MT - 1)) * wp + 16 * (kg < KG ? kg : KG - 1));
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kg = 0; kg < TT; ++kg)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) acc[t] = mfma16(A[kg][t][j], a[kg][j], acc[t]);      // a[kg] == 0 for kg >= KG
+            float* ob = store + p.aOff[l + 1] + (size_t)rt * MT * 256 + lane_off;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int u = 16 * t + 4 * g + j;
+                    v[j] = (t < MT && u < out) ? act_fwd(acc[t][j], act) : (u == ones ? 1.f : 0.f);
+                }
+                a[t] = v;
+                if (t < MT) *reinterpret_cast<f32x4*>(ob + t * 256) = v;
+            }
+        }
+        // ---- likelihood: a = f (lane (row i16, g) holds outputs 16 t + 4 g + j)
+        f32x4 dz[TT];
+        {
+            const long row = rt * 16 + i16;
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int o = 16 * t + 4 * g + j;
+                    float d = 0.f;
+                    if (row < n && o < nd.d_out) {
+                        const float fi = a[t][j], y = Y[row * nd.d_out + o];
+                        float da;
+                        if (nd.lik == TBNN_LIK_BERNOULLI) {
+                            const float pr = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);    // likelihood.py:226-231
+                            const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
+                            const float t1 = (y == 0.f) ? 0.f : y * logf(pr);
+                            const float t2 = (1.f - y == 0.f) ? 0.f : (1.f - y) * log1pf(-pr);
+                            stat += (double)(t1 + t2);
+                            da = inside ? (y / pr - (1.f - y) / (1.f - pr)) : 0.f;
+                        } else {
+                            const float res = y - fi;                                  // likelihood.py:88-94
+                            stat += (double)res * (double)res;
+                            da = res * inv_var;
+                        }
+                        d = da * act_bwd(fi, lact);
+                    }
+                    dz[t][j] = d;
+                }
+        }
+        // ---- delta chain: dz_l stored, dz_{l-1} = (W_l^T dz_l) * act'_{l-1}(a_l)
+        const int lend = l0 > 1 ? l0 : 1;
+        for (int l = nl - 1; l >= lend; --l) {
+            const int KG = p.TM[l], MT = p.TM[l - 1], wp = 16 * KG, out = nd.out[l - 1], act = nd.act[l - 1], TKl = p.TK[l];
+            float* db = store + p.dOff[l] + (size_t)rt * KG * 256 + lane_off;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) if (t < KG) *reinterpret_cast<f32x4*>(db + t * 256) = dz[t];
+            const float* w = img + p.tOff[l] + (size_t)i16 * wp + 4 * g;
+            const float* ab = store + p.aOff[l] + (size_t)rt * TKl * 256 + lane_off;
+            f32x4 A[TT][TT], acc[TT], aux[TT];
+#pragma unroll
+            for (int kg = 0; kg < TT; ++kg)
+#pragma unroll
+                for (int t = 0; t < TT; ++t)
+                    A[kg][t] = *reinterpret_cast<const f32x4*>(w + (size_t)(16 * (t < MT ? t : MT - 1)) * wp + 16 * (kg < KG ? kg : KG - 1));
+#pragma unroll
+            for (int t = 0; t < TT; ++t) aux[t] = *reinterpret_cast<const f32x4*>(ab + (t < MT ? t : MT - 1) * 256);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kg = 0; kg < TT; ++kg)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) acc[t] = mfma16(A[kg][t][j], dz[kg][j], acc[t]);     // dz[kg] == 0 for kg >= KG
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int u = 16 * t + 4 * g + j;
+                    dz[t][j] = (t < MT && u < out) ? acc[t][j] * act_bwd(aux[t][j], act) : 0.f;
+                }
+        }
+        {
+            const int TMl = p.TM[lend - 1];
+            float* db = store + p.dOff[lend - 1] + (size_t)rt * TMl * 256 + lane_off;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) if (t < TMl) *reinterpret_cast<f32x4*>(db + t * 256) = dz[t];
+        }
+    }
+    const double wtot = wave_sum(stat);
+    if (lane == 0) red[wave] = wtot;
+    __syncthreads();
+    if (threadIdx.x == 0) pstat[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // network output f blocks -> fout[d_out][n] (network.predict, network.py:141-171)
 __global__ __launch_bounds__(256) void k_lay_unpack_f(const float* __restrict__ f, long n, long ntiles, int TMl, int d_out, float* __restrict__ fout) {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -344,13 +496,24 @@ static inline void lay_forward_chain(const NetDev& nd, const LayPlan& p, hipStre
         lay_gemm_launch<0>(st, img + p.wOff[l], 16 * p.TK[l], store + p.aOff[l], p.TK[l], store + p.aOff[l + 1], p.TO[l], nullptr, 0, p.ntiles,
                            nd.act[l], nd.out[l], l + 1 == nd.nl ? -1 : nd.out[l]);
 }
-// one gradient: forward chain, likelihood, delta chain, dW slabs (p.NS slabs of `pitch` floats; pstat[p.NS])
+// one gradient: forward chain, likelihood, delta chain, dW slabs (p.NS slabs of `pitch` floats; pstat[p.NP])
 static inline int lay_launch(const NetDev& nd, const LayPlan& p, hipStream_t st, const float* img, const float* eta, const float* Y, long n,
                              float* store, float* slabs, int pitch, double* pstat) {
-    lay_forward_chain(nd, p, st, img, store);
     const int L = nd.nl - 1;
-    hipLaunchKernelGGL(k_lay_lik, dim3(p.NS), dim3(256), 0, st, nd, eta, (const float*)(store + p.aOff[nd.nl]), Y, n, p.TM[L], store + p.dOff[L], pstat);
-    for (int l = L; l >= 1; --l)
+    int lb;                                   // the backward GEMMs still to run: layers lb .. 1
+    if (p.tail) {
+        for (int l = 0; l < p.l0; ++l)
+            lay_gemm_launch<0>(st, img + p.wOff[l], 16 * p.TK[l], store + p.aOff[l], p.TK[l], store + p.aOff[l + 1], p.TO[l], nullptr, 0, p.ntiles,
+                               nd.act[l], nd.out[l], nd.out[l]);
+        if (p.TT == 2) hipLaunchKernelGGL(k_lay_tail<2>, dim3(p.GT), dim3(256), 0, st, nd, p, img, eta, Y, n, store, pstat);
+        else hipLaunchKernelGGL(k_lay_tail<4>, dim3(p.GT), dim3(256), 0, st, nd, p, img, eta, Y, n, store, pstat);
+        lb = (p.l0 > 1 ? p.l0 : 1) - 1;
+    } else {
+        lay_forward_chain(nd, p, st, img, store);
+        hipLaunchKernelGGL(k_lay_lik, dim3(p.NS), dim3(256), 0, st, nd, eta, (const float*)(store + p.aOff[nd.nl]), Y, n, p.TM[L], store + p.dOff[L], pstat);
+        lb = L;
+    }
+    for (int l = lb; l >= 1; --l)
         lay_gemm_launch<1>(st, img + p.tOff[l], 16 * p.TM[l], store + p.dOff[l], p.TM[l], store + p.dOff[l - 1], p.TM[l - 1], store + p.aOff[l], p.TK[l],
                            p.ntiles, nd.act[l - 1], nd.out[l - 1], -1);
     hipLaunchKernelGGL(k_lay_dw, dim3(p.NS, p.NY), dim3(256), 0, st, nd, p, (const float*)store, slabs, pitch);

@@ -373,7 +373,7 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
     if (h->lstore) { hipFree(h->lstore); h->lstore = nullptr; }
     if (h->lay) {
         lay_plan_rows(nd, n, h->lplan);
-        grid = h->lplan.NS;
+        grid = h->lplan.NP;                       // entries of the statistic buffer in use; the gradient slabs: lplan.NS
         h->scratchPerWG = 0;
         HIPCHK(hipMalloc(&h->lstore, (size_t)h->lplan.store_floats * sizeof(float)));
         HIPCHK(hipMemsetAsync(h->lstore, 0, (size_t)h->lplan.store_floats * sizeof(float), h->stream));     // dz padding: written once, here
@@ -403,7 +403,7 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
     // tbnn_forward always uses the generic forward kernel: keep a scratch for it
     h->grid = grid;
     h->pitch = (nd.P + 3) & ~3;                  // float4-readable slabs
-    h->nslab = h->wide_id >= 0 ? 1 : grid;
+    h->nslab = h->wide_id >= 0 ? 1 : (h->lay ? h->lplan.NS : grid);
     HIPCHK(hipMalloc(&h->slabs, (size_t)h->nslab * h->pitch * sizeof(float)));
     HIPCHK(hipMemset(h->slabs, 0, (size_t)h->nslab * h->pitch * sizeof(float)));
     if (grid > PSTAT_CAP) return fail(-2, "grid exceeds PSTAT_CAP");

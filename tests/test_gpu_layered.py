@@ -123,6 +123,24 @@ def test_forward_layered(native, case):
     np.testing.assert_allclose(f, ref, rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("case", ["mnist_like", "tabular100", "three_out", "deep", "one_layer"])
+def test_fused_tail_matches_separate_launches(native, monkeypatch, case):
+    """k_lay_tail (the narrow suffix of layers + likelihood + their delta chain in one launch; row counts below 32 k) against one
+    launch per layer and direction (TBNN_LAY_TAIL=0): value, statistic and gradient"""
+    dims, n, acts, prior, lik = CASES[case]
+    spec, X, Y, theta, eta = scaled_problem(dims, n, acts or [o.ACT_RELU], prior, lik)
+    res = []
+    for tail in ("1", "0"):
+        monkeypatch.setenv("TBNN_LAY_TAIL", tail)
+        ch = make_chain(native, spec, native.KERNEL_AUTO)
+        ch.set_data(X, Y)
+        res.append(ch.logp_grad(theta, eta))
+        ch.close()
+    (lp1, g1, st1), (lp0, g0, st0) = res
+    assert abs(lp1 - lp0) <= 1e-6 * abs(lp0) and abs(st1 - st0) <= 1e-6 * abs(st0)
+    assert np.abs(g1 - g0).max() <= 2e-5 * np.abs(g0).max()
+
+
 def test_forward_many_layered(native):
     dims, n, acts, prior, lik = CASES["three_out"]
     spec, X, Y, theta, eta = scaled_problem(dims, n, acts, prior, lik)
