@@ -188,3 +188,33 @@ def test_mnist_shaped_classification_flow(tmp_path, monkeypatch, native):
     assert np.mean((preds.mean(axis=0)[0] > 0.5) == (lab[1000:] > 0.5)) > 0.9
     spec = o.make_spec([784, 20, 20, 1], o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI, final_act=o.ACT_SIGMOID)
     np.testing.assert_allclose(preds[0], o.forward(spec, p.vectors[0], X[1000:], np.float64), rtol=5e-5, atol=2e-5)
+
+
+def test_layered_data_swap_metrics_and_hyper_step(native):
+    """the same chain over two data sets of different size (the activation store is rebuilt), the device metrics over the
+    staged rows, and a hyper transition followed by a weight transition (the O(P) refresh of the cached gradient)"""
+    dims, n, acts, prior, lik = CASES["three_out"]
+    spec, X, Y, theta, eta = scaled_problem(dims, n, acts, prior, lik)
+    ch = make_chain(native, spec, native.KERNEL_AUTO, seed=3)
+    for rows in (n, 171, 640):
+        ch.set_data(X[:rows], Y[:rows])
+        lp, g, st = ch.logp_grad(theta, eta)
+        lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X[:rows], Y[:rows], np.float64)[:2]
+        assert abs(lp - lp64) <= LOGP_RTOL * abs(lp64) + 1e-3
+        assert np.abs(g - g64).max() <= 1e-4 * np.abs(g64).max()
+    ch.set_validation(X[:200], Y[:200])
+    ch.set_state(theta); ch.set_hypers(eta)
+    m = ch.metrics(which=1)
+    f = o.forward(spec, theta, X[:200], np.float64).T
+    assert abs(m[0] - np.mean((f - Y[:200]) ** 2)) <= 1e-5 * max(1.0, m[0])
+    # hyper transition, then a weight transition from the refreshed cache against a fresh evaluation at the new hypers
+    p0h = np.random.default_rng(1).standard_normal(spec.n_hypers).astype(np.float32)
+    ch.hmc_step(1e-3, 2)
+    hs = ch.hyper_step(1e-3, 5, p0=p0h, log_u=-1e30)
+    assert hs["accepted"] == 1
+    th, et = ch.get_state(), ch.get_hypers()
+    p0 = np.random.default_rng(2).standard_normal(spec.n_params).astype(np.float32)
+    out = ch.hmc_step(1e-3, 3, p0=p0, log_u=float(np.log(0.5)), trace=True)
+    ref = o.weight_step(spec, th, et, X[:640], Y[:640], 1e-3, 3, p0, float(np.log(0.5)), np.float64)
+    np.testing.assert_allclose(out["trace_logp"], ref.trace_logp, rtol=LOGP_RTOL, atol=2e-3)
+    ch.close()
