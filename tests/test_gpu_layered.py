@@ -218,3 +218,35 @@ def test_layered_data_swap_metrics_and_hyper_step(native):
     ref = o.weight_step(spec, th, et, X[:640], Y[:640], 1e-3, 3, p0, float(np.log(0.5)), np.float64)
     np.testing.assert_allclose(out["trace_logp"], ref.trace_logp, rtol=LOGP_RTOL, atol=2e-3)
     ch.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_layered_random_architectures(native, monkeypatch, seed):
+    """random depth / widths / fan-in / output count / activations / likelihood / row count (tile-boundary widths 15-17, 31-33
+    favoured): value and gradient against the fp64 oracle, with and without the fused tail"""
+    rng = np.random.default_rng(1000 + seed)
+    edge = [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65]
+    pick = lambda hi: int(rng.choice(edge)) if rng.random() < 0.5 else int(rng.integers(1, hi))
+    nl = int(rng.integers(1, 6))
+    dims = [pick(90)] + [pick(70) for _ in range(nl - 1)] + [int(rng.integers(1, 6))]
+    acts = [int(rng.choice([o.ACT_RELU, o.ACT_TANH, o.ACT_SIGMOID, o.ACT_ELU])) for _ in range(nl - 1)]
+    lik = int(rng.choice([o.LIK_GAUSSIAN, o.LIK_BERNOULLI, o.LIK_FIXED_GAUSSIAN]))
+    prior = int(rng.choice([o.PRIOR_CAUCHY, o.PRIOR_GAUSSIAN]))
+    n = int(rng.choice([1, 16, 17, 100, 333, 1000]))
+    spec, X, Y, theta, eta = scaled_problem(dims, n, acts or [o.ACT_RELU], prior, lik, seed=seed)
+    lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)[:2]
+    for tail in ("1", "0"):
+        monkeypatch.setenv("TBNN_LAY_TAIL", tail)
+        monkeypatch.setenv("TBNN_JIT", "0")
+        layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+        ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, kernel=native.KERNEL_AUTO, jit=False)
+        if not ch.kernel_name.startswith("layered<"):          # a registry shape by chance
+            ch.close()
+            pytest.skip("registry shape")
+        ch.set_data(X, Y)
+        lp, g, st = ch.logp_grad(theta, eta)
+        ch.close()
+        assert abs(lp - lp64) <= LOGP_RTOL * abs(lp64) + 1e-3, (dims, acts, lik, n, tail)
+        for l, (ow, ob) in zip(spec.layers, spec.offsets()):
+            for a, b in ((ow, ob), (ob, ob + l.out_dim)):
+                assert np.abs(g[a:b] - g64[a:b]).max() <= 1e-4 * max(np.abs(g64[a:b]).max(), 1e-3), (dims, acts, lik, n, tail, a, b)
