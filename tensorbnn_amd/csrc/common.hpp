@@ -26,6 +26,21 @@ struct NetDev {
     int reserved_flags;           // bit 0: fast kernel processes one tile at a time (diagnostic)
 };
 
+// Gradient-slab stores of the narrow family: NON-TEMPORAL (global_store ... nt) when the slabs are big next to the launch (P >= 2048
+// parameters x 256 workgroups: configs[1] writes 5.6 MB in a 47-us launch).  A slab is written once per launch and read once by the
+// next kernel (k_update); kept out of the L2's dirty set, the launch's end no longer waits for its write-back: fused pass 49.6 -> 48.0 us
+// by hipEvent, 18.81 k -> 19.29 k leapfrog steps/s at configs[1].  Measured neutral at configs[3] / configs[4] (0.2 - 3 MB per 0.3 - 4 ms)
+// and slightly negative for small networks (configs[0]: 108.0 k -> 106.1 k: their slabs are L2 hits for k_update) -- those keep plain
+// stores.  TBNN_SLAB_NT=0: plain stores everywhere.
+#ifndef TBNN_SLAB_NT
+#define TBNN_SLAB_NT 1
+#endif
+template <bool NT>
+__device__ __forceinline__ void slab_store(float* ptr, float val) {
+    if constexpr (NT && TBNN_SLAB_NT) __builtin_nontemporal_store(val, ptr);
+    else *ptr = val;
+}
+
 // Per-chain scalar record kept on the device (doubles: energies are summed
 // and differenced in fp64 -- strictly more accurate than the reference's fp32).
 struct Scal {

@@ -660,8 +660,8 @@ struct SlabOut {
                         for (int r = 0; r < 4; ++r) {
                             const int row = unit_of(out, row0 + r, false);
                             if (row >= 0)
-                                slab[C::offW(l) + (col < in ? row * in + col : in * out + row)] =
-                                    (c0[r] + c1[r]) + (c2[r] + c3[r]);                   // col == in: bias (ones column)
+                                slab_store<(C::P() >= 2048)>(slab + C::offW(l) + (col < in ? row * in + col : in * out + row),
+                                        (c0[r] + c1[r]) + (c2[r] + c3[r]));                // col == in: bias (ones column)
                         }
                     }
                 }
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             }
             v += __shfl_xor(v, 1, 64);
             v += __shfl_xor(v, 2, 64);
-            if (e < NE && w == 0) slab[C::offW(Lr) + (u < inL ? o * inL + u : inL * d_out + o)] = v;
+            if (e < NE && w == 0) slab_store<(C::P() >= 2048)>(slab + C::offW(Lr) + (u < inL ? o * inL + u : inL * d_out + o), v);
         }
     }
     if (tid == 0) {

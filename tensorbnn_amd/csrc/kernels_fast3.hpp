@@ -822,7 +822,7 @@ struct SlabOut3 {
                         for (int r = 0; r < 4; ++r) {
                             const int row = unit_of(out, row0 + r, false);
                             if (row >= 0)
-                                slab[C::offW(l) + (col < in ? row * in + col : in * out + row)] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
+                                slab_store<(C::P() >= 2048)>(slab + C::offW(l) + (col < in ? row * in + col : in * out + row), (c0[r] + c1[r]) + (c2[r] + c3[r]));
                         }
                     }
                 }
@@ -857,7 +857,7 @@ struct FringeOut {
                 }
                 const int cs = 16 * nt + i16, u = C::funit(l, f);
                 const int col = l == 0 ? (cs <= in ? cs : -1) : unit_of(in, cs, true);
-                if (col >= 0) slab[C::offW(l) + (col < in ? u * in + col : in * out + u)] = v;
+                if (col >= 0) slab_store<(C::P() >= 2048)>(slab + C::offW(l) + (col < in ? u * in + col : in * out + u), v);
             }
         } else
         // D layout: thread (item = (f, kslot, g), wave): item count per layer = NF * (KIN+1) * 4 lane groups
@@ -886,7 +886,7 @@ struct FringeOut {
                 }
                 v += __shfl_xor(v, 1, 64);
                 v += __shfl_xor(v, 2, 64);
-                if (dest >= 0 && w == 0) slab[dest] = v;
+                if (dest >= 0 && w == 0) slab_store<(C::P() >= 2048)>(slab + dest, v);
             }
         }
         if constexpr (l + 1 < C::NL) FringeOut<S, l + 1>::run(lb, slab, tid);
