@@ -26,18 +26,21 @@ struct NetDev {
     int reserved_flags;           // bit 0: fast kernel processes one tile at a time (diagnostic)
 };
 
-// Gradient-slab stores of the narrow family: NON-TEMPORAL (global_store ... nt) when the slabs are big next to the launch (P >= 2048
-// parameters x 256 workgroups: configs[1] writes 5.6 MB in a 47-us launch).  A slab is written once per launch and read once by the
-// next kernel (k_update); kept out of the L2's dirty set, the launch's end no longer waits for its write-back: fused pass 49.6 -> 48.0 us
-// by hipEvent, 18.81 k -> 19.29 k leapfrog steps/s at configs[1].  Measured neutral at configs[3] / configs[4] (0.2 - 3 MB per 0.3 - 4 ms)
-// and slightly negative for small networks (configs[0]: 108.0 k -> 106.1 k: their slabs are L2 hits for k_update) -- those keep plain
-// stores.  TBNN_SLAB_NT=0: plain stores everywhere.
+// Gradient-slab stores of the narrow family: WRITE-THROUGH (global_store ... sc1: a relaxed agent-scope atomic store) when the slabs
+// are big next to the launch (P >= 2048 parameters x 256 workgroups: configs[1] writes 5.6 MB in a 47-us launch).  A slab is written
+// once per launch and read once by the next kernel (k_update).  Left dirty in the L2s it waits for the end of the launch: between two
+// kernels this 8-XCD part writes every dirty line back, and that write-back sat on the critical path of every leapfrog step.
+// configs[1], bench.py --workload c2: plain stores 18.81 k leapfrog steps/s (fused pass 49.6 us by hipEvent), non-temporal stores
+// 19.31 k (47.9 us), write-through 19.72 k (47.1 us).  Small next to long launches (configs[4], the mid-width kernel: 2,788 -> 2,797 steps/s), neutral for small networks (P < 2048:
+// plain stores), negative for the layered family's many small dW launches (8 -> 300 -> 300 -> 1: 493 -> 511 us): plain stores there.
+// TBNN_SLAB_NT: 0 plain stores everywhere, 1 non-temporal, 2 write-through (default).
 #ifndef TBNN_SLAB_NT
-#define TBNN_SLAB_NT 1
+#define TBNN_SLAB_NT 2
 #endif
 template <bool NT>
 __device__ __forceinline__ void slab_store(float* ptr, float val) {
-    if constexpr (NT && TBNN_SLAB_NT) __builtin_nontemporal_store(val, ptr);
+    if constexpr (NT && TBNN_SLAB_NT == 2) __hip_atomic_store(ptr, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if constexpr (NT && TBNN_SLAB_NT == 1) __builtin_nontemporal_store(val, ptr);
     else *ptr = val;
 }
 

@@ -614,7 +614,7 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                             for (int r = 0; r < 4; ++r) {
                                 const int row = unit_of(outl, 16 * mt + 4 * g + r, false);
                                 if (row >= 0)
-                                    slab[C::offW(l) + (col < inl ? row * inl + col : inl * outl + row)] = (c0[r] + c1[r]) + (c2[r] + c3[r]);
+                                    slab_store<(C::P() >= 2048)>(slab + C::offW(l) + (col < inl ? row * inl + col : inl * outl + row), (c0[r] + c1[r]) + (c2[r] + c3[r]));
                             }
                         }
                     }
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
             float v[MID_WAVES];
 #pragma unroll
             for (int w = 0; w < MID_WAVES; ++w) v[w] = lb[(w * d_out + o) * (16 * TP + 1) + s];
-            slab[C::offW(LL) + (u < inL ? o * inL + u : inL * d_out + o)] = (v[0] + v[1]) + (v[2] + v[3]);
+            slab_store<(C::P() >= 2048)>(slab + C::offW(LL) + (u < inL ? o * inL + u : inL * d_out + o), (v[0] + v[1]) + (v[2] + v[3]));
         }
     }
     if (tid == 0) {
