@@ -18,7 +18,7 @@ the reference's dual averaging per epoch) and configs[0], each with its own roof
 
 roofline: dominant kernel = the fused forward+backward pass (k_fwd_bwd_fast3; k_chain_wide + k_dw_wide for the wide
 configs).  achieved = algorithmic matmul FLOP of one pass (2n(3S - in1*out1)) / its mean duration,
-measured with hipEvent pairs on the chain's own stream around every 10th pass inside the timed region.  peak = 157.3
+measured with hipEvent pairs on the chain's own stream around every 47th pass inside the timed region.  peak = 157.3
 TFLOP/s (FP32 MFMA, dense, MI355X_MICROARCH.md).  traffic = HBM bytes per pass from the committed rocprofv3 PMC pass
 (profiles/), or null.
 cpu_baseline: the oracle's C restatement (oracle/c, kind "port") timed on the host cores on a bounded sample of the
@@ -263,8 +263,11 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
 
     run(warmup, eps_warm)
     hyp_acc.clear(); hyp_eps.clear()
-    # hipEvent pairs around every 10th fused pass: the event pool is created HERE, outside the timed region
-    ch.set_profiling(10)
+    # hipEvent pairs around a sample of the fused passes: the event pool is created HERE, outside the timed region
+    # hipEvent pair around every 47th fused pass inside the timed region (coprime to the trajectory lengths: the samples walk through
+    # all positions of a trajectory).  Every pair costs the stream a bubble: at every 10th pass (rounds 1-3) the pairs themselves took
+    # 1.2 % off the measured rate of configs[1] (19.75 k against 19.98 k leapfrog steps/s)
+    ch.set_profiling(int(os.environ.get("TBNN_BENCH_PROFILE_STRIDE", "47")))
     fence()
     t0 = time.perf_counter()
     outs = run(steps, eps)

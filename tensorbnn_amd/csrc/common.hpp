@@ -152,6 +152,18 @@ __device__ __forceinline__ float philox_normal(uint32_t j, uint32_t epoch, uint3
     const float ang = 6.28318530717958647692f * u2;
     return (j & 1) ? rad * sinf(ang) : rad * cosf(ang);
 }
+// the four normals of Philox block b = j / 4 at once (the same arithmetic as philox_normal, one block cipher instead of four)
+__device__ __forceinline__ void philox_normal4(uint32_t b, uint32_t epoch, uint32_t purpose, uint32_t k0, uint32_t k1, float (&out)[4]) {
+    const Philox4 r = philox4x32_10(b, epoch, purpose, 0u, k0, k1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float u1 = u01(r.v[2 * h]), u2 = u01(r.v[2 * h + 1]);
+        const float rad = sqrtf(-2.f * logf(u1));
+        const float ang = 6.28318530717958647692f * u2;
+        out[2 * h] = rad * cosf(ang);
+        out[2 * h + 1] = rad * sinf(ang);
+    }
+}
 __device__ __forceinline__ float philox_logu(uint32_t epoch, uint32_t purpose, uint32_t k0, uint32_t k1) {
     const Philox4 r = philox4x32_10(0u, epoch, purpose, 0u, k0, k1);
     return logf(u01(r.v[0]));

@@ -159,10 +159,17 @@ __global__ __launch_bounds__(1024) void k_begin(
 {
     __shared__ double red[16];
     double k = 0.0;
-    for (int j = threadIdx.x; j < nd.P; j += blockDim.x) {
-        const float v = p0_inj ? p0_inj[j] : philox_normal((uint32_t)j, epoch, PURPOSE_MOMENTUM, key0, key1);
-        p[j] = v;
-        k += (double)v * (double)v;
+    if (p0_inj) {
+        for (int j = threadIdx.x; j < nd.P; j += blockDim.x) { const float v = p0_inj[j]; p[j] = v; k += (double)v * (double)v; }
+    } else {
+        // one Philox block = four momenta per thread and trip
+        for (int b = threadIdx.x; 4 * b < nd.P; b += blockDim.x) {
+            float v[4];
+            philox_normal4((uint32_t)b, epoch, PURPOSE_MOMENTUM, key0, key1, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * b + i < nd.P) { p[4 * b + i] = v[i]; k += (double)v[i] * (double)v[i]; }
+        }
     }
     k = block_sum(k, red);
     if (threadIdx.x == 0) {
@@ -176,11 +183,16 @@ enum { EN_CUR = 0, EN_NEW = 1, EN_TRACE = 2, EN_REFRESH = 3 };   // EN_REFRESH: 
 // Metropolis decision when which == EN_NEW).
 __global__ __launch_bounds__(1024) void k_energy(
     NetDev nd, int which, const float* __restrict__ eta, const float* __restrict__ q,
-    const float* __restrict__ p, const float* __restrict__ q_cur,
+    const float* __restrict__ p, const float* q_cur,              // (no restrict: the merged commit writes the same array)
     const double* __restrict__ partial_stat, int nslab, long n,
-    Scal* __restrict__ sc, double* __restrict__ trace_slot)
+    Scal* __restrict__ sc, double* __restrict__ trace_slot,
+    // EN_NEW with commit_out: the transition's end in this one launch -- the record for the host (k_commit_scal) and, when
+    // accepted, cur <- proposal (k_commit: q, g, gd); two launches fewer per transition
+    Scal* __restrict__ commit_out = nullptr, const float* __restrict__ g = nullptr, float* q_cur_w = nullptr,
+    float* __restrict__ g_cur = nullptr, const float* __restrict__ gd = nullptr, float* __restrict__ gd_cur = nullptr)
 {
     __shared__ double red[16];
+    __shared__ int s_acc;
     double st = 0.0;
     if (which != EN_REFRESH) {
         for (int w = threadIdx.x; w < nslab; w += blockDim.x) st += partial_stat[w];
@@ -199,24 +211,36 @@ __global__ __launch_bounds__(1024) void k_energy(
         k1 = block_sum(k1, red);
         d2 = block_sum(d2, red);
     }
-    if (threadIdx.x != 0) return;
-    if (which == EN_REFRESH) { st = sc->stat_cur; which = EN_CUR; }
-    const double lp = pr + data_logp(nd, eta, st, n);
-    if (which == EN_TRACE) { *trace_slot = lp; return; }
-    if (which == EN_CUR) {
-        sc->stat_cur = st; sc->prior_cur = pr; sc->logp_cur = lp;
+    const bool commit = which == EN_NEW && commit_out != nullptr;
+    if (threadIdx.x != 0 && !commit) return;
+    if (threadIdx.x == 0) {
+        if (which == EN_REFRESH) { st = sc->stat_cur; which = EN_CUR; }
+        const double lp = pr + data_logp(nd, eta, st, n);
+        if (which == EN_TRACE) { *trace_slot = lp; return; }
+        if (which == EN_CUR) {
+            sc->stat_cur = st; sc->prior_cur = pr; sc->logp_cur = lp;
+            if (trace_slot) *trace_slot = lp;
+            return;
+        }
+        sc->stat_new = st; sc->prior_new = pr; sc->logp_new = lp;
+        sc->k1 = 0.5 * k1; sc->d2 = d2;
+        double lar = lp - sc->logp_cur + sc->k0 - 0.5 * k1;
+        if (!isfinite(lar)) lar = -INFINITY;                       // TFP safe_sum / non-finite => reject
+        sc->lar = lar;
+        const int acc = sc->logu < lar ? 1 : 0;
+        sc->accepted = acc;
+        sc->sjd = acc ? d2 : 0.0;
         if (trace_slot) *trace_slot = lp;
-        return;
+        if (commit) {                                              // k_commit_scal: the record as the host reads it, then cur <- new
+            *commit_out = *sc;
+            if (acc) { sc->stat_cur = st; sc->prior_cur = pr; sc->logp_cur = lp; }
+            s_acc = acc;
+        }
     }
-    sc->stat_new = st; sc->prior_new = pr; sc->logp_new = lp;
-    sc->k1 = 0.5 * k1; sc->d2 = d2;
-    double lar = lp - sc->logp_cur + sc->k0 - 0.5 * k1;
-    if (!isfinite(lar)) lar = -INFINITY;                       // TFP safe_sum / non-finite => reject
-    sc->lar = lar;
-    const int acc = sc->logu < lar ? 1 : 0;
-    sc->accepted = acc;
-    sc->sjd = acc ? d2 : 0.0;
-    if (trace_slot) *trace_slot = lp;
+    if (!commit) return;
+    __syncthreads();
+    if (!s_acc) return;
+    for (int j = threadIdx.x; j < nd.P; j += blockDim.x) { q_cur_w[j] = q[j]; g_cur[j] = g[j]; gd_cur[j] = gd[j]; }       // k_commit
 }
 
 // After EN_NEW: commit the proposal when accepted.  (scalars are committed by

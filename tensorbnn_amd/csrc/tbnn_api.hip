@@ -986,10 +986,19 @@ static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, 
         }
         launch_update(h, t < L ? UPD_MID : UPD_LAST, eps, h->eta, h->q, h->g);
     }
-    launch_energy(h, EN_NEW, h->eta, h->q, d_trace ? d_trace + L : nullptr);
-    hipLaunchKernelGGL(k_commit, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, h->sc, h->q, h->g, h->q_cur, h->g_cur,
-                       (const float*)h->gd, h->gd_cur);
-    hipLaunchKernelGGL(k_commit_scal, dim3(1), dim3(64), 0, h->stream, h->sc, d_out);
+    // the Metropolis decision, the host record and the commit in ONE single-workgroup launch for networks whose state that
+    // workgroup copies in a few trips (TBNN_MERGE_ENDS=0: three launches, as before round 3)
+    static const bool merge_env = !(getenv("TBNN_MERGE_ENDS") && atoi(getenv("TBNN_MERGE_ENDS")) == 0);
+    if (merge_env && nd.P <= 32768) {
+        hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, h->nd, (int)EN_NEW, (const float*)h->eta, (const float*)h->q, (const float*)h->p,
+                           (const float*)h->q_cur, stat_ptr(h), stat_entries(h), rows_total(h), h->sc, d_trace ? d_trace + L : (double*)nullptr,
+                           d_out, (const float*)h->g, h->q_cur, h->g_cur, (const float*)h->gd, h->gd_cur);
+    } else {
+        launch_energy(h, EN_NEW, h->eta, h->q, d_trace ? d_trace + L : nullptr);
+        hipLaunchKernelGGL(k_commit, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, h->sc, h->q, h->g, h->q_cur, h->g_cur,
+                           (const float*)h->gd, h->gd_cur);
+        hipLaunchKernelGGL(k_commit_scal, dim3(1), dim3(64), 0, h->stream, h->sc, d_out);
+    }
     HIPCHK(hipGetLastError());
     h->epoch += 1;
     return 0;

@@ -88,7 +88,9 @@ __device__ __forceinline__ float4 upd_column_partial(const float* slabs, int nsl
 __device__ __forceinline__ void upd_finish(const UpdPre& u, const NetDev& nd, int mode, float eps, const float* __restrict__ eta, int j,
                                            float gj, float* __restrict__ q, float* __restrict__ p, float* __restrict__ g,
                                            const int* __restrict__ imgmap, float* __restrict__ qimg, float* __restrict__ gd) {
-    if (mode != UPD_FIRST && gd) {
+    // (the gradient and its data term are kept for the state a transition ENDS in -- k_commit copies them, the hyper refresh reads
+    // them; between two leapfrog steps nobody reads them: UPD_MID stores neither)
+    if (mode != UPD_FIRST && mode != UPD_MID && gd) {
         const float sg = nd.lik == TBNN_LIK_GAUSSIAN ? lik_sigma(nd, eta) : 1.f;
         gd[j] = gj * (sg * sg);
     }
@@ -102,12 +104,12 @@ __device__ __forceinline__ void upd_finish(const UpdPre& u, const NetDev& nd, in
         return;
     }
     float pj = u.p_j + eps * gj;                              // full kick
-    g[j] = gj;
     if (mode == UPD_MID) {
         const float qj = u.q_j + eps * pj;                    // drift
         p[j] = pj; q[j] = qj;
         if (imgmap) { qimg[u.m0] = qj; if (u.m1 >= 0) qimg[u.m1] = qj; }
     } else {
+        g[j] = gj;
         pj = pj - 0.5f * eps * gj;                            // undo half kick
         p[j] = pj;
     }
