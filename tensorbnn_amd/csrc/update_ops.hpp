@@ -32,13 +32,19 @@ __device__ __forceinline__ float prior_grad(int prior, float loc, float scale, f
 
 // Reduce the per-workgroup gradient slabs, add the prior gradient, then kick /
 // drift.  One thread column = 4 consecutive parameters (float4 slab reads; the
-// slab pitch is a multiple of 4), 16 slab groups per block, every thread keeps
+// slab pitch is a multiple of 4), UPD_GROUPS slab groups per block, every thread keeps
 // 4 independent 16-B loads in flight; fixed-order LDS tree => deterministic.
 // When imgmap != null the new position is also scattered into the padded
 // weight image (W_l and, for l >= 1, W_l^T: imgmap[j] / imgmap[P+j]) the
 // shape-specialised kernel stages into LDS.
-#define UPD_COLS 8     // float4 columns per block (32 parameters)
+// (geometry measured at configs[1] after the slabs became write-through: 8 x 32: 19.92 k leapfrog steps/s, 16 x 16: 19.94, 4 x 64: 19.57,
+// 8 x 16: 19.91, 16 x 32: 20.12, 32 x 32: 20.00, 16 x 64: 19.82, 32 x 16: 19.98)
+#ifndef UPD_COLS
+#define UPD_COLS 16    // float4 columns per block (64 parameters)
+#endif
+#ifndef UPD_GROUPS
 #define UPD_GROUPS 32  // slab groups per block
+#endif
 
 // what a finishing thread (one parameter) needs besides the reduced gradient; fetched BEFORE the slab loads: one memory
 // round trip instead of two on the critical path of a leapfrog step
