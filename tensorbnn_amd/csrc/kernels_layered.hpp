@@ -50,6 +50,20 @@ struct LayPlan {
     int tail;                         // this data set runs the tail (set per data set: lay_plan_rows)
 };
 
+// a result tile's 16 bytes per lane.  Every block this family stores is read by a LATER kernel, and between two kernels this part
+// writes every dirty L2 line back: stored write-through (sc1) nothing waits dirty for a launch's end (784-20-20-1: 56.4 -> 55.0 us per
+// leapfrog step, 100-50-50-1 at 1e5 rows: 153.4 -> 149.6; non-temporal stores instead: 56.4 -> 56.8 / 158.5 -- the reader then misses
+// L2 AND the memory-side cache).  LAY_ST_POLICY=0: plain stores.
+#ifndef LAY_ST_POLICY
+#define LAY_ST_POLICY 2
+#endif
+__device__ __forceinline__ void lay_block_store(float* p, const f32x4& v) {
+#if LAY_ST_POLICY == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
 static inline int lay_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 static inline void lay_plan_shape(const NetDev& nd, LayPlan& p) {
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = u0 + j < n_units ? acc[r][t][j] * act_bwd(a[j], act) : 0.f;
                 }
-                *reinterpret_cast<f32x4*>(outb + ((size_t)(rt0 + r) * MT + t0 + t) * 256 + i16 * 16 + 4 * g) = v;
+                lay_block_store(outb + ((size_t)(rt0 + r) * MT + t0 + t) * 256 + i16 * 16 + 4 * g, v);
             }
         }
         if (SK) __syncthreads();            // `part` is free again
@@ -399,7 +413,7 @@ __global__ __launch_bounds__(256) void k_lay_tail(NetDev nd, LayPlan p, const fl
                     v[j] = (t < MT && u < out) ? act_fwd(acc[t][j], act) : (u == ones ? 1.f : 0.f);
                 }
                 a[t] = v;
-                if (t < MT) *reinterpret_cast<f32x4*>(ob + t * 256) = v;
+                if (t < MT) lay_block_store(ob + t * 256, v);
             }
         }
         // ---- likelihood: a = f (lane (row i16, g) holds outputs 16 t + 4 g + j)
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(256) void k_lay_tail(NetDev nd, LayPlan p, const fl
             const int KG = p.TM[l], MT = p.TM[l - 1], wp = 16 * KG, out = nd.out[l - 1], act = nd.act[l - 1], TKl = p.TK[l];
             float* db = store + p.dOff[l] + (size_t)rt * KG * 256 + lane_off;
 #pragma unroll
-            for (int t = 0; t < TT; ++t) if (t < KG) *reinterpret_cast<f32x4*>(db + t * 256) = dz[t];
+            for (int t = 0; t < TT; ++t) if (t < KG) lay_block_store(db + t * 256, dz[t]);
             const float* w = img + p.tOff[l] + (size_t)i16 * wp + 4 * g;
             const float* ab = store + p.aOff[l] + (size_t)rt * TKl * 256 + lane_off;
             f32x4 A[TT][TT], acc[TT], aux[TT];
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(256) void k_lay_tail(NetDev nd, LayPlan p, const fl
             const int TMl = p.TM[lend - 1];
             float* db = store + p.dOff[lend - 1] + (size_t)rt * TMl * 256 + lane_off;
 #pragma unroll
-            for (int t = 0; t < TT; ++t) if (t < TMl) *reinterpret_cast<f32x4*>(db + t * 256) = dz[t];
+            for (int t = 0; t < TT; ++t) if (t < TMl) lay_block_store(db + t * 256, dz[t]);
         }
     }
     const double wtot = wave_sum(stat);
