@@ -89,6 +89,7 @@ struct tbnn_ctx {
     std::vector<hipEvent_t> pev; size_t pev_used = 0;   // pooled events: created once, re-used after every drain (no allocator in the timed loop)
     // hyper workspace
     float* hyp_ws = nullptr;
+    bool merge_ends = true;                // TBNN_MERGE_ENDS (read at tbnn_create): decision + record + commit in one k_energy launch
 };
 
 extern "C" const char* tbnn_last_error(void) { return g_err.c_str(); }
@@ -340,6 +341,7 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
         HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
     }
     { const char* e1 = getenv("TBNN_FAST_SINGLE"); if (e1 && atoi(e1)) h->nd.reserved_flags |= 1; }
+    { const char* e2 = getenv("TBNN_MERGE_ENDS"); h->merge_ends = !(e2 && atoi(e2) == 0); }
     const char* env = getenv("TBNN_PROFILE_FWDBWD");
     h->profile = env ? atoi(env) : 0;
 #undef HIPB
@@ -988,8 +990,7 @@ static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, 
     }
     // the Metropolis decision, the host record and the commit in ONE single-workgroup launch for networks whose state that
     // workgroup copies in a few trips (TBNN_MERGE_ENDS=0: three launches, as before round 3)
-    static const bool merge_env = !(getenv("TBNN_MERGE_ENDS") && atoi(getenv("TBNN_MERGE_ENDS")) == 0);
-    if (merge_env && nd.P <= 32768) {
+    if (h->merge_ends && nd.P <= 32768) {
         hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, h->nd, (int)EN_NEW, (const float*)h->eta, (const float*)h->q, (const float*)h->p,
                            (const float*)h->q_cur, stat_ptr(h), stat_entries(h), rows_total(h), h->sc, d_trace ? d_trace + L : (double*)nullptr,
                            d_out, (const float*)h->g, h->q_cur, h->g_cur, (const float*)h->gd, h->gd_cur);

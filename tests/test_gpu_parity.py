@@ -195,6 +195,27 @@ def test_logp_grad_fast_cooperative_tail(native, monkeypatch, dims, act, prior, 
     ch.close()
 
 
+@pytest.mark.parametrize("case", ["c1", "c2_small", "c5_small"])
+def test_one_launch_transition_end_is_bit_identical(native, monkeypatch, case):
+    """The Metropolis decision + host record + commit in ONE k_energy launch (default, P <= 32 k) against the three launches of
+    rounds 1-2 (TBNN_MERGE_ENDS=0): the same records and the same state over free-running transitions with accepts and rejects."""
+    spec, X, Y, theta, eta = problem(case)
+    res = []
+    for merged in ("1", "0"):
+        monkeypatch.setenv("TBNN_MERGE_ENDS", merged)
+        ch = make_chain(native, spec, native.KERNEL_AUTO, seed=21, chain_id=3)
+        ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+        outs = ch.hmc_run(1e-5, 5, 6) + ch.hmc_run(5e-2, 5, 6) + [ch.hmc_step(1e-5, 3, trace=True)]      # accepts, then rejects
+        res.append((ch.get_state(), [(o_["log_accept_ratio"], o_["accepted"], o_["logp_old"], o_["logp_new"], o_["kinetic_new"], o_["sjd"]) for o_ in outs],
+                    outs[-1]["trace_logp"]))
+        ch.close()
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(np.array(res[0][1], dtype=np.float64), np.array(res[1][1], dtype=np.float64))     # (NaN == NaN: a diverged proposal)
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    acc = [r[1] for r in res[0][1]]
+    assert 0 < sum(acc) < len(acc), acc
+
+
 def test_fast_vs_generic_full_size(native):
     """BASELINE configs[1] at full size (n=1e5): MFMA kernel vs generic kernel vs fp64 oracle."""
     spec, X, Y, theta, eta = o.synth_problem([5, 50, 50, 50, 1], 100000)
