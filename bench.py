@@ -20,7 +20,7 @@ roofline: dominant kernel = the fused forward+backward pass (k_fwd_bwd_fast3; k_
 configs).  achieved = algorithmic matmul FLOP of one pass (2n(3S - in1*out1)) / its mean duration,
 measured with hipEvent pairs on the chain's own stream around every 47th pass inside the timed region.  peak = 157.3
 TFLOP/s (FP32 MFMA, dense, MI355X_MICROARCH.md).  traffic = HBM bytes per pass from the committed rocprofv3 PMC pass
-(profiles/), or null.
+(profiles/) -- quoted, like frac_rocprof, only when that pass was measured on the build that is loaded (tbnn_build_id), else null.
 cpu_baseline: the oracle's C restatement (oracle/c, kind "port") timed on the host cores on a bounded sample of the
 same workload from the same state (rank 0, N = 1 only, outside the timed GPU region): best thread count of a short
 scan, a 1-thread figure, and a PyTorch-CPU value+grad cross-check (oracle/torch_ref.py).
@@ -146,14 +146,32 @@ def cpu_baseline(name, wl, X, Y, theta, eta, eps, P):
     return out
 
 
-def rocprof_kernel_us(name):
-    """(mean duration in us of the fused pass's kernels by rocprofv3 --kernel-trace --stats, the tracked CSV it comes from)
-    from profiles/rocprof_kernel_us.json (written by tools/rocprof_summary.py from the round's committed CSVs), or (None, None)"""
+def committed_profile(name, build_id, profiles_dir=None):
+    """What the committed rocprofv3 summaries under profiles/ say about workload `name` -- but only when they were measured on THIS
+    build: rocprof_kernel_us.json / pmc_traffic.json carry the tbnn_build_id() of the library that was profiled
+    (tools/rocprof_summary.py), and a kernel changed without re-profiling must not be quoted with the old kernel's numbers.
+    Returns {"kernel_us", "source", "traffic", "match", "profiled_build"}; kernel_us / traffic are None on a mismatch."""
+    d = profiles_dir or os.path.join(ROOT, "profiles")
+    key = "c5" if name == "c5g" else name               # (c5g: configs[4]'s kernels on other priors)
+    out = {"kernel_us": None, "source": None, "traffic": None, "match": False, "profiled_build": None}
     try:
-        e = json.load(open(os.path.join(ROOT, "profiles", "rocprof_kernel_us.json")))["c5" if name == "c5g" else name]
-        return float(e["us"]), e["source"]
+        ku = json.load(open(os.path.join(d, "rocprof_kernel_us.json")))
     except Exception:
-        return None, None
+        return out
+    out["profiled_build"] = (ku.get("_build") or {}).get("build_id")
+    out["match"] = bool(build_id) and out["profiled_build"] == build_id
+    if not out["match"]:
+        return out
+    e = ku.get(key)
+    if e:
+        out["kernel_us"], out["source"] = float(e["us"]), e["source"]
+    try:
+        tj = json.load(open(os.path.join(d, "pmc_traffic.json")))
+        if (tj.get("_build") or {}).get("build_id") == build_id:
+            out["traffic"] = tj.get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return out
 
 
 def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
@@ -301,23 +319,17 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
     if rank != 0:
         return None
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = "c5" if name == "c5g" else name          # (c5g: configs[4]'s kernels on other priors)
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    prof_c = committed_profile(name, nat.build_id())
+    traffic = prof_c["traffic"]
     roofline = None
     if k_us and name != "c1":
         achieved = flops / (k_us * 1e-6) / 1e12
-        rp_us, rp_src = rocprof_kernel_us(name)
+        rp_us, rp_src = prof_c["kernel_us"], prof_c["source"]
         roofline = {"bound": "mfma", "kernel": kernel_name, "achieved": round(achieved, 3),
                     "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4),
                     "frac_rocprof": round(flops / (rp_us * 1e-6) / 1e12 / PEAK_TFLOPS, 4) if rp_us else None,
                     "rocprof_kernel_us": rp_us, "rocprof_source": rp_src,
+                    "profile_build_match": prof_c["match"], "build_id": nat.build_id(), "profiled_build": prof_c["profiled_build"],
                     "traffic": traffic, "kernel_us": round(k_us, 2), "flop_per_launch": flops,
                     "hbm_gbps_algorithmic": round((4.0 * N_ROWS * (DIMS[0] + DIMS[-1]) + 12.0 * P) / (k_us * 1e-6) / 1e9, 2),
                     "end_to_end_frac": round(value / world * flops / 1e12 / PEAK_TFLOPS, 4)}
@@ -359,8 +371,8 @@ def _short_cpu(c):
 def _short_roof(r):
     if not r:
         return None
-    keep = ("bound", "achieved", "peak", "unit", "frac", "frac_rocprof", "rocprof_source", "traffic", "kernel_us",
-            "end_to_end_frac")          # ("kernel" is config.kernel: not repeated on the short line)
+    keep = ("bound", "achieved", "peak", "unit", "frac", "frac_rocprof", "rocprof_source", "profile_build_match", "traffic",
+            "kernel_us", "end_to_end_frac")          # ("kernel" is config.kernel: not repeated on the short line)
     out = {k: r[k] for k in keep if k in r}
     if "launch latency" in str(out.get("bound", "")):
         out["bound"] = "launch latency"

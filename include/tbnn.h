@@ -87,6 +87,10 @@ typedef struct tbnn_ctx* tbnn_handle;
 
 const char* tbnn_last_error(void);
 int tbnn_abi_version(void);
+/* hash of the sources (kernel headers, translation units, this header, compiler flags) the loaded library was built from;
+ * profiles/rocprof_kernel_us.json and pmc_traffic.json carry the id of the library they were measured on, and bench.py
+ * quotes them only when it matches */
+const char* tbnn_build_id(void);
 /* number of visible HIP devices (<0: error) */
 int tbnn_device_count(void);
 
@@ -179,6 +183,14 @@ int tbnn_forward_many(tbnn_handle h, const float* thetas, int32_t m, int64_t the
  *   out3[2] = mean |r - round(p)|     1 - Accuracy */
 int tbnn_metrics(tbnn_handle h, int which, const float* theta, float mean, float sd, int exp_pred, int exp_real,
                  double out3[3]);
+
+/* predictor.trainProbs / reweight (predictor.py:157-273): for m saved networks, the sum over the dense
+ * layers of calculateHyperProbs(hypers, tensors) (layer.py:199-242, :379-422) in ONE launch (one workgroup per network).
+ * theta_i = thetas + i * theta_stride (>= P floats), eta_i = etas + i * eta_stride (>= 4 * layers floats: loc_w, g_w, loc_b,
+ * g_b per dense layer); priors: `layers` TBNN_PRIOR_* values to judge the layers under (reweight loads another architecture)
+ * or NULL = the chain's own.  out: m doubles (sums in fp64). */
+int tbnn_hyper_probs_many(tbnn_handle h, const int32_t* priors, const float* thetas, int64_t theta_stride,
+                          const float* etas, int64_t eta_stride, int32_t m, double* out);
 
 /* ---- kernels for shapes outside the ahead-of-time registries.  The shape-specialised MFMA kernels are
  * C++ templates; tensorbnn_amd/jit.py instantiates them for a given network with hipcc at run time

@@ -54,6 +54,7 @@ _H = C.c_void_p
 SYMBOLS = [
     ("tbnn_last_error", C.c_char_p, []),
     ("tbnn_abi_version", C.c_int, []),
+    ("tbnn_build_id", C.c_char_p, []),
     ("tbnn_device_count", C.c_int, []),
     ("tbnn_create", C.c_int, [C.POINTER(NetDesc), C.c_int, C.c_uint64, C.c_uint32, C.POINTER(_H)]),
     ("tbnn_destroy", C.c_int, [_H]),
@@ -81,6 +82,7 @@ SYMBOLS = [
     ("tbnn_predict", C.c_int, [_H, C.c_int, _fp, _fp]),
     ("tbnn_forward_many", C.c_int, [_H, _fp, C.c_int32, C.c_int64, C.c_int, _fp, C.c_int64, _fp]),
     ("tbnn_metrics", C.c_int, [_H, C.c_int, _fp, C.c_float, C.c_float, C.c_int, C.c_int, _dp]),
+    ("tbnn_hyper_probs_many", C.c_int, [_H, C.POINTER(C.c_int32), _fp, C.c_int64, _fp, C.c_int64, C.c_int32, _dp]),
     ("tbnn_register_kernel_lib", C.c_int, [C.c_char_p]),
     ("tbnn_fused_kernel_available", C.c_int, [C.POINTER(NetDesc)]),
     ("tbnn_comm_unique_id", C.c_int, [C.POINTER(C.c_ubyte)]),
@@ -125,6 +127,11 @@ def _f32(a) -> np.ndarray:
 
 def _p(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(_fp)
+
+
+def build_id() -> str:
+    """hash of the sources the loaded libtbnn.so was built from (tbnn_build_id)"""
+    return lib.tbnn_build_id().decode()
 
 
 def device_count() -> int:
@@ -298,6 +305,19 @@ class Chain:
             n = xp.shape[0]
         out = np.empty((th.shape[0], self.d_out, n), dtype=np.float32)
         _check(lib.tbnn_forward_many(self._h, _p(th), th.shape[0], th.shape[1], int(which), _p(xp), n, _p(out)))
+        return out
+
+    def hyper_probs_many(self, thetas, etas, priors=None) -> np.ndarray:
+        """sum over the dense layers of calculateHyperProbs for m saved networks (predictor.trainProbs / reweight):
+        thetas [m, P], etas [m, >= 4 * layers], priors: one PRIOR_* per dense layer or None (the chain's) -> float64 [m]"""
+        th = np.ascontiguousarray(thetas, dtype=np.float32)
+        et = np.ascontiguousarray(etas, dtype=np.float32)
+        if th.ndim != 2 or th.shape[1] != self.P or et.ndim != 2 or et.shape[0] != th.shape[0]:
+            raise ValueError(f"thetas must be [m, {self.P}] and etas [m, >= 4 * layers]")
+        pr = None if priors is None else (C.c_int32 * len(priors))(*[int(x) for x in priors])
+        out = np.empty(th.shape[0], dtype=np.float64)
+        _check(lib.tbnn_hyper_probs_many(self._h, pr, _p(th), th.shape[1], _p(et), et.shape[1], th.shape[0],
+                                         out.ctypes.data_as(_dp)))
         return out
 
     def metrics(self, which: int = 0, theta=None, mean: float = 0.0, sd: float = 1.0, exp_pred: bool = False,

@@ -5,7 +5,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", "tbnn_api.hip"), os.path.join(HERE, "csrc", "tbnn_wide.hip"),
-       os.path.join(HERE, "csrc", "tbnn_mid.hip"), os.path.join(HERE, "csrc", "adapter.cpp")]
+       os.path.join(HERE, "csrc", "tbnn_mid.hip"), os.path.join(HERE, "csrc", "tbnn_tall.hip"),
+       os.path.join(HERE, "csrc", "adapter.cpp")]
 # both kernel families: the chain MFMAs write ArchVGPRs (their results feed the VALU), dW accumulators are pinned to
 # AccVGPRs by hand (kernels_fast.hpp, mfma16_acc)
 NARROW_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
@@ -13,7 +14,8 @@ PER_SOURCE_FLAGS = {"tbnn_api.hip": NARROW_FLAGS,
                     # experiments: TBNN_WIDE_FLAGS adds flags to the wide translation unit, TBNN_WIDE_AGPR_FORM=1 drops the VGPR form there
                     "tbnn_wide.hip": ([] if os.environ.get("TBNN_WIDE_AGPR_FORM") == "1" else NARROW_FLAGS)
                                      + os.environ.get("TBNN_WIDE_FLAGS", "").split(),
-                    "tbnn_mid.hip": NARROW_FLAGS + os.environ.get("TBNN_MID_FLAGS", "").split()}
+                    "tbnn_mid.hip": NARROW_FLAGS + os.environ.get("TBNN_MID_FLAGS", "").split(),
+                    "tbnn_tall.hip": NARROW_FLAGS + os.environ.get("TBNN_TALL_FLAGS", "").split()}
 # TBNN_BUILD_TAG=<tag>: a diagnostic variant (TBNN_EXTRA_FLAGS / TBNN_*_FLAGS) built side by side as libtbnn_<tag>.so with its
 # own object directory; load it with TBNN_LIB=<path>
 _TAG = os.environ.get("TBNN_BUILD_TAG", "")
@@ -29,26 +31,46 @@ def _deps():
     return d
 
 
+def sources_id(flags=()) -> str:
+    """sha256 over everything the library is compiled from (and how): csrc/*, include/tbnn.h, the compiler flags"""
+    import hashlib
+    hsh = hashlib.sha256()
+    cs = os.path.join(HERE, "csrc")
+    for f in sorted(os.listdir(cs)):
+        if f.endswith((".hpp", ".hip", ".cpp")):
+            hsh.update(f.encode()); hsh.update(open(os.path.join(cs, f), "rb").read())
+    hsh.update(open(os.path.join(HERE, "..", "include", "tbnn.h"), "rb").read())
+    hsh.update(repr((list(flags), sorted(PER_SOURCE_FLAGS.items()))).encode())
+    return hsh.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in _deps()):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value", "-Wno-unused-result"]
     flags += os.environ.get("TBNN_EXTRA_FLAGS", "").split()      # diagnostic builds (-DWIDE_DBG_...)
+    bid = sources_id(flags)
     os.makedirs(OBJ_DIR, exist_ok=True)
     # one hipcc per translation unit, side by side (the two kernel families take ~1 min each)
     procs, objs = [], []
     for src in SRC:
         obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
         cmd = [hipcc] + flags + PER_SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        if os.path.basename(src) == "tbnn_api.hip":
+            cmd.insert(1, f'-DTBNN_BUILD_ID="{bid}"')
         if src.endswith(".hip"):
             cmd[1:1] = ["-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics"]   # per-kernel register / scratch remarks on stderr
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+        # stderr to a file per compile: the resource-usage remarks of dozens of kernels overflow a pipe, and a compiler blocked on
+        # a full pipe until its turn to be drained would serialise the side-by-side build
+        errf = open(obj + ".stderr", "w+")
+        procs.append((cmd, subprocess.Popen(cmd, stderr=errf, text=True), errf))
         objs.append(obj)
-    for cmd, p in procs:
-        _, err = p.communicate()
+    for cmd, p, errf in procs:
+        p.wait()
+        errf.seek(0); err = errf.read(); errf.close()
         remarks = [l for l in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l]
         other = [l for l in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l and not l.startswith("In file included from")
                  and "warnings generated" not in l and "warning generated" not in l]

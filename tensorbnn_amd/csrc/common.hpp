@@ -44,6 +44,17 @@ __device__ __forceinline__ void slab_store(float* ptr, float val) {
     else *ptr = val;
 }
 
+// 16 bytes of a slab / stored block at once, write-through: one `global_store_dwordx4 ... sc1` (a 4-byte sc1 store is one fabric
+// write per lane: ~6x the time per byte of the 16-byte form, MI355X_MICROARCH.md).  The compiler's hazard recognizer does not see
+// an inline-asm store as a VMEM store and would not keep a following VALU write off the store-data VGPRs (2 wait states on a
+// > 64-bit store): the s_nop inside the statement provides them whatever the register allocation.
+typedef float tb_f32x4 __attribute__((ext_vector_type(4)));
+template <bool WT>
+__device__ __forceinline__ void store16(float* ptr, const tb_f32x4& v) {
+    if constexpr (WT && TBNN_SLAB_NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(ptr), "v"(v) : "memory");
+    else *reinterpret_cast<tb_f32x4*>(ptr) = v;
+}
+
 // Per-chain scalar record kept on the device (doubles: energies are summed
 // and differenced in fp64 -- strictly more accurate than the reference's fp32).
 struct Scal {

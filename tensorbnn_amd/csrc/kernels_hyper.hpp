@@ -320,3 +320,39 @@ __global__ __launch_bounds__(HYP_THREADS) void k_hyper(
     __syncthreads();
     if (sh_acc != 0 && tid < H) eta[tid] = e[tid];
 }
+
+// ---- predictor.trainProbs / reweight (predictor.py:157-273): the sum over the dense layers of calculateHyperProbs
+// (layer.py:199-242 Cauchy, :379-422 Gaussian) for m SAVED networks in one launch -- blockIdx.x = network, theta_i and eta_i
+// strided; nd.prior[] is the prior family the CALLER wants each layer judged under (reweight loads another architecture).
+// The value hyper_finish computes per group, without the data term and without the gradient; sums in double.
+__global__ __launch_bounds__(256) void k_hyper_probs(NetDev nd, const float* __restrict__ thetas, long theta_stride,
+                                                     const float* __restrict__ etas, long eta_stride, double* __restrict__ out)
+{
+    __shared__ double red[4];
+    const float* q = thetas + (size_t)blockIdx.x * theta_stride;
+    const float* e = etas + (size_t)blockIdx.x * eta_stride;
+    double total = 0.0;                                          // thread 0's
+    for (int grp = 0; grp < 2 * nd.nl; ++grp) {
+        const HypGroup G = hyp_group(nd, grp);
+        const float loc = e[4 * G.l + 2 * G.part];
+        const float gg = e[4 * G.l + 2 * G.part + 1];
+        const float inv_scale = 1.f / (gg * gg);                 // layer.py:209-212 (Q3)
+        const bool cauchy = nd.prior[G.l] == TBNN_PRIOR_CAUCHY;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int i = threadIdx.x; i < G.cnt; i += blockDim.x) hyp_term<double>(cauchy, q[G.off + i], loc, inv_scale, a0, a1, a2);
+        const double s0 = block_sum(a0, red);
+        const double s2 = block_sum(a2, red);
+        if (threadIdx.x == 0) {
+            const double scale = (double)(float)(gg * gg), cnt = (double)G.cnt;
+            if (cauchy) {
+                total += mvn1_logp((double)loc, 0.0, 0.2) + mvn1_logp(scale, 0.70710678118654757, 0.5);      // layer.py:221-228
+                total += s0 - cnt * log(3.14159265358979323846 * scale);                                     // sum cauchyLogProb (Q1)
+            } else {
+                total += mvn1_logp((double)loc, 0.0, 0.1) + mvn1_logp(scale, 1.0, 0.1);                      // layer.py:401-408
+                const double s = fmin(fmax(scale, 1e-8), 1e8);
+                total += -0.5 * (2.0 * log(s) + s2 / (s * s) + 1.8378770664093453);                           // Q2: k = 1
+            }
+        }
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = total;
+}

@@ -59,7 +59,9 @@ struct LayPlan {
 #endif
 __device__ __forceinline__ void lay_block_store(float* p, const f32x4& v) {
 #if LAY_ST_POLICY == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+    // (the s_nop: wait states between this > 64-bit store and a VALU write of its data registers, which the compiler's hazard
+    // recognizer does not insert behind inline asm)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 #else
     *reinterpret_cast<f32x4*>(p) = v;
 #endif

@@ -81,6 +81,11 @@ __host__ __device__ constexpr int mid_ops_before(int j, int N1, int NE, int NMF)
 #ifndef MID_WPAD
 #define MID_WPAD 4
 #endif
+// layer-0 fan-in: the rows of a tile and the next tile's prefetched copy live in registers (2 x 4 x ceil(d_in / 16) VGPRs);
+// above this the tall family (kernels_tall.hpp) splits the fan-in over the waves of a workgroup
+#ifndef MID_MAX_FANIN
+#define MID_MAX_FANIN 128
+#endif
 // diagnostic build only (-DMID_STAMPS): shader-clock stamps of workgroup 0 / wave 0 during its SECOND tile
 #ifdef MID_STAMPS
 __device__ unsigned long long g_mid_stamps[64];
@@ -101,7 +106,7 @@ struct MidCfg {
     static constexpr int LL = NL - 1;                 // last layer (VALU)
     static constexpr int d_in = in(0), d_out = out(LL);
     static_assert(d_out <= 2, "last layer runs on the VALU (<= 2 outputs)");
-    static_assert(d_in <= 32, "layer-0 fan-in above 32 is not laid out");
+    static_assert(d_in <= MID_MAX_FANIN, "layer-0 fan-in: x and its prefetch copy live in registers");
     // a_l = input of layer l (l = 1..LL) in the padded slot order of kernels_fast.hpp (slot_of / unit_of / ones_slot)
     static constexpr int TR(int l) { return cdiv(in(l), 16); }          // register tiles (real units)
     static constexpr int TA(int l) { return cdiv(in(l) + 1, 16); }      // block tiles (with the ones slot)

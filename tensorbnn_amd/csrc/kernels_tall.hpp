@@ -1,0 +1,568 @@
+// k_fwd_bwd_tall: the fused forward + likelihood + backward pass for networks with a LONG first-layer fan-in and narrow
+// hidden layers -- the reference's own classification tutorial, 784 -> 20 -> 20 -> 1 on MNIST pixels
+// (docs/ClassificationExample.md:103-173), is the type: dW_0 alone is 2 x 50 tiles, more than one wave's accumulator file,
+// and the rows (3 KB each) are what the pass streams.  Until round 4 such shapes ran on the layered family (five launches,
+// the rows read twice per gradient).
+//
+// One WORKGROUP = one 16-row tile; the fan-in is split over its four waves (wave w owns the column tiles
+// [w CH, (w+1) CH) of the rows, of W_0 and of dW_0):
+//   * W_0's chunk lives in the wave's REGISTERS for the whole launch, as MFMA A operands (MT0 x CH x 4 VGPRs), fetched once
+//     from the padded image k_update maintains; the chunk of dW_0 in the wave's AccVGPRs (the same count);
+//   * a row tile: every wave multiplies its chunk of the rows (16-B loads: lane (row, g) holds columns 16kt+4g .. +3, which
+//     is the MFMA B operand as it stands) into partial pre-activations, the four partials meet in an LDS exchange buffer
+//     (ONE barrier per tile, two alternating buffers), every wave sums them in the same fixed order and then runs the narrow
+//     rest of the network -- middle layers on MFMAs with the weights in LDS, the <= 2-output last layer on the VALU, the
+//     likelihood and the delta chain -- REDUNDANTLY: it is small next to layer 0, and every wave ends up holding delta_0
+//     for its own chunk of dW_0 without a second exchange;
+//   * the gradient of the narrow layers is shared out without a branch: a dW tile is a sum over the tile's four k-steps
+//     (rows 4s .. 4s+3), wave w contributes k-step w only (its operand address is 64 w + lane); the last layer's per-lane
+//     sums take the rows with (row & 3) == w.  The epilogue's fixed-order sum over the four waves -- the one every fused
+//     family has -- puts the pieces together;
+//   * dW_0 += delta_0^T [x, 1]: both operands through per-wave LDS blocks [16 rows][16 slots] (written as the registers
+//     stand, read lane-linearly), as in kernels_mid.hpp; every wave writes its own column chunk of the slab itself.
+// Launch signature, slab layout and FusedOps family are the narrow family's (one gradient slab per workgroup, k_update
+// reduces).  The rows are read ONCE per gradient.
+//
+// Reference math: layer.py:278 (W@a+b), activationFunctions.py:36/49/62, likelihood.py:88-94,226-236,
+// BNN_functions.py:23-32; reverse mode SURVEY A12; the path: network.py:394-408.
+#pragma once
+#include "kernels_mid.hpp"
+
+// Waves per workgroup = ways the fan-in is split: four, one per SIMD.  (Eight -- two per SIMD, 256 registers each, all
+// accumulators in ArchVGPRs because the compiler halves a wave's budget as soon as one AccVGPR is asked for -- was built and
+// measured in round 4: 784 -> 20 -> 20 -> 1 at 12,000 rows 29.2 us against 28.4 us.  The two waves of a SIMD run the same program
+// in lockstep between the per-tile barriers, so one's serial stretch does not run under the other's MFMA blocks, and the
+// redundant narrow layers double.  Not kept.)
+template <class S, int NW_ = 4>
+struct TallCfg {
+    static constexpr int NW = NW_;
+    static_assert(NW == 4, "four waves per workgroup");
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int NL = S::NL;
+    static_assert(NL >= 2, "the tall path needs a hidden layer");
+    static constexpr int in(int l) { return S::D[l]; }
+    static constexpr int out(int l) { return S::D[l + 1]; }
+    static constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+    static constexpr int r4(int a) { return (a + 3) & ~3; }
+    static constexpr int NM = NL - 2;                 // middle layers 1 .. NM (MFMA, weights in LDS)
+    static constexpr int LL = NL - 1;                 // last layer (VALU)
+    static constexpr int d_in = in(0), d_out = out(LL);
+    static_assert(d_out <= 2, "last layer runs on the VALU (<= 2 outputs)");
+    static constexpr int TR(int l) { return cdiv(in(l), 16); }          // register tiles of a_l (l >= 1: slot order of kernels_fast.hpp)
+    static constexpr int TA(int l) { return cdiv(in(l) + 1, 16); }      // block tiles of a_l (with the ones slot)
+    static constexpr int ksteps(int K, int kg) { int rem = K - 16 * kg; return rem >= 16 ? 4 : (rem <= 0 ? 0 : (rem + 3) / 4); }
+    static constexpr int KG(int K) { return cdiv(K, 16); }
+    static constexpr int maxT() { int m = 0; for (int l = 1; l <= LL; ++l) m = TR(l) > m ? TR(l) : m; return m; }
+    static constexpr int MAXT = maxT();
+    // layer 0: the rows' columns in their own order (slot = column, the ones slot at column d_in), split over the waves
+    static constexpr int MT0 = TR(1);
+    static constexpr int NT0 = cdiv(d_in + 1, 16);                      // column tiles of [x, 1]
+    static constexpr int CH = cdiv(NT0, NW);                            // column tiles per wave
+    static constexpr int NTP = NW * CH;                         // padded tile count of the W_0 image
+    static constexpr bool ALIGNED = d_in % 4 == 0;                      // rows are 16-B aligned: one load per lane and tile
+    // dW accumulator tiles of the middle layers (layer l: TR(l+1) x TA(l)); dW_0: MT0 x CH per wave
+    static constexpr int dwt(int l) { return TR(l + 1) * TA(l); }
+    static constexpr int dwoff(int l) { int o = 0; for (int m = 1; m < l; ++m) o += dwt(m); return o; }
+    static constexpr int DWM_TILES = dwoff(NM + 1);
+    // ---- weight image in HBM (k_update scatters theta into it through image_map)
+    //   W_0: MFMA A-operand granules [M tile][column tile (NTP)][lane (i, g)][s]: lane holds W_0[slot 16t+i][column 16kt+4g+s]
+    //   then the part that is copied to LDS: biases 0..NM in slot order, W_LL [d_out][16 TR(LL)], b_LL, the middle layers
+    //   row-major [16 TR(l+1) out slots][LDM(l)] (pitch == 4 mod 8: the strided W^T reads of the delta chain are conflict-free)
+    static constexpr int W0_FLOATS = MT0 * NTP * 256;
+    static constexpr int boff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += 16 * TR(m + 1); return o; }   // in the LDS part
+    static constexpr int WLP = 16 * TR(LL);
+    static constexpr int WL_OFF = boff(NM + 1);
+    static constexpr int BL_OFF = WL_OFF + d_out * WLP;
+    static constexpr int PERM_FLOATS = r4(BL_OFF + d_out);
+    static constexpr int LDM(int l) { return 16 * TR(l) + MID_WPAD; }
+    static constexpr int wmoff(int l) { int o = PERM_FLOATS; for (int m = 1; m < l; ++m) o += 16 * TR(m + 1) * LDM(m); return o; }
+    static constexpr int SMALL_FLOATS = r4(wmoff(NM + 1));              // the LDS-resident part
+    static constexpr int IMG_FLOATS = W0_FLOATS + SMALL_FLOATS;
+    // ---- LDS: [small image][exchange: 2 buffers x 4 waves x MT0 tiles x 64 lanes x 4][per wave: blocks of 256 floats]
+    static constexpr int EX_OFF = SMALL_FLOATS;
+    static constexpr int EX_FLOATS = 2 * NW * MT0 * 256;
+    static constexpr int XB_OFF = 0;                                                              // x (+ ones slot): CH blocks
+    static constexpr int aboff(int l) { int o = XB_OFF + CH * 256; for (int m = 1; m < l; ++m) o += TA(m) * 256; return o; }   // a_l, l = 1..NM
+    static constexpr int dboff(int l) { int o = aboff(NM + 1); for (int m = 0; m < l; ++m) o += TR(m + 1) * 256; return o; }   // delta_l, l = 0..NM
+    static constexpr int WAVE_FLOATS = dboff(NM + 1);
+    static constexpr int WAVE_OFF = EX_OFF + EX_FLOATS;
+    static constexpr int LDS_MAIN = WAVE_OFF + NW * WAVE_FLOATS;
+    // epilogue staging of the middle layers' dW tiles ([wave][tile][lane] x 16 B) and of the last layer's sums
+    static constexpr int EP_FLOATS = NW * (DWM_TILES > 0 ? DWM_TILES : 1) * 256;
+    static constexpr int LL_FLOATS = NW * d_out * (16 * TR(LL) + 1);
+    static constexpr int LDS_FLOATS = LDS_MAIN > EP_FLOATS ? (LDS_MAIN > LL_FLOATS ? LDS_MAIN : LL_FLOATS) : (EP_FLOATS > LL_FLOATS ? EP_FLOATS : LL_FLOATS);
+    // ---- parameters
+    static constexpr int offW(int l) { int p = 0; for (int m = 0; m < l; ++m) p += in(m) * out(m) + out(m); return p; }
+    static constexpr int P() { return offW(NL); }
+    static constexpr bool LDS_OK = LDS_FLOATS * 4 + 64 <= 160 * 1024;
+    // a wave's registers, roughly: its chunks of W_0 and dW_0, the rows' chunk, the narrow layers' accumulators + working set
+    static constexpr int REG_EST = 2 * 4 * MT0 * CH + 4 * CH + 4 * DWM_TILES + 4 * d_out * TR(LL) + 12 * MAXT + 48;
+};
+template <class S> struct TallPick { static constexpr int NW = 4; };
+
+template <class S, int NW>
+struct TallLast {              // per-lane partial sums of the VALU last layer's dW / db
+    using C = TallCfg<S, NW>;
+    f32x4 acc[C::d_out][C::TR(C::LL)];
+    float accb[C::d_out];
+};
+
+// FWD: forward pass only (network.predict, network.py:141-171; predictor.py:132-155 with blockIdx.y = network)
+template <class S, int NW, bool FWD = false>
+__global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_fwd_bwd_tall(
+    NetDev nd, const float* __restrict__ qimgs, long img_stride, const float* __restrict__ eta,
+    const float* __restrict__ X, const float* __restrict__ Y, long n,
+    float* __restrict__ slabs, int pitch, double* __restrict__ pstat, float* __restrict__ fouts, long out_stride)
+{
+    using C = TallCfg<S, NW>;
+    static_assert(C::LDS_OK, "LDS budget");
+    constexpr int TALL_WAVES = NW, TALL_THREADS = 64 * NW;
+    constexpr bool ACC_A = true;       // accumulators pinned to AccVGPRs by asm MFMAs (as in kernels_mid.hpp)
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+    __shared__ double red[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+    constexpr int d_in = C::d_in, d_out = C::d_out, NM = C::NM, LL = C::LL, MT0 = C::MT0, CH = C::CH;
+    const float* qimg = qimgs + (size_t)blockIdx.y * img_stride;
+    float* fout = FWD ? fouts + (size_t)blockIdx.y * out_stride : nullptr;
+    const long ntiles = (n + 15) / 16;
+    const int kt0 = wave * CH;                          // first column tile of this wave
+
+    // the rows of a tile, this wave's columns: lane (row i16, g) holds columns 16 (kt0 + c) + 4g .. +3.  16-B aligned rows: one
+    // buffer load per lane and column tile through a resource that covers exactly the tile's valid rows (rows past n and tiles
+    // past the end read as zeros: no branch, no 64-bit address per load; the column tile is the instruction's immediate offset);
+    // fix() zeroes the columns past d_in (which lie in range: the next row) and sets the ones slot when the values are used
+    const int vbase = i16 * (d_in * 4) + 64 * kt0 + 16 * g;
+    auto fetch = [&](long tile, f32x4 (&xv)[CH]) __attribute__((always_inline)) {
+        if constexpr (C::ALIGNED) {
+            const bool in = tile < ntiles;
+            const long left = n - tile * 16;
+            const int rows = in ? (int)(left < 16 ? left : 16) : 0;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X) + (in ? tile : 0) * 16 * d_in, 0, rows * d_in * 4, 0x00020000);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) xv[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vbase, 64 * c, 0));
+        } else {
+            const long row = tile * 16 + i16;
+            const bool ok = tile < ntiles && row < n;
+            const float* xr = X + row * d_in;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int col0 = 16 * (kt0 + c) + 4 * g;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) if (ok && col0 + s < d_in) v[s] = xr[col0 + s];
+                xv[c] = v;
+            }
+        }
+    };
+    auto fix = [&](f32x4 v, int c) __attribute__((always_inline)) {
+        if (16 * (kt0 + c) + 16 > d_in) {              // wave-uniform: only the column tile(s) at and behind the end of the rows
+            const int col0 = 16 * (kt0 + c) + 4 * g;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = col0 + s < d_in ? v[s] : (col0 + s == d_in ? 1.f : 0.f);
+        }
+        return v;
+    };
+    f32x4 xn[CH];
+    long tile = blockIdx.x;
+    fetch(tile, xn);
+
+    // ---- prologue: this wave's chunk of W_0 -> registers; the small image -> LDS; the per-wave blocks zeroed
+    f32x4 Wr[MT0][CH];
+    {
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(qimg);
+#pragma unroll
+        for (int t = 0; t < MT0; ++t)
+#pragma unroll
+#ifdef TALL_DBG_NOPRO          // diagnostic build: what the W_0 chunk's loads cost
+            for (int c = 0; c < CH; ++c) Wr[t][c] = f32x4{0.001f * lane, 0.002f, 0.003f * c, 0.004f * t};
+#else
+            for (int c = 0; c < CH; ++c) Wr[t][c] = w4[(size_t)(t * C::NTP + kt0 + c) * 64 + lane];
+#endif
+    }
+    float* wl = lds + C::WAVE_OFF + wave * C::WAVE_FLOATS;
+    {
+        constexpr int N4 = C::SMALL_FLOATS / 4;
+        const float4* src = reinterpret_cast<const float4*>(qimg + C::W0_FLOATS);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int e = tid; e < N4; e += TALL_THREADS) dst[e] = src[e];
+        float4* z = reinterpret_cast<float4*>(wl);
+        for (int e = lane; e < C::WAVE_FLOATS / 4; e += 64) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    const float sigma = FWD ? 1.f : lik_sigma(nd, eta);
+    const float inv_var = 1.f / (sigma * sigma);
+    double stat = 0.0;
+    f32x4 dW0[FWD ? 1 : MT0 * CH];
+    f32x4 dWm[(FWD || C::DWM_TILES == 0) ? 1 : C::DWM_TILES];
+#pragma unroll
+    for (int t = 0; t < (FWD ? 1 : MT0 * CH); ++t) dW0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < ((FWD || C::DWM_TILES == 0) ? 1 : C::DWM_TILES); ++t) dWm[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    TallLast<S, NW> LR;
+#pragma unroll
+    for (int o = 0; o < d_out; ++o) {
+        LR.accb[o] = 0.f;
+#pragma unroll
+        for (int t = 0; t < C::TR(LL); ++t) LR.acc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // last layer's weights, slot order: lane (r, g) holds slots 16t+4g .. +3
+    f32x4 wL[d_out][C::TR(LL)];
+#pragma unroll
+    for (int o = 0; o < d_out; ++o)
+#pragma unroll
+        for (int t = 0; t < C::TR(LL); ++t) wL[o][t] = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
+
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const bool rvalid = tile * 16 + i16 < n;
+        f32x4 x[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) x[c] = fix(xn[c], c);
+        float y[d_out];
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) y[o] = (!FWD && rvalid) ? Y[(tile * 16 + i16) * d_out + o] : 0.f;
+        if constexpr (!FWD) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) *reinterpret_cast<f32x4*>(wl + C::XB_OFF + c * 256 + i16 * 16 + 4 * g) = x[c];
+        }
+        // ---- layer 0, this wave's share of the fan-in: two accumulator sets (even / odd column tiles) keep the MFMA chain
+        // four deep (a lone pair of accumulators is revisited after 32 cycles, 8 short of the dependent latency)
+        f32x4 acc0[2][MT0];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < MT0; ++t) acc0[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < MT0; ++t) acc0[c & 1][t] = mfma16(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
+        // the next tile's rows: x's registers are free from here on, the loads land under the rest of this tile
+        fetch(tile + gridDim.x, xn);
+        {
+            f32x4* ex = reinterpret_cast<f32x4*>(lds + C::EX_OFF) + buf * (TALL_WAVES * MT0 * 64);
+#pragma unroll
+            for (int t = 0; t < MT0; ++t) ex[(wave * MT0 + t) * 64 + lane] = acc0[0][t] + acc0[1][t];
+        }
+        __syncthreads();
+        f32x4 a[C::MAXT];                  // the current layer's input a_l, D layout: tile t reg j of lane (r, g) = slot 16t+4g+j of row r
+        {
+            const f32x4* ex = reinterpret_cast<const f32x4*>(lds + C::EX_OFF) + buf * (TALL_WAVES * MT0 * 64);
+#pragma unroll
+            for (int t = 0; t < MT0; ++t) {
+                f32x4 z;
+                {
+                    const f32x4 e0 = ex[(0 * MT0 + t) * 64 + lane], e1 = ex[(1 * MT0 + t) * 64 + lane];
+                    const f32x4 e2 = ex[(2 * MT0 + t) * 64 + lane], e3 = ex[(3 * MT0 + t) * 64 + lane];
+                    z = (e0 + e1) + (e2 + e3);
+                }
+                const f32x4 b = *reinterpret_cast<const f32x4*>(lds + C::boff(0) + 16 * t + 4 * g);
+                z = b + z;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[t][r] = actc_fwd<S::act(0)>(z[r]);
+            }
+        }
+
+        // ---- middle layers, forward (every wave, redundantly): a_l -> a_{l+1}; a_l (+ ones slot) to its blocks for dW_l / act'
+        sfor<1, NM + 1>(SFOR_LAMBDA(l) {
+            constexpr int l = SFOR_VAL(l);
+            if constexpr (!FWD) {
+#pragma unroll
+                for (int t = 0; t < C::TA(l); ++t) {
+                    f32x4 v = t < C::TR(l) ? a[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    constexpr int os = ones_slot(C::in(l));
+                    if (t == os / 16 && g == (os % 16) / 4) v[os % 4] = 1.f;
+                    *reinterpret_cast<f32x4*>(wl + C::aboff(l) + t * 256 + i16 * 16 + 4 * g) = v;
+                }
+            }
+            constexpr int MT = C::TR(l + 1), K = C::in(l), KGn = C::KG(K);
+            f32x4 acc[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * t + 4 * g);
+            const float* wrow = lds + C::wmoff(l) + i16 * C::LDM(l) + 4 * g;
+            sfor<0, KGn>(SFOR_LAMBDA(kg) {
+                constexpr int kg = SFOR_VAL(kg);
+                f32x4 A[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) A[t] = load_ks(wrow + 16 * t * C::LDM(l) + 16 * kg, C::ksteps(K, kg));
+#pragma unroll
+                for (int s = 0; s < C::ksteps(K, kg); ++s)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[t] = mfma16(A[t][s], a[kg][s], acc[t]);
+            });
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[t][r] = actc_fwd<S::HACT>(acc[t][r]);
+        });
+
+        // ---- last layer on the VALU: f_o = b_o + sum_u W[o][u] a_LL[u]
+        constexpr int TP = C::TR(LL);
+        float dzl[d_out];
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) {
+            float p = 0.f;
+#pragma unroll
+            for (int t = 0; t < TP; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p = fmaf(wL[o][t][r], a[t][r], p);
+            const float fi = actc_fwd<S::LACT>(lane_group_sum(p) + lds[C::BL_OFF + o]);
+            if constexpr (FWD) {
+                if (rvalid && g == 0 && wave == 0) fout[(size_t)o * n + tile * 16 + i16] = fi;      // [d_out][n]
+                dzl[o] = 0.f;
+            } else {
+                dzl[o] = rvalid ? lik_delta<S>(fi, y[o], inv_var, g == 0 && wave == 0, stat) : 0.f;
+            }
+        }
+        if constexpr (!FWD) {
+        f32x4 dz[C::MAXT];
+        {
+            // the last layer's dW / db sums take the rows with (row & (NW - 1)) == wave; delta_{LL-1} = (W_LL^T dz_LL) * act'(a_LL)
+            const bool mine = (i16 & (NW - 1)) == wave;
+#pragma unroll
+            for (int o = 0; o < d_out; ++o) {
+                const float dm = mine ? dzl[o] : 0.f;
+                LR.accb[o] += dm;
+#pragma unroll
+                for (int t = 0; t < TP; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) LR.acc[o][t][r] = fmaf(dm, a[t][r], LR.acc[o][t][r]);
+            }
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < d_out; ++o)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d[r] = fmaf(wL[o][t][r], dzl[o], d[r]);
+                dz[t] = actc_bwd_mul4<S::act(LL - 1), false>(d, a[t]);
+            }
+        }
+        // ---- backward through the middle layers l = NM .. 1
+        sfor<0, NM>(SFOR_LAMBDA(li) {
+            constexpr int l = NM - SFOR_VAL(li);
+            constexpr int TZ = C::TR(l + 1), TAl = C::TA(l), MU = C::TR(l), K = C::out(l), KGn = C::KG(K);
+            float* dbl = wl + C::dboff(l);
+            const float* ab = wl + C::aboff(l);
+#pragma unroll
+            for (int t = 0; t < TZ; ++t) *reinterpret_cast<f32x4*>(dbl + t * 256 + i16 * 16 + 4 * g) = dz[t];
+            // dW_l += delta_l^T [a_l, 1], this wave's k-step (rows 4 wave .. 4 wave + 3)
+            {
+                float Aop[TZ], Bop[TAl];
+#pragma unroll
+                for (int t = 0; t < TZ; ++t) Aop[t] = dbl[t * 256 + 64 * wave + lane];
+#pragma unroll
+                for (int u = 0; u < TAl; ++u) Bop[u] = ab[u * 256 + 64 * wave + lane];
+#pragma unroll
+                for (int t = 0; t < TZ; ++t)
+#pragma unroll
+                    for (int u = 0; u < TAl; ++u) mfma16_acc<ACC_A>(dWm[C::dwoff(l) + t * TAl + u], Aop[t], Bop[u]);
+            }
+            // delta_{l-1} = (W_l^T delta_l) * act'(a_l): W^T from the row-major image, strided 4-B reads
+            f32x4 acc[MU];
+#pragma unroll
+            for (int u = 0; u < MU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* wcol = lds + C::wmoff(l) + 4 * g * C::LDM(l) + i16;
+            sfor<0, KGn>(SFOR_LAMBDA(kg) {
+                constexpr int kg = SFOR_VAL(kg);
+#pragma unroll
+                for (int s = 0; s < C::ksteps(K, kg); ++s)
+#pragma unroll
+                    for (int u = 0; u < MU; ++u) acc[u] = mfma16(wcol[(16 * kg + s) * C::LDM(l) + 16 * u], dz[kg][s], acc[u]);
+            });
+#pragma unroll
+            for (int u = 0; u < MU; ++u) {
+                const f32x4 al = *reinterpret_cast<const f32x4*>(ab + u * 256 + i16 * 16 + 4 * g);
+                dz[u] = actc_bwd_mul4<S::act(l - 1), false>(acc[u], al);
+            }
+        });
+        // ---- dW_0 += delta_0^T [x, 1], this wave's column tiles
+        {
+            float* db0 = wl + C::dboff(0);
+#pragma unroll
+            for (int t = 0; t < MT0; ++t) *reinterpret_cast<f32x4*>(db0 + t * 256 + i16 * 16 + 4 * g) = dz[t];
+            const float* xb = wl + C::XB_OFF;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float Aop[MT0], Bop[CH];
+#pragma unroll
+                for (int t = 0; t < MT0; ++t) Aop[t] = db0[t * 256 + 64 * s + lane];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) Bop[c] = xb[c * 256 + 64 * s + lane];
+#pragma unroll
+                for (int t = 0; t < MT0; ++t)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) mfma16_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
+            }
+        }
+        }   // !FWD
+    }
+    if constexpr (!FWD) {
+    if constexpr (ACC_A) {
+        mfma_drain_acc(dW0);
+        if constexpr (C::DWM_TILES > 0) mfma_drain_acc(dWm);
+    }
+    float* slab = slabs + (size_t)blockIdx.x * pitch;
+    constexpr bool WT = C::P() >= 2048;
+    // ---- dW_0: every wave writes its own column tiles.  D layout: lane (n = i16, g) reg r = dW[out slot 16t+4g+r][column 16kt+n]:
+    // a lane's four registers are four ROWS of the slab.  With 16-B aligned rows the tiles of one M tile are turned through the
+    // wave's own x blocks (dead by now; written [m][n], read back lane-linearly: lane l holds row l / 4, columns 4 (l % 4) .. +3)
+    // and leave as 16-byte write-through stores -- a 4-byte sc1 store is one fabric write per lane
+    {
+        constexpr int out0 = C::out(0);
+        sfor<0, MT0>(SFOR_LAMBDA(t) {
+            constexpr int t = SFOR_VAL(t);
+            if constexpr (C::ALIGNED) {
+                float* stg = wl + C::XB_OFF;
+                sfor<0, CH>(SFOR_LAMBDA(c) {
+                    constexpr int c = SFOR_VAL(c);
+                    const f32x4 v = dW0[t * CH + c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stg[c * 256 + (4 * g + r) * 16 + i16] = v[r];
+                });
+                const int m = lane >> 2, n4 = (lane & 3) * 4;
+                const int row = unit_of(out0, 16 * t + m, false);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stg + c * 256 + 4 * lane);
+                    const int col = 16 * (kt0 + c) + n4;
+                    if (row >= 0) {
+#ifdef TALL_DBG_NOSTORE        // diagnostic build: what the dW_0 slab stores cost
+                        if (col < d_in && v[0] == 123.456f) store16<WT>(slab + row * d_in + col, v);
+#else
+                        if (col < d_in) store16<WT>(slab + row * d_in + col, v);
+#endif
+                        else if (col == d_in) slab_store<WT>(slab + d_in * out0 + row, v[0]);      // the ones column: db_0
+                    }
+                }
+            } else {
+                sfor<0, CH>(SFOR_LAMBDA(c) {
+                    constexpr int c = SFOR_VAL(c);
+                    const int col = 16 * (kt0 + c) + i16;
+                    const f32x4 v = dW0[t * CH + c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = unit_of(out0, 16 * t + 4 * g + r, false);
+                        if (row >= 0 && col <= d_in)
+                            slab_store<WT>(slab + (col < d_in ? row * d_in + col : d_in * out0 + row), v[r]);
+                    }
+                });
+            }
+        });
+    }
+    const double wtot = wave_sum(stat);
+    if (lane == 0) red[wave] = wtot;
+    // ---- middle layers: the four waves' k-step shares of every tile, summed in fixed order
+    if constexpr (C::DWM_TILES > 0) {
+        __syncthreads();                   // images / blocks are dead
+        f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::DWM_TILES * 64);
+        sfor<0, C::DWM_TILES>(SFOR_LAMBDA(t) { mine[SFOR_VAL(t) * 64 + lane] = dWm[SFOR_VAL(t)]; });
+        __syncthreads();
+        sfor<1, NM + 1>(SFOR_LAMBDA(l) {
+            constexpr int l = SFOR_VAL(l);
+            constexpr int inl = C::in(l), outl = C::out(l), MT = C::TR(l + 1), NT = C::TA(l);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int t = C::dwoff(l) + mt * NT + nt;
+                    if ((t & (TALL_WAVES - 1)) == wave) {
+                        const f32x4* src = reinterpret_cast<const f32x4*>(lds) + t * 64 + lane;
+                        const f32x4 c0 = src[0], c1 = src[C::DWM_TILES * 64], c2 = src[2 * C::DWM_TILES * 64], c3 = src[3 * C::DWM_TILES * 64];
+                        const int col = unit_of(inl, 16 * nt + i16, true);          // inl: the ones pseudo-unit (bias column)
+                        if (col >= 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = unit_of(outl, 16 * mt + 4 * g + r, false);
+                                if (row >= 0)
+                                    slab_store<WT>(slab + C::offW(l) + (col < inl ? row * inl + col : inl * outl + row), (c0[r] + c1[r]) + (c2[r] + c3[r]));
+                            }
+                        }
+                    }
+                }
+        });
+    }
+    {
+        // last layer: reduce the per-row partials over the 16 lanes of a lane group, then over the 4 waves
+        constexpr int TP = C::TR(LL), inL = C::in(LL);
+        float* lb = lds;                               // [wave][o][slot], then [wave][o] biases
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) {
+#pragma unroll
+            for (int t = 0; t < TP; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = row16_sum(LR.acc[o][t][r]);
+                    if (i16 == 0) lb[(wave * d_out + o) * (16 * TP + 1) + 16 * t + 4 * g + r] = v;
+                }
+            const float vb = row16_sum(LR.accb[o]);
+            if (lane == 0) lb[(wave * d_out + o) * (16 * TP + 1) + 16 * TP] = vb;
+        }
+        __syncthreads();
+        for (int e = tid; e < d_out * (inL + 1); e += TALL_THREADS) {
+            const int o = e / (inL + 1), u = e - o * (inL + 1);
+            const int s = u < inL ? slot_of(inL, u) : 16 * TP;
+            float v[TALL_WAVES];
+#pragma unroll
+            for (int w = 0; w < TALL_WAVES; ++w) v[w] = lb[(w * d_out + o) * (16 * TP + 1) + s];
+            slab_store<WT>(slab + C::offW(LL) + (u < inL ? o * inL + u : inL * d_out + o), (v[0] + v[1]) + (v[2] + v[3]));
+        }
+    }
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < TALL_WAVES; ++w) t += red[w];
+        pstat[blockIdx.x] = t;
+    }
+    }   // !FWD
+}
+
+// host: flat parameter index -> offset in the weight image (map[j]); no transposed copy (map[P + j] = -1)
+template <class S>
+static void tall_image_map(int* map) {
+    using C = TallCfg<S, TallPick<S>::NW>;
+    const int P = C::P();
+    for (int l = 0; l < C::NL; ++l) {
+        const int in = C::in(l), out = C::out(l), ow = C::offW(l);
+        for (int i = 0; i < out; ++i) {
+            const int ri = slot_of(out, i);
+            for (int k = 0; k < in; ++k) {
+                int m0;
+                if (l == 0) m0 = (((ri / 16) * C::NTP + k / 16) * 64 + ((k % 16) / 4) * 16 + ri % 16) * 4 + k % 4;
+                else if (l == C::LL) m0 = C::W0_FLOATS + C::WL_OFF + i * C::WLP + slot_of(in, k);
+                else m0 = C::W0_FLOATS + C::wmoff(l) + ri * C::LDM(l) + slot_of(in, k);
+                map[ow + i * in + k] = m0;
+                map[P + ow + i * in + k] = -1;
+            }
+            map[ow + in * out + i] = C::W0_FLOATS + (l == C::LL ? C::BL_OFF + i : C::boff(l) + ri);
+            map[P + ow + in * out + i] = -1;
+        }
+    }
+}
+
+// one workgroup per 16-row tile and pass; at most one workgroup per CU, the tiles dealt out evenly
+static inline int tall_grid(long n) {
+    const long ntiles = (n + 15) / 16, rounds = (ntiles + 255) / 256;
+    return (int)((ntiles + rounds - 1) / rounds);
+}
+template <class S>
+static inline int tall_launch_t(int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta, const float* X,
+                                const float* Y, long n, float* slabs, int pitch, double* pstat) {
+    constexpr int NW = TallPick<S>::NW;
+    hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, false>), dim3(grid), dim3(64 * NW), 0, st, nd, qimg, 0L, eta, X, Y, n, slabs, pitch, pstat,
+                       (float*)nullptr, 0L);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// forward only: `nets` networks (grid.y; images img_stride floats apart), fouts[net][d_out][n]
+template <class S>
+static inline int tall_forward_t(int gx, int nets, hipStream_t st, const float* qimgs, long img_stride, const float* X, long n,
+                                 float* fouts, long out_stride) {
+    NetDev nd{};
+    constexpr int NW = TallPick<S>::NW;
+    hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, true>), dim3(gx, nets), dim3(64 * NW), 0, st, nd, qimgs, img_stride, (const float*)nullptr, X,
+                       (const float*)nullptr, n, (float*)nullptr, 0, (double*)nullptr, fouts, out_stride);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -21,6 +21,7 @@
 #include "kernels_layered.hpp"
 #include "wide_api.hpp"
 #include "mid_api.hpp"
+#include "tall_api.hpp"
 #include "fused_ops.hpp"
 #include <mutex>
 
@@ -94,6 +95,12 @@ struct tbnn_ctx {
 
 extern "C" const char* tbnn_last_error(void) { return g_err.c_str(); }
 extern "C" int tbnn_abi_version(void) { return TBNN_ABI_VERSION; }
+// hash of the sources this library was built from (tensorbnn_amd/build.py: kernel headers, translation units, include/tbnn.h,
+// compiler flags): what ties a committed rocprofv3 summary under profiles/ to the library bench.py has loaded
+#ifndef TBNN_BUILD_ID
+#define TBNN_BUILD_ID "unknown"
+#endif
+extern "C" const char* tbnn_build_id(void) { return TBNN_BUILD_ID; }
 extern "C" int tbnn_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -138,6 +145,11 @@ static const FusedOps* find_jit(const NetDev& nd) {
     for (const FusedOps* o : g_jit) if (fused_ops_match(*o, nd)) return o;
     return nullptr;
 }
+// a FusedOps table for this network: a run-time registered library first, then the ahead-of-time tall-fan-in instantiations
+static const FusedOps* find_ops(const NetDev& nd) {
+    const FusedOps* o = find_jit(nd);
+    return o ? o : tall_find(nd);
+}
 extern "C" int tbnn_register_kernel_lib(const char* path) {
     if (!path) return fail(-1, "null path");
     void* lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
@@ -163,6 +175,7 @@ extern "C" int tbnn_fused_kernel_available(const tbnn_net_desc* desc) {
     if (rc) return rc;
     if (fast_lookup(nd) >= 0 || mid_lookup(nd) >= 0) return 1;
     if (wide_lookup(nd) >= 0) return 2;
+    if (tall_find(nd)) return 1;
     return find_jit(nd) ? 3 : 0;
 }
 
@@ -262,7 +275,7 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
     const bool mid_on = !(getenv("TBNN_MID") && atoi(getenv("TBNN_MID")) == 0);
     const int mid = (fid < 0 && mid_on) ? mid_lookup(nd) : -1;
     const int wid = (fid < 0 && mid < 0) ? wide_lookup(nd) : -1;
-    const FusedOps* jo = (fid < 0 && mid < 0 && wid < 0) ? find_jit(nd) : nullptr;
+    const FusedOps* jo = (fid < 0 && mid < 0 && wid < 0) ? find_ops(nd) : nullptr;
     if (want == TBNN_KERNEL_FAST && fid < 0 && mid < 0 && wid < 0 && !jo) return bail(-1, "TBNN_KERNEL_FAST requested but no specialised kernel covers this shape");
     if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && mid >= 0) {
         h->kernel = TBNN_KERNEL_FAST; h->mid_id = mid; h->kernel_name = mid_name(mid);
@@ -1137,6 +1150,44 @@ extern "C" int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const fl
             HIPCHK(hipGetLastError());
         }
     }
+    return 0;
+}
+
+// predictor.trainProbs / reweight (predictor.py:188-206, :248-266): sum over the dense layers of calculateHyperProbs for m saved
+// (theta, eta) pairs in ONE launch (grid.x = network).  priors: nl prior families to judge the layers under, or null (the chain's)
+extern "C" int tbnn_hyper_probs_many(tbnn_handle h, const int32_t* priors, const float* thetas, int64_t theta_stride,
+                                     const float* etas, int64_t eta_stride, int32_t m, double* out) {
+    NEED(h);
+    const NetDev& nd0 = h->nd;
+    if (!thetas || !etas || !out || m < 1 || theta_stride < nd0.P || eta_stride < 4 * nd0.nl)
+        return fail(-1, "hyper_probs_many: null pointer, m < 1, theta_stride < P or eta_stride < 4 * layers");
+    NetDev nd = nd0;
+    if (priors)
+        for (int l = 0; l < nd.nl; ++l) {
+            if (priors[l] != TBNN_PRIOR_CAUCHY && priors[l] != TBNN_PRIOR_GAUSSIAN) return fail(-1, "hyper_probs_many: unknown prior");
+            nd.prior[l] = priors[l];
+        }
+    HIPCHK(hipSetDevice(h->device));
+    float *dTh = nullptr, *dEt = nullptr; double* dOut = nullptr;
+    auto cleanup = [&]() { if (dTh) hipFree(dTh); if (dEt) hipFree(dEt); if (dOut) hipFree(dOut); };
+#define HP_CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(-2, hipGetErrorString(e_)); } } while (0)
+    const int chunk = (int)std::min<size_t>((size_t)m, std::max<size_t>(1, ((size_t)1 << 28) / (size_t)nd.P));      // <= 1 GiB of weights per pass
+    HP_CHK(hipMalloc(&dTh, (size_t)chunk * nd.P * sizeof(float)));
+    HP_CHK(hipMalloc(&dEt, (size_t)chunk * 4 * nd.nl * sizeof(float)));
+    HP_CHK(hipMalloc(&dOut, (size_t)chunk * sizeof(double)));
+    for (int i0 = 0; i0 < m; i0 += chunk) {
+        const int c = std::min(chunk, m - i0);
+        HP_CHK(hipMemcpy2DAsync(dTh, (size_t)nd.P * sizeof(float), thetas + (size_t)i0 * theta_stride, (size_t)theta_stride * sizeof(float),
+                                (size_t)nd.P * sizeof(float), (size_t)c, hipMemcpyHostToDevice, h->stream));
+        HP_CHK(hipMemcpy2DAsync(dEt, (size_t)4 * nd.nl * sizeof(float), etas + (size_t)i0 * eta_stride, (size_t)eta_stride * sizeof(float),
+                                (size_t)4 * nd.nl * sizeof(float), (size_t)c, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_hyper_probs, dim3(c), dim3(256), 0, h->stream, nd, (const float*)dTh, (long)nd.P, (const float*)dEt, (long)(4 * nd.nl), dOut);
+        HP_CHK(hipGetLastError());
+        HP_CHK(hipMemcpyAsync(out + i0, dOut, (size_t)c * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HP_CHK(hipStreamSynchronize(h->stream));
+    }
+#undef HP_CHK
+    cleanup();
     return 0;
 }
 

@@ -13,8 +13,11 @@ Family choice (first that compiles wins; a shape no family accepts is remembered
 runs on the layered kernels):
   * narrow (`k_fwd_bwd_fast3`, else `k_fwd_bwd_fast`): every dW accumulator in one wave's registers --
     fan-in <= 16, at most NARROW_TILES 16x16 dW tiles in total;
-  * mid (`k_fwd_bwd_mid`): >= 3 dense layers, <= 2 outputs, fan-in <= 32, at most 63 dW tiles over the MFMA
+  * mid (`k_fwd_bwd_mid`): >= 3 dense layers, <= 2 outputs, fan-in <= 128, at most 63 dW tiles over the MFMA
     layers and weight images + operand blocks within 160 KB of LDS (`mid_fits`): one fused kernel, nothing through HBM;
+  * tall (`k_fwd_bwd_tall`): a long first-layer fan-in (33 .. a few thousand columns) in front of narrow hidden layers
+    (<= 64 units), <= 2 outputs: the fan-in split over the four waves of a workgroup, W_0 and dW_0 in registers
+    (`tall_fits`) -- the reference's MNIST example 784 -> 20 -> 20 -> 1;
   * wide (`k_chain_wide` + `k_dw_wide`): >= 3 dense layers, <= 2 outputs, fan-in <= 32,
     hidden widths <= 256.
 Requirements common to both: one activation for all hidden layers; dense layers only.
@@ -31,6 +34,7 @@ NARROW_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]      # keep in step with bui
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 NARROW_TILES = 40
+MID_MAX_FANIN = 128          # keep in step with kernels_mid.hpp
 
 
 def cache_dir() -> str:
@@ -79,8 +83,10 @@ def families(dims) -> list:
         if dims[-1] <= 2 and nl >= 2:
             out.append("fast3")
         out.append("fast")
-    if nl >= 3 and dims[-1] <= 2 and dims[0] <= 32 and mid_fits(dims):
+    if nl >= 3 and dims[-1] <= 2 and dims[0] <= MID_MAX_FANIN and mid_fits(dims):
         out.append("mid")
+    if nl >= 2 and dims[-1] <= 2 and dims[0] > 32 and tall_fits(dims):
+        out.append("tall")
     if nl >= 3 and dims[-1] <= 2 and dims[0] <= 32 and max(dims[1:-1]) <= 256:
         out.append("wide")
     skip = {f for f in os.environ.get("TBNN_JIT_SKIP", "").split(",") if f}      # diagnostic / tests: e.g. "mid" forces the wide path
@@ -104,11 +110,36 @@ def mid_fits(dims) -> bool:
     return (img + 4 * wave) * 4 + 64 <= 160 * 1024
 
 
+def tall_fits(dims) -> bool:
+    """the tall-fan-in fused kernel (kernels_tall.hpp, TallCfg): a wave's chunk of W_0 and of dW_0 in its registers, the narrow
+    layers' images, the exchange buffers and the per-wave operand blocks in 160 KB of LDS (an estimate: the build refuses a
+    kernel that spills and the next family takes the shape)"""
+    nl = len(dims) - 1
+    if max(dims[1:-1]) > 64:
+        return False
+    tr = lambda l: _cdiv(dims[l], 16)
+    ta = lambda l: _cdiv(dims[l] + 1, 16)
+    mt0, ch = tr(1), _cdiv(ta(0), 4)
+    dwm = sum(tr(l + 1) * ta(l) for l in range(1, nl - 1))
+    vgpr = 4 * mt0 * ch + 6 * ch + 70
+    agpr = 4 * mt0 * ch + 4 * dwm
+    if vgpr > 256 or vgpr + agpr > 500:
+        return False
+    r4 = lambda a: (a + 3) & ~3
+    perm = r4(sum(16 * tr(l + 1) for l in range(nl - 1)) + dims[-1] * 16 * tr(nl - 1) + dims[-1])
+    small = r4(perm + sum(16 * tr(l + 1) * (16 * tr(l) + 4) for l in range(1, nl - 1)))
+    wave = (ch + sum(ta(l) for l in range(1, nl - 1)) + sum(tr(l + 1) for l in range(nl - 1))) * 256
+    return (small + 8 * mt0 * 256 + 4 * wave) * 4 + 64 <= 160 * 1024
+
+
 def source(dims, hact, lact, bern, family) -> str:
     shape = f"Shape<{hact}, {lact}, {'true' if bern else 'false'}, {', '.join(map(str, dims))}>"
     if family == "wide":
         return (f'#include "{CSRC}/jit_wide.hpp"\nusing S = {shape};\n'
                 'extern "C" int tbnn_jit_ops(FusedOps* o) { JitWide<S>::fill(o); return 0; }\n')
+    if family == "tall":
+        return (f'#include "{CSRC}/jit_tall.hpp"\nusing S = {shape};\n'
+                'extern "C" int tbnn_jit_ops(FusedOps* o) { JitTall<S>::fill(o); return 0; }\n')
     if family == "mid":
         return (f'#include "{CSRC}/jit_mid.hpp"\nusing S = {shape};\n'
                 'extern "C" int tbnn_jit_ops(FusedOps* o) { JitMid<S>::fill(o); return 0; }\n')

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import _native as nat
 from .activationFunctions import Relu, Sigmoid, Tanh
-from .layer import DenseLayer, GaussianDenseLayer
+from .layer import CauchyDenseLayer, DenseLayer, GaussianDenseLayer
 from .likelihood import GaussianLikelihood
 
 
@@ -93,10 +93,7 @@ class predictor(object):
 
     def predict(self, inputMatrix, n=1):
         """predictor.py:132-155: list of [d_out, rows] predictions, every n-th network."""
-        if self._chain is None:
-            self._chain = nat.Chain(self._descriptor(), likelihood=nat.LIK_FIXED_GAUSSIAN, fixed_sd=1.0,
-                                    device=self.device)
-            print("tensorbnn_amd: forward kernel", self._chain.kernel_name)    # once; Chain warns when it is the generic one
+        self._ensure_chain()
         x = np.asarray(inputMatrix, dtype=np.float32)
         # one native call for the whole ensemble (tbnn_forward_many): the rows are staged once, narrow networks run
         # as one batched launch of the forward-only MFMA kernel
@@ -127,9 +124,28 @@ class predictor(object):
             out.append(np.float32(np.sum(_multivariate_log_prob(np.ones_like(cur) * sd, cur, real))))
         return out
 
+    def _ensure_chain(self):
+        if self._chain is None:
+            self._chain = nat.Chain(self._descriptor(), likelihood=nat.LIK_FIXED_GAUSSIAN, fixed_sd=1.0,
+                                    device=self.device)
+            print("tensorbnn_amd: forward kernel", self._chain.kernel_name)    # once; Chain warns when it is the generic one
+        return self._chain
+
     def _hyper_probs(self, weights, n):
-        """predictor.py:188-206 / :248-266: minus the data term, minus every layer's calculateHyperProbs"""
-        for m in range(0, self.numNetworks, n):
+        """predictor.py:188-206 / :248-266: minus the data term, minus every layer's calculateHyperProbs.  With the built-in
+        dense layers the sum over layers of calculateHyperProbs of EVERY picked network is one launch of the native library
+        (tbnn_hyper_probs_many, one workgroup per network, the priors of the architecture loaded right now); layers from
+        customLayerDict keep their own Python calculateHyperProbs."""
+        picked = list(range(0, self.numNetworks, n))
+        dense = [l for l in self.layers if l.numTensors > 0]
+        if picked and len(self.hypers) and all(type(l) in (CauchyDenseLayer, GaussianDenseLayer) for l in dense) and \
+                all(l.numHyperTensors == 0 for l in self.layers if l.numTensors == 0):
+            ch = self._ensure_chain()
+            thetas = np.stack([self.vectors[m] for m in picked])
+            etas = np.stack([np.asarray(self.hypers[m], dtype=np.float32).reshape(-1)[:4 * len(dense)] for m in picked])
+            hp = ch.hyper_probs_many(thetas, etas, priors=[l.prior_kind for l in dense])
+            return np.array([np.float32(-np.float32(w) - np.float32(v)) for w, v in zip(weights, hp)])
+        for m in picked:
             matrixIndex = hyperIndex = 0
             current = -weights[m // n]
             for layer in self.layers:

@@ -85,3 +85,63 @@ def test_forward_many(native, case):
     np.testing.assert_allclose(ch.forward_many(thetas[:2], which=0)[1], o.forward(spec, thetas[1], X, np.float64), rtol=2e-5, atol=2e-5)
     np.testing.assert_array_equal(ch.get_state(), theta)
     ch.close()
+
+
+@pytest.mark.parametrize("dims,prior,judge", [
+    ([5, 50, 50, 50, 1], o.PRIOR_CAUCHY, None),                         # the chain's own priors
+    ([5, 50, 50, 50, 1], o.PRIOR_CAUCHY, o.PRIOR_GAUSSIAN),              # reweight: judged under the other family
+    ([20, 100, 100, 2], o.PRIOR_GAUSSIAN, None),
+    ([3, 7, 5, 2], o.PRIOR_GAUSSIAN, o.PRIOR_CAUCHY),
+])
+def test_hyper_probs_many(native, dims, prior, judge):
+    """tbnn_hyper_probs_many (predictor.trainProbs / reweight, predictor.py:188-206): for m saved (theta, eta) pairs the sum over
+    the dense layers of calculateHyperProbs, one launch -- against the fp64 oracle's layer_hyper_log_prob summed per network,
+    <= 4e-6 relative"""
+    spec, X, Y, theta, eta = o.synth_problem(dims, 64, o.ACT_RELU, prior, o.LIK_GAUSSIAN)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    ch = native.Chain(layers, likelihood=spec.likelihood, kernel=native.KERNEL_AUTO)
+    rng = np.random.default_rng(17)
+    m = 23
+    thetas = np.zeros((m, theta.size + 3), dtype=np.float32)             # a stride wider than P
+    thetas[:, :theta.size] = theta[None, :] * (1.0 + 0.2 * rng.standard_normal((m, theta.size)))
+    etas = (eta[None, :] * (1.0 + 0.05 * rng.standard_normal((m, eta.size))) + 0.01 * rng.standard_normal((m, eta.size))).astype(np.float32)
+    got = ch.hyper_probs_many(np.ascontiguousarray(thetas[:, :theta.size]), etas, priors=None if judge is None else [judge] * len(layers))
+    jspec = spec if judge is None else o.make_spec(dims, o.ACT_RELU, judge, o.LIK_GAUSSIAN, o.ACT_NONE)
+    for i in range(m):
+        parts = o.unflatten(jspec, thetas[i, :theta.size].astype(np.float64))
+        want = sum(float(o.layer_hyper_log_prob(l, etas[i, 4 * k:4 * k + 4].astype(np.float64), W, b, np.float64))
+                   for k, (l, (W, b)) in enumerate(zip(jspec.layers, parts)))
+        assert abs(got[i] - want) <= 4e-6 * abs(want) + 1e-6, (i, got[i], want)
+    ch.close()
+
+
+def test_reweight_on_device(native, tmp_path):
+    """predictor.reweight with the built-in dense layers: trainProbs and the new architecture's sums come from
+    tbnn_hyper_probs_many; the normalised weights against a direct evaluation with the oracle"""
+    from tensorbnn_amd.predictor import predictor
+    rng = np.random.default_rng(11)
+    shapes = [(4, 3), (4, 1), (2, 4), (2, 1)]
+    names = ["dense", "relu", "dense"]
+    w = o.SampleWriter(str(tmp_path / "run"), shapes, names, 9, 1, 1, 2)
+    for it in range(1, 7):
+        sts = [(0.5 * rng.standard_normal(sh)).astype(np.float32) for sh in shapes]
+        hyp = [np.float32(v + 0.02 * rng.standard_normal(1)) for v in ([0.02, 1.0, -0.02, 0.99] * 2 + [0.3])]
+        w.after_epoch(it, sts, hyp)
+    w.close()
+    p = predictor(str(tmp_path / "run") + "/")
+    (tmp_path / "arch2.txt").write_text("denseGaussian\nrelu\ndenseGaussian\n")
+    wts = p.reweight(str(tmp_path / "arch2.txt"), n=1, likelihood=None)
+    assert p._chain is not None
+    assert wts.shape == (p.numNetworks,) and abs(wts.sum() - 1) < 1e-5 and np.all(wts >= 0)
+    sc = o.make_spec([3, 4, 2], o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, o.ACT_NONE)
+    sg = o.make_spec([3, 4, 2], o.ACT_RELU, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN, o.ACT_NONE)
+    lw = []
+    for k in range(p.numNetworks):
+        t = [m_[k].astype(np.float64) for m_ in p.matrices]
+        h = np.asarray(p.hypers[k], dtype=np.float64).reshape(-1)
+        old = sum(float(o.layer_hyper_log_prob(sc.layers[j], h[4 * j:4 * j + 4], t[2 * j], t[2 * j + 1], np.float64)) for j in range(2))
+        new = sum(float(o.layer_hyper_log_prob(sg.layers[j], h[4 * j:4 * j + 4], t[2 * j], t[2 * j + 1], np.float64)) for j in range(2))
+        lw.append(new - old)
+    ref = np.exp(np.array(lw) - max(lw)); ref /= ref.sum()
+    np.testing.assert_allclose(wts, ref, rtol=2e-4, atol=1e-7)
+    assert [l.name for l in p.layers] == names

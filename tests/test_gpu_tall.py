@@ -1,0 +1,163 @@
+"""GPU parity of the fused kernels for layer-0 fan-in above 32 (round 4): the tall-fan-in family (kernels_tall.hpp: the fan-in
+split over the four waves of a workgroup, one 16-row tile per workgroup -- the reference's MNIST example 784 -> 20 -> 20 -> 1,
+docs/ClassificationExample.md:103-173) and the mid-width family with its fan-in limit lifted (100 -> 50 -> 50 -> 1).
+
+Same test set as the mid-width family: value / gradient per tensor / statistic against the fp64 oracle and the thread-per-row
+kernel, ragged row counts, several row tiles per workgroup (TBNN_FAST_GRID), whole transitions with trace, forward and
+ensemble forward, determinism.  Tolerances: tests/test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+import tbnn_oracle as o
+from test_gpu_parity import LOGP_RTOL, check_logp_grad, make_chain
+
+pytestmark = pytest.mark.gpu
+
+TALL = {
+    "mnist": dict(dims=[784, 20, 20, 1], n=1003, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_BERNOULLI),
+    "tall_t1": dict(dims=[70, 24, 40, 1], n=517, act=o.ACT_TANH, prior=o.PRIOR_GAUSSIAN, lik=o.LIK_GAUSSIAN),
+    "tall_t2": dict(dims=[128, 16, 2], n=333, act=o.ACT_RELU, prior=o.PRIOR_CAUCHY, lik=o.LIK_GAUSSIAN),
+    "tall_t3": dict(dims=[200, 33, 18, 50, 2], n=900, act=o.ACT_SIGMOID, prior=o.PRIOR_CAUCHY, lik=o.LIK_BERNOULLI),
+}
+
+
+def problem(case):
+    c = TALL[case]
+    spec, X, Y, theta, eta = o.synth_problem(c["dims"], c["n"], c["act"], c["prior"], c["lik"])
+    if c["dims"][0] >= 100:          # keep the pre-activations of a long fan-in O(1): pixel-like rows in [0, 1) / sqrt(fan-in)
+        X = (np.abs(X) / np.sqrt(c["dims"][0])).astype(np.float32)
+        if c["lik"] == o.LIK_BERNOULLI:
+            Y = (np.random.default_rng(9).random(Y.shape) < 0.5).astype(np.float32)
+    return spec, X, Y, theta, eta
+
+
+@pytest.mark.parametrize("case", list(TALL))
+def test_logp_grad_tall(native, case):
+    spec, X, Y, theta, eta = problem(case)
+    ch = make_chain(native, spec, native.KERNEL_FAST)
+    assert ch.kernel_name.startswith("tall<"), ch.kernel_name
+    ch.close()
+    lp, g = check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+    lp_g, g_g = check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_GENERIC)
+    assert abs(lp - lp_g) <= 2e-6 * abs(lp_g) + 1e-4
+    assert np.abs(g - g_g).max() <= 5e-5 * np.abs(g_g).max()
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 129, 4200 + 3])
+def test_logp_grad_tall_ragged_rows(native, n):
+    spec, X, Y, theta, eta = o.synth_problem([70, 24, 40, 1], n, o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN)
+    check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+
+
+@pytest.mark.parametrize("case,grid", [("mnist", 3), ("mnist", 64), ("tall_t1", 2), ("tall_t2", 5), ("tall_t3", 7)])
+def test_tall_several_tiles_per_workgroup(native, monkeypatch, case, grid):
+    """a small grid (TBNN_FAST_GRID): every workgroup walks several row tiles (accumulators carried over tiles, the exchange
+    buffers alternate) -- same value and gradient as the one-tile-per-workgroup launch, and as the fp64 oracle"""
+    spec, X, Y, theta, eta = problem(case)
+    lp0, g0 = check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+    monkeypatch.setenv("TBNN_FAST_GRID", str(grid))
+    lp, g = check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
+    assert abs(lp - lp0) <= 1e-6 * abs(lp0) + 1e-5
+    assert np.abs(g - g0).max() <= 2e-5 * np.abs(g0).max()
+
+
+@pytest.mark.parametrize("case", list(TALL))
+def test_transition_tall(native, monkeypatch, case):
+    spec, X, Y, theta, eta = problem(case)
+    rng = np.random.default_rng(3)
+    p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+    monkeypatch.setenv("TBNN_FAST_GRID", "5")
+    ch = make_chain(native, spec, native.KERNEL_FAST)
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    monkeypatch.delenv("TBNN_FAST_GRID")
+    eps = 2e-5
+    out = ch.hmc_step(eps, 4, p0=p0, log_u=float(np.log(0.5)), trace=True)
+    ref = o.weight_step(spec, theta, eta, X, Y, eps, 4, p0, float(np.log(0.5)), np.float64)
+    np.testing.assert_allclose(out["trace_logp"], ref.trace_logp, rtol=LOGP_RTOL, atol=2e-3)
+    # lar is a difference of two fp32-evaluated log-probs: the band of tests/test_gpu_fullsize.py with its
+    # resolution term -- un-normalised rows over a 70..784-wide fan-in put |logp| at 1e5..1e6
+    lar_tol = 2e-2 + 1e-4 * abs(ref.log_accept_ratio) + 1e-6 * abs(ref.trace_logp[0])
+    assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= lar_tol, (out["log_accept_ratio"], ref.log_accept_ratio, ref.trace_logp[0])
+    if abs(ref.log_accept_ratio - float(np.log(0.5))) > 2 * lar_tol:
+        assert bool(out["accepted"]) == ref.accepted
+    np.testing.assert_allclose(ch.get_state(), ref.theta_proposed if out["accepted"] else theta, rtol=0, atol=2e-6 * max(1.0, np.abs(ref.theta).max()))
+    # free-running transitions afterwards: finite, and the chain moves
+    outs = ch.hmc_run(eps, 5, 4)
+    assert all(np.isfinite(o_["log_accept_ratio"]) for o_ in outs)
+    ch.close()
+
+
+@pytest.mark.parametrize("case", list(TALL))
+def test_forward_tall(native, case):
+    """network.predict / the ensemble forward on the forward-only instantiation (grid.y = network)"""
+    spec, X, Y, theta, eta = problem(case)
+    ch = make_chain(native, spec, native.KERNEL_FAST)
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    ref = o.forward(spec, theta, X, np.float64)
+    f = ch.predict(0)
+    np.testing.assert_allclose(f, ref, rtol=2e-5, atol=2e-5)
+    rng = np.random.default_rng(5)
+    thetas = (theta[None, :] + 0.05 * rng.standard_normal((5, theta.size))).astype(np.float32)
+    fm = ch.forward_many(thetas, X=X[:77])
+    for i in range(5):
+        np.testing.assert_allclose(fm[i], o.forward(spec, thetas[i], X[:77], np.float64), rtol=2e-5, atol=2e-5)
+    ch.close()
+
+
+def test_tall_determinism(native):
+    spec, X, Y, theta, eta = problem("mnist")
+    res = []
+    for _ in range(2):
+        ch = make_chain(native, spec, native.KERNEL_FAST)
+        ch.set_data(X, Y)
+        res.append(ch.logp_grad(theta, eta))
+        ch.close()
+    assert res[0][0] == res[1][0]
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def test_mnist_shape_full_rows(native):
+    """784 -> 20 -> 20 -> 1 at the tutorial's scale (12,000 rows): value, statistic and every gradient tensor against the C restatement"""
+    import c_oracle
+    spec, X, Y, theta, eta = o.synth_problem([784, 20, 20, 1], 12000, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI)
+    X = (np.abs(X) / 28.0).astype(np.float32)
+    ch = make_chain(native, spec, native.KERNEL_AUTO)
+    assert ch.kernel_name.startswith("tall<"), ch.kernel_name
+    ch.set_data(X, Y)
+    lp, g, st = ch.logp_grad(theta, eta)
+    co = c_oracle.COracle(spec, X, Y)
+    lp_c, g_c = co.logp_grad(theta, eta)[:2]
+    assert abs(lp - lp_c) <= LOGP_RTOL * abs(lp_c)
+    for l, (ow, ob) in zip(spec.layers, spec.offsets()):
+        for a, b in ((ow, ob), (ob, ob + l.out_dim)):
+            assert np.abs(g[a:b] - g_c[a:b]).max() <= 1e-4 * max(np.abs(g_c[a:b]).max(), 1e-3)
+    ch.close()
+
+
+# ---- the mid-width family with layer-0 fan-in above 32 (kernels_mid.hpp, MID_MAX_FANIN)
+@pytest.mark.parametrize("dims,n,act,lik", [
+    ([100, 50, 50, 1], 1003, o.ACT_RELU, o.LIK_GAUSSIAN),
+    ([40, 24, 40, 1], 517, o.ACT_TANH, o.LIK_GAUSSIAN),
+    ([64, 32, 48, 2], 700, o.ACT_SIGMOID, o.LIK_BERNOULLI),
+])
+def test_mid_long_fan_in(native, dims, n, act, lik):
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, act, o.PRIOR_CAUCHY, lik)
+    ch = make_chain(native, spec, native.KERNEL_AUTO, jit=True)
+    assert "mid<" in ch.kernel_name, ch.kernel_name
+    ch.set_data(X, Y)
+    lp, g, st = ch.logp_grad(theta, eta)
+    lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)
+    assert abs(lp - lp64) <= LOGP_RTOL * abs(lp64) + 1e-3
+    for l, (ow, ob) in zip(spec.layers, spec.offsets()):
+        for a, b in ((ow, ob), (ob, ob + l.out_dim)):
+            assert np.abs(g[a:b] - g64[a:b]).max() <= 1e-4 * max(np.abs(g64[a:b]).max(), 1e-3)
+    rng = np.random.default_rng(3)
+    p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+    ch.set_state(theta); ch.set_hypers(eta)
+    out = ch.hmc_step(2e-5, 4, p0=p0, log_u=float(np.log(0.5)), trace=True)
+    ref = o.weight_step(spec, theta, eta, X, Y, 2e-5, 4, p0, float(np.log(0.5)), np.float64)
+    np.testing.assert_allclose(out["trace_logp"], ref.trace_logp, rtol=LOGP_RTOL, atol=2e-3)
+    lar_tol = 2e-2 + 1e-4 * abs(ref.log_accept_ratio) + 1e-6 * abs(ref.trace_logp[0])       # (resolution term: see test_transition_tall)
+    assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= lar_tol, (out["log_accept_ratio"], ref.log_accept_ratio, ref.trace_logp[0])
+    ch.close()

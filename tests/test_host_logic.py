@@ -236,9 +236,18 @@ def test_jit_family_choice_and_source():
 
 def test_predictor_reweight_without_likelihood(tmp_path):
     """predictor.reweight / trainProbs, the path the reference can run (likelihood=None, predictor.py:157-273):
-    weights = exp(sum_layers hyperprobs_new - hyperprobs_train), normalised -- checked against a direct evaluation"""
+    weights = exp(sum_layers hyperprobs_new - hyperprobs_train), normalised -- checked against a direct evaluation.
+    Layers from customLayerDict (user plug-ins, predictor.py:30-36) are judged by their own Python calculateHyperProbs: that
+    is the route this host test walks; the built-in dense layers go through tbnn_hyper_probs_many on the device
+    (tests/test_gpu_metrics.py::test_reweight_on_device)."""
     from tensorbnn_amd.predictor import predictor
     from tensorbnn_amd.layer import CauchyDenseLayer, GaussianDenseLayer
+
+    class UserCauchy(CauchyDenseLayer):
+        pass
+
+    class UserGaussian(GaussianDenseLayer):
+        pass
     rng = np.random.default_rng(11)
     shapes = [(4, 3), (4, 1), (2, 4), (2, 1)]
     names = ["dense", "relu", "dense"]
@@ -251,7 +260,7 @@ def test_predictor_reweight_without_likelihood(tmp_path):
         nets.append((sts, hyp))
         w.after_epoch(it, sts, hyp)
     w.close()
-    p = predictor(str(tmp_path / "run") + "/")
+    p = predictor(str(tmp_path / "run") + "/", customLayerDict={"dense": UserCauchy, "denseGaussian": UserGaussian})
     assert p.numNetworks >= 4 and p.extractParameters()[0].shape[1:] == (4, 3)
     (tmp_path / "arch2.txt").write_text("denseGaussian\nrelu\ndenseGaussian\n")
     wts = p.reweight(str(tmp_path / "arch2.txt"), n=1, likelihood=None)
@@ -268,6 +277,7 @@ def test_predictor_reweight_without_likelihood(tmp_path):
     np.testing.assert_allclose(wts, ref, rtol=2e-4, atol=1e-7)
     # the architecture is restored afterwards (predictor.py:271)
     assert [l.name for l in p.layers] == names
+    assert p._chain is None                       # no native chain was needed for user-defined layers
 
 
 def test_autocorr_restatement():
@@ -344,6 +354,40 @@ def test_bench_host_helpers():
     assert set(bench.CONFIG_KEY) >= {"c1", "c2", "c4", "c5"}
 
 
+def test_bench_quotes_committed_profiles_only_for_the_loaded_build(tmp_path):
+    """roofline.frac_rocprof / roofline.traffic come from committed rocprofv3 summaries; they are quoted only when those were
+    measured on the build that is loaded (tbnn_build_id written by tools/rocprof_summary.py), and are null otherwise -- a
+    kernel changed without re-profiling must not carry the old kernel's numbers"""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    from tensorbnn_amd import _native as nat, build as b
+    bid = nat.build_id()
+    assert len(bid) == 16 and bid == b.sources_id(["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-value",
+                                                     "-Wno-unused-result"])        # the library reports the sources it was built from
+    ku = {"c2": {"us": 44.3, "kernels": {"k_fwd_bwd_fast3": 44.3}, "source": "profiles/x_c2_kernel_stats.csv"},
+          "c5": {"us": 362.0, "kernels": {"k_fwd_bwd_mid": 362.0}, "source": "profiles/x_c5_kernel_stats.csv"},
+          "_build": {"build_id": bid, "lib_sha256": "0" * 64, "git_head": "abc", "tag": "x"}}
+    tr = {"c2": {"hbm_bytes_per_launch": 12593417}, "_build": dict(ku["_build"])}
+    json.dump(ku, open(tmp_path / "rocprof_kernel_us.json", "w")); json.dump(tr, open(tmp_path / "pmc_traffic.json", "w"))
+    got = bench.committed_profile("c2", bid, str(tmp_path))
+    assert got["match"] and got["kernel_us"] == 44.3 and got["traffic"] == 12593417 and got["source"].endswith("x_c2_kernel_stats.csv")
+    assert bench.committed_profile("c5g", bid, str(tmp_path))["kernel_us"] == 362.0           # configs[4]'s kernels on other priors
+    stale = bench.committed_profile("c2", "f" * 16, str(tmp_path))                           # another build is loaded
+    assert not stale["match"] and stale["kernel_us"] is None and stale["traffic"] is None and stale["profiled_build"] == bid
+    tr["_build"]["build_id"] = "e" * 16                                                      # PMC pass from an older build than the trace
+    json.dump(tr, open(tmp_path / "pmc_traffic.json", "w"))
+    half = bench.committed_profile("c2", bid, str(tmp_path))
+    assert half["kernel_us"] == 44.3 and half["traffic"] is None
+    del ku["_build"]                                                                         # a file from before round 4: never quoted
+    json.dump(ku, open(tmp_path / "rocprof_kernel_us.json", "w"))
+    assert bench.committed_profile("c2", bid, str(tmp_path))["kernel_us"] is None
+    assert bench.committed_profile("c2", bid, str(tmp_path / "nowhere"))["kernel_us"] is None
+    # the committed files under profiles/ carry a build id (whatever it is)
+    for f in ("rocprof_kernel_us.json", "pmc_traffic.json"):
+        assert "_build" in json.load(open(os.path.join(ROOT, "profiles", f))), f
+
+
 def test_bench_line_fits_driver_tail():
     """the stdout line of bench.py keeps every config's value / roofline fraction / CPU baseline within 2 KB (the driver's
     record keeps a 2-KB tail); checked on the committed full record of round 2 with the rocprof fields filled in"""
@@ -353,7 +397,8 @@ def test_bench_line_fits_driver_tail():
     full = json.load(open(os.path.join(ROOT, "profiles", "r02b_bench_full.json")))
     for r in [full] + list(full["secondary"].values()):
         if r.get("roofline") and r["roofline"].get("frac") is not None:
-            r["roofline"].update(frac_rocprof=0.4291, rocprof_kernel_us=4849.123, rocprof_source="profiles/r03z_c4_kernel_stats.csv")
+            r["roofline"].update(frac_rocprof=0.4291, rocprof_kernel_us=4849.123, rocprof_source="profiles/r03z_c4_kernel_stats.csv",
+                                 profile_build_match=True)
     line = bench.compact_line(full)
     text = json.dumps(line)
     assert len(text) <= 2300

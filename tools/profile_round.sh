@@ -1,6 +1,8 @@
 #!/bin/bash
 # One round's rocprofv3 evidence for profiles/: kernel trace + stats and separate PMC passes (never combined with a trace
-# domain) for BASELINE configs[1] (bench.py --workload c2), configs[3] and configs[4] (tools/widetime.py at full size).
+# domain) of THE BENCH COMMAND ITSELF for BASELINE configs[1], configs[3] and configs[4] (bench.py --workload c2 | c4 | c5: the
+# burned-in state and step size the driver's line is measured at, so that the dominant kernel's mean duration here can be
+# held against ms_per_step / L of that line; rounds 1-3 profiled tools/widetime.py at the initial state for c4 / c5).
 #   tools/profile_round.sh r03b        -> gpurun_out/r03b/{c2,c4,c5}_kernel_stats.csv, *_pmc_summary.json,
 #                                         rocprof_kernel_us.json, pmc_traffic.json   (copy the ones to be judged into profiles/)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -9,8 +11,8 @@ OUT=gpurun_out/$R
 mkdir -p $OUT
 declare -A CMD
 CMD[c2]="python3 bench.py --workload c2 --steps 40 --warmup 10 --no-cpu-baseline"
-CMD[c4]="python3 tools/widetime.py c4 10"
-CMD[c5]="python3 tools/widetime.py c5 10"
+CMD[c4]="python3 bench.py --workload c4 --no-cpu-baseline"
+CMD[c5]="python3 bench.py --workload c5 --no-cpu-baseline"
 for W in ${PROFILE_WORKLOADS:-c2 c4 c5}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- ${CMD[$W]} > $OUT/trace_$W.log 2>&1 || echo "trace $W failed"
   f=$(find $OUT/trace_$W -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${W}_kernel_stats.csv

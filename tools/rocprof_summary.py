@@ -7,6 +7,7 @@ out = sys.argv[1]
 tag = os.path.basename(os.path.normpath(out))
 # kernels of one fused forward+backward pass, per workload
 PASS = {"c2": ["k_fwd_bwd_fast3"], "c4": ["k_chain_wide", "k_dw_wide", "k_reduce_wide"], "c5": ["k_fwd_bwd_mid", "k_chain_wide", "k_dw_wide", "k_reduce_wide"]}
+PASS = {w: PASS[w] for w in os.environ.get("PROFILE_WORKLOADS", "c2 c4 c5").split() if w in PASS}
 
 
 def kname(full):
@@ -48,6 +49,15 @@ for w, names in PASS.items():
                           "kernels": " + ".join(sorted(summ)),
                           "correction": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes): gfx950 FETCH_SIZE counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM)",
                           "source": f"profiles/{tag}_{w}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)"}
+# what was profiled: the loaded library's own id (hash of its sources, tbnn_build_id), its file hash, the commit it was built at
+# (TBNN_GIT_HEAD: the GPU box has no .git) -- bench.py quotes these files only on a build_id match
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hashlib
+from tensorbnn_amd import _native as nat
+build = {"build_id": nat.build_id(), "lib_sha256": hashlib.sha256(open(nat.LIB_PATH, "rb").read()).hexdigest(),
+         "git_head": os.environ.get("TBNN_GIT_HEAD") or None, "tag": tag}
+kernel_us["_build"] = build
+traffic["_build"] = build
 json.dump(kernel_us, open(os.path.join(out, "rocprof_kernel_us.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(kernel_us, indent=1)); print(json.dumps(traffic, indent=1))
