@@ -289,13 +289,29 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
     fence()
     t0 = time.perf_counter()
     outs = run(steps, eps)
+    dt_own = time.perf_counter() - t0          # this rank's own clock: its last epoch's record has been read back (hmc_run / gather return)
+    if os.environ.get("TBNN_BENCH_FAIL_RANK") == str(rank):      # test hook: a rank that dies mid-run must take the job down, non-zero
+        print(f"[rank {rank}] TBNN_BENCH_FAIL_RANK: exiting with code 3", file=sys.stderr, flush=True)
+        os._exit(3)
     fence()
     dt = time.perf_counter() - t0
+    ranks = None
     if world > 1:
         cdev = ctx["cdev"]
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # what every rank saw: its own rate (a starved launch thread shows here), the communicator size its collective library
+        # reports (ncclCommCount), the gather route it took
+        mine = torch.tensor([steps * L / dt_own, float(comm.count()) if comm is not None else -1.0,
+                             1.0 if comm is not None else 0.0, float(len(os.sched_getaffinity(0)))], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per = [a.tolist() for a in allr]
+        ranks = {"steps_per_s": [round(a[0], 1) for a in per], "steps_per_s_min": round(min(a[0] for a in per), 1),
+                 "steps_per_s_max": round(max(a[0] for a in per), 1), "nccl_comm_count": [int(a[1]) for a in per],
+                 "native_gather": [bool(a[2]) for a in per], "cpus_allowed": [int(a[3]) for a in per],
+                 "omp_num_threads": os.environ.get("OMP_NUM_THREADS"), "collective_library": os.environ.get("TBNN_RCCL_LIB", "librccl (RCCL)")}
         acc = torch.tensor([float(np.mean([o["accept_prob"] for o in outs])),
                             float(np.mean([o["accepted"] for o in outs]))], dtype=torch.float64, device=cdev)
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
@@ -350,6 +366,8 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
         "accept_ratio": round(acc_prob, 4), "accepted_fraction": round(acc_frac, 4),
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    if ranks is not None:
+        line["ranks"] = ranks
     if hyper:
         line["hyper_accept_ratio"] = round(float(np.mean(hyp_acc)), 4) if hyp_acc else None
         line["hyper_step_size"] = {"first": hyp_eps[0], "last": hyp_eps[-1], "rule": "dual averaging, network.py:457-469"} if hyp_eps else None
@@ -391,6 +409,10 @@ def compact_line(line):
     cfg.pop("parallelism", None)
     out["config"] = cfg
     out.pop("accepted_fraction", None)
+    if "ranks" in out:                                   # per-rank diagnostics: min / max and what the collective library counted
+        r = out["ranks"]
+        out["ranks"] = {"steps_per_s_min": r["steps_per_s_min"], "steps_per_s_max": r["steps_per_s_max"],
+                        "nccl_comm_count": sorted(set(r["nccl_comm_count"])), "native_gather": all(r["native_gather"])}
     if "secondary" in line:
         sec = {}
         for key, r in line["secondary"].items():
@@ -414,6 +436,25 @@ def compact_line(line):
     return out
 
 
+def visible_gpus():
+    """GPUs this process could use, counted WITHOUT touching the HIP runtime (the parent of the ranks must stay GPU-free): KFD
+    topology nodes with SIMDs, cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES; None when sysfs does not say"""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        cnt = 0
+        for node in os.listdir(base):
+            for ln in open(os.path.join(base, node, "properties")):
+                if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                    cnt += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            cnt = min(cnt, len([x for x in v.split(",") if x.strip() != ""]))
+    return cnt
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` run bare: launch N ranks with torch.distributed.run as a child process, pass their output
     through (rank 0 prints the one JSON line), return the child's exit code"""
@@ -426,7 +467,11 @@ def spawn_ranks(n):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
+    # one launch thread per rank does the work; the math libraries of N ranks must not each start a thread per logical CPU of a
+    # box whose cgroup schedules 2 CPUs per rank
+    thr = str(max(1, min(4, (len(os.sched_getaffinity(0)) or 1) // n)))
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        env.setdefault(var, thr)
     return subprocess.call(cmd, env=env)
 
 
@@ -448,7 +493,13 @@ def main():
     # --gpus N > 1 without a launcher around us: start the N ranks ourselves (one process per GPU) as a CHILD
     # torch.distributed.run and relay rank 0's line.  Nothing in this process has touched the GPU (or imported torch) yet.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        have = visible_gpus()
+        if os.environ.get("TBNN_BENCH_SINGLE_GPU", "0") != "1" and have is not None and have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible on this node (one rank per GPU; nothing was started)")
         raise SystemExit(spawn_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:      # ranks started by a launcher: same thread caps as spawn_ranks sets
+        for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+            os.environ.setdefault(var, "2")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -212,6 +212,8 @@ int tbnn_comm_unique_id(unsigned char id[TBNN_COMM_ID_BYTES]);
 /* ncclCommInitRank on the chain's device; collective over all `world` ranks */
 int tbnn_comm_create(tbnn_handle h, int world, int rank, const unsigned char id[TBNN_COMM_ID_BYTES],
                      tbnn_comm_handle* out);
+/* ranks in the communicator as the collective library reports them (ncclCommCount); < 0: error */
+int tbnn_comm_count(tbnn_comm_handle c);
 int tbnn_comm_destroy(tbnn_comm_handle c);
 /* checkpoint-time gather (network.py:610-663 writes one chain; with N chains every rank ends up
  * with all N samples): all-gather of (theta, eta) = P+H floats per rank.  d_out: device buffer of

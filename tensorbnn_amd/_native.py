@@ -87,6 +87,7 @@ SYMBOLS = [
     ("tbnn_fused_kernel_available", C.c_int, [C.POINTER(NetDesc)]),
     ("tbnn_comm_unique_id", C.c_int, [C.POINTER(C.c_ubyte)]),
     ("tbnn_comm_create", C.c_int, [_H, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.POINTER(_H)]),
+    ("tbnn_comm_count", C.c_int, [_H]),
     ("tbnn_comm_destroy", C.c_int, [_H]),
     ("tbnn_gather_samples", C.c_int, [_H, _H, C.c_void_p, _fp]),
     ("tbnn_set_row_shard", C.c_int, [_H, _H, C.c_int64]),
@@ -358,6 +359,10 @@ class Comm:
         self._c = _H()
         buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(uid)
         _check(lib.tbnn_comm_create(chain._h, self.world, self.rank, buf, C.byref(self._c)))
+
+    def count(self) -> int:
+        """ranks in the communicator as the collective library reports them (ncclCommCount)"""
+        return _check(lib.tbnn_comm_count(self._c))
 
     def close(self):
         if getattr(self, "_c", None):

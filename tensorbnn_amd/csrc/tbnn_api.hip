@@ -503,6 +503,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -527,7 +528,7 @@ static int rccl_load() {
     RcclApi a; a.lib = lib;
 #define RSYM(field, name) do { *(void**)(&a.field) = dlsym(lib, name); if (!a.field) return fail(-5, std::string("librccl.so lacks ") + name); } while (0)
     RSYM(GetUniqueId, "ncclGetUniqueId"); RSYM(CommInitRank, "ncclCommInitRank"); RSYM(CommDestroy, "ncclCommDestroy");
-    RSYM(AllReduce, "ncclAllReduce"); RSYM(AllGather, "ncclAllGather"); RSYM(GetErrorString, "ncclGetErrorString");
+    RSYM(CommCount, "ncclCommCount"); RSYM(AllReduce, "ncclAllReduce"); RSYM(AllGather, "ncclAllGather"); RSYM(GetErrorString, "ncclGetErrorString");
 #undef RSYM
     g_rccl = a;
     return 0;
@@ -564,6 +565,13 @@ extern "C" int tbnn_comm_create(tbnn_handle h, int world, int rank, const unsign
     if (r != ncclSuccess) { delete c; return fail(-5, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
     *out = c;
     return 0;
+}
+// ranks in the communicator AS THE COLLECTIVE LIBRARY SEES IT (ncclCommCount): what bench.py reports per rank at N > 1
+extern "C" int tbnn_comm_count(tbnn_comm_handle c) {
+    if (!c) return fail(-1, "null communicator");
+    int n = 0;
+    NCCLCHK(g_rccl.CommCount(c->comm, &n));
+    return n;
 }
 extern "C" int tbnn_comm_destroy(tbnn_comm_handle c) {
     if (!c) return 0;

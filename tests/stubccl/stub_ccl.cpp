@@ -92,6 +92,12 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int world, ncclUniqueId id, int r
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = ((StubComm*)comm)->seg->joined.load(std::memory_order_acquire);      // ranks that really joined the segment
+    return ncclSuccess;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     StubComm* c = (StubComm*)comm;
     if (c) { munmap(c->seg, sizeof(Seg)); delete c; }

@@ -52,6 +52,7 @@ def main():
         ch = chain_of(spec, chain_id=rank)
         ch.set_data(X, Y); ch.set_state(theta + np.float32(rank)); ch.set_hypers(eta * np.float32(1 + rank))
         comm = nat.Comm(ch, world, rank, exchange_id(rank, idfile))
+        res["comm_count"] = np.array(comm.count())
         for it in range(3):                                  # a few transitions between gathers, as at checkpoint time
             ch.hmc_step(1e-5, 3)
             g = ch.gather_samples(comm)

@@ -149,6 +149,76 @@ def test_bench_multi_rank_control_flow(tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["chains"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["config"]["sample_gather"].startswith("tbnn_gather_samples") and "secondary" not in d
     assert d["value"] > 0 and d["roofline"]["frac"] > 0.05
+    assert d["ranks"]["nccl_comm_count"] == [2] and d["ranks"]["native_gather"] is True
+    assert 0 < d["ranks"]["steps_per_s_min"] <= d["ranks"]["steps_per_s_max"]
+
+
+def _bench_env(**extra):
+    from test_gpu_multirank import build_stub
+    env = dict(os.environ, TBNN_RCCL_LIB=build_stub(), **extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "OMP_NUM_THREADS"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_four_ranks_rehearsal(tmp_path):
+    """The driver's multi-GPU invocation rehearsed on the one GPU of the test box: `bench.py --gpus 4` starts its own four ranks
+    (torch.distributed.run as a child), the unique id travels over torch.distributed, every rank joins the native communicator
+    (stand-in collective library: RCCL refuses two ranks on one device), gathers through tbnn_gather_samples inside the timed
+    region, and rank 0 prints ONE line that says what every rank saw.  Four, not eight: the GPU box admits at most six processes
+    of one user on its card (this test's own process is one of them); nothing in the path depends on the rank count beyond the
+    collective library's own limit."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "6", "--warmup", "2", "--sampling-step", "2"]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=_bench_env(TBNN_BENCH_SINGLE_GPU="1"), cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["chains"] == 4 and d["scaling"] == "weak" and d["steps"] == 6
+    assert d["config"]["sample_gather"].startswith("tbnn_gather_samples")
+    assert d["ranks"]["nccl_comm_count"] == [4] and d["ranks"]["native_gather"] is True
+    assert 0 < d["ranks"]["steps_per_s_min"] <= d["ranks"]["steps_per_s_max"]
+    # value = leapfrog steps of ALL ranks over the slowest rank's wall time
+    assert abs(d["value"] - 4 * 6 * 50 / (d["ms_per_step"] * 6 / 1e3)) <= 1e-3 * d["value"]
+    full = [json.loads(l) for l in r.stderr.splitlines() if l.startswith("{")][-1]
+    assert len(full["ranks"]["steps_per_s"]) == 4 and full["ranks"]["nccl_comm_count"] == [4, 4, 4, 4]
+    assert full["ranks"]["omp_num_threads"] is not None            # thread caps reached the ranks
+    print(f"4-rank rehearsal: {time.time() - t0:.0f} s, per-rank steps/s {full['ranks']['steps_per_s']}")
+
+
+def test_bench_rank_death_is_a_nonzero_exit(tmp_path):
+    """a rank that dies inside the timed region (test hook TBNN_BENCH_FAIL_RANK) takes the whole job down: non-zero exit code,
+    no result line, no hang"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--sampling-step", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=_bench_env(TBNN_BENCH_SINGLE_GPU="1", TBNN_BENCH_FAIL_RANK="1"), cwd=root)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_more_ranks_than_gpus_fails_fast():
+    """`bench.py --gpus 8` on a box with fewer GPUs: refused by the parent before any rank is started (one rank per GPU; it never
+    doubles ranks up on a device by itself), non-zero, within seconds"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = _bench_env()
+    env.pop("TBNN_BENCH_SINGLE_GPU", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout), r.stderr[-500:]
+    assert time.time() - t0 < 30
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_classification_flow(tmp_path, monkeypatch, native):

@@ -64,6 +64,18 @@ def test_gather_two_ranks(tmp_path):
     assert np.abs(r0["own2"] - r1["own2"]).max() > 0.5                  # the two chains really are different chains
 
 
+def test_gather_four_ranks(tmp_path):
+    """the same at world = 4 (as many ranks as the GPU box's process limit leaves room for next to this process)"""
+    res = run_world("gather", 4, tmp_path)
+    for it in range(3):
+        g0 = res[0][f"g{it}"]
+        assert g0.shape == (4, 5451 + 17)
+        for r in range(4):
+            np.testing.assert_array_equal(res[r][f"g{it}"], g0)
+            np.testing.assert_array_equal(g0[r], res[r][f"own{it}"])
+    assert all(int(r["comm_count"]) == 4 for r in res)
+
+
 def test_row_shard_two_ranks(tmp_path, native):
     import worker                                                       # shapes only
     ranks = run_world("shard", 2, tmp_path)

@@ -434,3 +434,34 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):      # thread caps for N ranks on a CPU-limited cgroup
+        assert 1 <= int(seen["env"][var]) <= 4
+    # more ranks than GPUs: the parent refuses before anything is started (sysfs says how many there are; no HIP call)
+    seen.clear()
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 1)
+    monkeypatch.delenv("TBNN_BENCH_SINGLE_GPU", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "only 1 GPU(s) visible" in str(e.value.code) and not seen
+    monkeypatch.setenv("TBNN_BENCH_SINGLE_GPU", "1")                                # the one-GPU rehearsal hook still spawns
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and seen
+
+
+def test_visible_gpus_respects_visibility_masks(monkeypatch, tmp_path):
+    sys.path.insert(0, ROOT)
+    import bench
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate((0, 1024, 1024, 1024)):                                # node 0: the CPU
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\n")
+    real_listdir, real_open = os.listdir, open
+    monkeypatch.setattr(os, "listdir", lambda p: real_listdir(str(nodes)) if p == "/sys/class/kfd/kfd/topology/nodes" else real_listdir(p))
+    import builtins
+    monkeypatch.setattr(builtins, "open", lambda p, *a, **k: real_open(str(p).replace("/sys/class/kfd/kfd/topology/nodes", str(nodes)), *a, **k))
+    for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpus() == 2
