@@ -148,7 +148,10 @@ static const FusedOps* find_jit(const NetDev& nd) {
 // a FusedOps table for this network: a run-time registered library first, then the ahead-of-time tall-fan-in instantiations
 static const FusedOps* find_ops(const NetDev& nd) {
     const FusedOps* o = find_jit(nd);
-    return o ? o : tall_find(nd);
+    if (o) return o;
+    // TBNN_TALL=0 (diagnostic / A-B runs, the layered family's tests): shapes the tall-fan-in registry covers take the layered path
+    const bool tall_on = !(getenv("TBNN_TALL") && atoi(getenv("TBNN_TALL")) == 0);
+    return tall_on ? tall_find(nd) : nullptr;
 }
 extern "C" int tbnn_register_kernel_lib(const char* path) {
     if (!path) return fail(-1, "null path");
@@ -175,8 +178,8 @@ extern "C" int tbnn_fused_kernel_available(const tbnn_net_desc* desc) {
     if (rc) return rc;
     if (fast_lookup(nd) >= 0 || mid_lookup(nd) >= 0) return 1;
     if (wide_lookup(nd) >= 0) return 2;
-    if (tall_find(nd)) return 1;
-    return find_jit(nd) ? 3 : 0;
+    if (find_ops(nd)) return find_jit(nd) ? 3 : 1;
+    return 0;
 }
 
 static void default_eta(const NetDev& nd, std::vector<float>& eta) {

@@ -50,6 +50,13 @@ CASES = {
 }
 
 
+@pytest.fixture(autouse=True)
+def layered_family_only(monkeypatch):
+    """this module tests the layered family: the 784 -> 20 -> 20 -> 1 cases stay on it although the tall-fan-in fused kernel
+    (kernels_tall.hpp, tests/test_gpu_tall.py) is what a chain gets for that shape by default"""
+    monkeypatch.setenv("TBNN_TALL", "0")
+
+
 def make_chain(native, spec, kernel, **kw):
     layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
     return native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, kernel=kernel, jit=False, **kw)
@@ -156,10 +163,12 @@ def test_forward_many_layered(native):
         np.testing.assert_allclose(out_v[i], ref[:, :77], rtol=2e-5, atol=2e-6)
 
 
-def test_mnist_shaped_classification_flow(tmp_path, monkeypatch, native):
+@pytest.mark.parametrize("family", ["tall", "layered"])
+def test_mnist_shaped_classification_flow(tmp_path, monkeypatch, native, family):
     """docs/ClassificationExample.md's network -- 784 inputs in [0, 1], two hidden layers of 20, one sigmoid output,
-    BernoulliLikelihood -- through the drop-in Python API on synthetic 'images': runs on the layered family (fan-in 784),
-    learns, writes samples the predictor reads back."""
+    BernoulliLikelihood -- through the drop-in Python API on synthetic 'images': on the fused tall-fan-in kernel (what a user gets)
+    and on the layered family (TBNN_TALL=0); learns, writes samples the predictor reads back."""
+    monkeypatch.setenv("TBNN_TALL", "1" if family == "tall" else "0")
     from tensorbnn_amd.activationFunctions import Relu, Sigmoid
     from tensorbnn_amd.layer import DenseLayer
     from tensorbnn_amd.likelihood import BernoulliLikelihood
@@ -180,7 +189,7 @@ def test_mnist_shaped_classification_flow(tmp_path, monkeypatch, native):
                   leapFrogMax=40, leapfrogIncrement=5, hyperStepSize=1e-4, hyperLeapfrog=10, burnin=20, averagingSteps=5)
     rec = net.train(50, 5, BernoulliLikelihood(), metricList=[Accuracy()], adjustHypers=True, folderName="mnist", networksPerFile=2,
                     displaySkip=25)
-    assert net._chain.kernel_name == "layered<784,20,20,1>"
+    assert net._chain.kernel_name == ("tall<relu,sigmoid,bernoulli;784,20,20,1>" if family == "tall" else "layered<784,20,20,1>")
     assert len(rec) == 50 and np.mean([r["main"]["accept_prob"] for r in rec]) > 0.2
     p = predictor(str(tmp_path / "mnist") + "/", likelihood=BernoulliLikelihood())
     preds = np.array(p.predict(X[1000:]))
