@@ -187,7 +187,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
     wl = WORKLOADS[name]
     DIMS, N_ROWS, L = wl["dims"], wl["n"], wl["L"]
     layers, lik, X, Y, theta0, eta0 = synth_problem(DIMS, N_ROWS, prior=wl["prior"], likelihood=wl["lik"])
-    burned = None if args.from_initial else burned_state(name)
+    burned = None if args.from_initial else burned_state(name, os.path.join(ROOT, "tests", "golden"))
     hyper = wl["hyper"]                   # configs[4]: hyper-HMC on the priors enabled (network.py:414-471)
     da = None
     if burned is not None:

@@ -5,6 +5,7 @@
 #include "../../include/tbnn.h"
 
 #define TBNN_WAVE 64
+#define PSTAT_CAP 512                     // entries of the per-workgroup statistic buffer (tbnn_api.hip): >= the grid of every fused pass
 
 // Network descriptor passed BY VALUE as a kernel argument (lives in SGPRs /
 // the kernarg segment: every lookup is wave-uniform).

@@ -39,9 +39,10 @@ struct LayPlan {
     long aOff[TBNN_MAX_LAYERS + 1];   // a_l, l = 0 .. nl (a_nl = the network output f)
     long dOff[TBNN_MAX_LAYERS];       // dz_l
     long store_floats;
-    int NS;                           // gradient slabs = workgroups of k_lay_dw (x) = workgroups of k_lay_lik
+    int NS;                           // gradient slabs = row ranges of k_lay_dw (grid.x)
     int NY;                           // k_lay_dw grid.y: splits the tile-block list
-    int dw_items;
+    int NLK;                          // workgroups of k_lay_lik
+    int dw_items;                     // tile blocks over all layers
     // the fused tail (k_lay_tail): layers l0 .. nl-1 (all narrow enough) + likelihood + their delta chain in ONE launch
     int l0;                           // nl: no tail
     int TT;                           // its compile-time tile bound: 2 or 4
@@ -66,6 +67,7 @@ __device__ __forceinline__ void lay_block_store(float* p, const f32x4& v) {
     *reinterpret_cast<f32x4*>(p) = v;
 #endif
 }
+#define LAY_RSRC_FLAGS 0x00020000           // raw buffer resources (as kernels_wide.hpp)
 static inline int lay_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 static inline void lay_plan_shape(const NetDev& nd, LayPlan& p) {
@@ -76,7 +78,7 @@ static inline void lay_plan_shape(const NetDev& nd, LayPlan& p) {
     for (int l = 0; l < nd.nl; ++l) { p.wOff[l] = o; o += 256 * p.TO[l] * p.TK[l]; }
     for (int l = 0; l < nd.nl; ++l) { p.tOff[l] = o; if (l >= 1) o += 256 * p.TM[l - 1] * p.TM[l]; }
     p.img_floats = (o + 3) & ~3;
-    p.ntiles = 0; p.store_floats = 0; p.NS = 1; p.NY = 1; p.dw_items = 0;
+    p.ntiles = 0; p.store_floats = 0; p.NS = 1; p.NY = 1; p.NLK = 1; p.dw_items = 0;
     // the longest suffix of layers whose tile counts all fit the tail kernel's register arrays (<= 4 tiles = 63 units + ones slot)
     p.l0 = nd.nl; p.TT = 2;
     while (p.l0 >= 1 && p.TK[p.l0 - 1] <= 4 && p.TO[p.l0 - 1] <= 4 && p.TM[p.l0 - 1] <= 4) --p.l0;
@@ -84,21 +86,42 @@ static inline void lay_plan_shape(const NetDev& nd, LayPlan& p) {
     if (const char* e = getenv("TBNN_LAY_TAIL")) if (atoi(e) == 0) p.l0 = nd.nl;       // A/B runs: one launch per layer and direction
     p.GT = 1; p.NP = 1; p.tail = 0;
 }
+// k_lay_dw's tile blocks: LAY_DBU output tiles x LAY_DBK input tiles per wave.  The kernel is bound by operand traffic (an operand
+// block feeds LAY_DBK resp. LAY_DBU MFMAs per k-step): 4 x 4 blocks load 0.5 blocks per MFMA.  8 x 4 blocks (0.375; -DLAY_DBU=8)
+// need 256 + 256 registers, one wave per SIMD, and run SLOWER: 8 -> 300 -> 300 -> 1 at 5e4 rows 180 us against 122 us.
+#ifndef LAY_DBU
+#define LAY_DBU 4
+#endif
+#define LAY_DBK 4
 static inline void lay_plan_rows(const NetDev& nd, long n, LayPlan& p) {
     p.ntiles = (n + 15) / 16;
     long o = 0;
     for (int l = 0; l <= nd.nl; ++l) { p.aOff[l] = o; o += p.ntiles * 256 * (l < nd.nl ? p.TK[l] : p.TM[nd.nl - 1]); }
     for (int l = 0; l < nd.nl; ++l) { p.dOff[l] = o; o += p.ntiles * 256 * p.TM[l]; }
     p.store_floats = o;
-    p.NS = (int)std::max<long>(1, std::min<long>(256, p.ntiles / 8));
+    p.NLK = (int)std::max<long>(1, std::min<long>(256, p.ntiles / 8));
     p.dw_items = 0;
-    for (int l = 0; l < nd.nl; ++l) p.dw_items += lay_cdiv(p.TM[l], 4) * lay_cdiv(p.TK[l], 4);       // LAY_DB x LAY_DB tile blocks (k_lay_dw)
-    p.NY = std::max(1, std::min(8, lay_cdiv(p.dw_items, 4)));
-    // the tail's grid: at most 512 workgroups, every wave the same number of row tiles
-    const long rounds = std::max<long>(1, (p.ntiles + 2047) / 2048);
-    p.GT = (int)std::max<long>(1, (p.ntiles + 4 * rounds - 1) / (4 * rounds));
-    p.tail = p.l0 < nd.nl && p.ntiles < 2048;      // it saves launches; over many rows the separate GEMMs are as fast (measured: r03_notes)
-    p.NP = p.tail ? std::max(p.NS, p.GT) : p.NS;
+    for (int l = 0; l < nd.nl; ++l) p.dw_items += lay_cdiv(p.TM[l], LAY_DBU) * lay_cdiv(p.TK[l], LAY_DBK);       // tile blocks (k_lay_dw)
+    // k_lay_dw's grid: NY workgroups share out the tile blocks (one block per wave when that takes at most 16 of them), NS row
+    // ranges -- one gradient slab each -- so that NS x NY x 4 waves are about 2048 (2 per SIMD; its row loop is double-buffered),
+    // and no more: every (slab, block) pair pays an epilogue of ~640 vector instructions + 64 scattered stores, and k_update reads
+    // NS x P floats (8 -> 300 -> 300 -> 1 at 5e4 rows with round 3's 256 slabs: 95 MB, 12 row tiles per block and slab).
+    // Measured and not kept (round 4): (block, row range) pairs of EQUAL MFMA count from a host-built list (small blocks get long
+    // ranges), in item order 128-187 us, grouped by rows and dealt to the XCDs 146-180 us, against 121-125 us for this plain grid:
+    // the kernel is bound by operand traffic (every stored block is read by ~5 tile blocks: 600 MB per gradient at 8 -> 300 ->
+    // 300 -> 1), and the plain grid's co-resident waves walk the SAME rows at the same time.
+    p.NY = std::max(1, std::min(16, lay_cdiv(p.dw_items, 4)));
+    long waves = 2048;
+    if (const char* e = getenv("TBNN_LAY_DW_WAVES")) { const long w = atol(e); if (w >= 4) waves = w; }
+    const long ns_want = (waves + 4 * p.NY - 1) / (4 * p.NY);
+    p.NS = (int)std::max<long>(1, std::min<long>(std::min<long>(256, ns_want), p.ntiles / 8));
+    // the tail's grid: at most PSTAT_CAP workgroups (one statistic entry each) of four waves, every wave the same number of row
+    // tiles; its grid-stride loop takes whatever a clamped grid leaves
+    const long cap = 4L * PSTAT_CAP;
+    const long rounds = std::max<long>(1, (p.ntiles + cap - 1) / cap);
+    p.GT = (int)std::min<long>(PSTAT_CAP, std::max<long>(1, (p.ntiles + 4 * rounds - 1) / (4 * rounds)));
+    p.tail = p.l0 < nd.nl && p.ntiles < cap;       // it saves launches; over many rows the separate GEMMs are as fast (measured: r03_notes)
+    p.NP = p.tail ? std::max(p.NLK, p.GT) : p.NLK;
 }
 // theta index j -> image positions: map[j] (W_l, biases in the ones-slot column), map[P + j] (W_l^T; -1: none)
 static inline void lay_image_map(const NetDev& nd, const LayPlan& p, int* map) {
@@ -157,20 +180,26 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int t = 0; t < LAY_TB; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // operand pointers: tiles / row tiles past the end are CLAMPED to the last valid one (their accumulators are never stored),
-        // so that every load of the k loop is unconditional -- a guarded load is a branch, and branches between the loads keep
-        // them from being in flight together
-        const float* wp[LAY_TB]; const float* bp[RB];
+        // operands by buffer loads: tiles / row tiles past the end are CLAMPED to the last valid one (their accumulators are never
+        // stored), so every load of the k loop is unconditional; the lane's offsets are constant VGPRs per item, the k-group is an
+        // SGPR offset -- no vector instruction computes an address inside the k loop
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(img), 0, MT * 16 * wpitch * 4, LAY_RSRC_FLAGS);
+        const long rows_here = ntiles - rt0 < RB ? ntiles - rt0 : RB;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + (size_t)rt0 * KG * 256, 0, (int)rows_here * KG * 1024, LAY_RSRC_FLAGS);
+        int wv[LAY_TB], bo[RB];
 #pragma unroll
-        for (int t = 0; t < LAY_TB; ++t) { const int tt = t0 + t < MT ? t0 + t : MT - 1; wp[t] = img + (size_t)(16 * tt + i16) * wpitch + 4 * g; }
+        for (int t = 0; t < LAY_TB; ++t) { const int tt = t0 + t < MT ? t0 + t : MT - 1; wv[t] = ((16 * tt + i16) * wpitch + 4 * g) * 4; }
+        const int bv = (i16 * 16 + 4 * g) * 4;
 #pragma unroll
-        for (int r = 0; r < RB; ++r) { const long rr = rt0 + r < ntiles ? rt0 + r : ntiles - 1; bp[r] = in + (size_t)rr * KG * 256 + i16 * 16 + 4 * g; }
-        auto kstep = [&](int kg) __attribute__((always_inline)) {
-            f32x4 A[LAY_TB], B[RB];
+        for (int r = 0; r < RB; ++r) bo[r] = (r < rows_here ? r : (int)rows_here - 1) * KG * 1024;
+        // two operand sets: k-group kg + 1 is requested before the MFMAs of k-group kg
+        auto ldk = [&](f32x4 (&A)[LAY_TB], f32x4 (&B)[RB], int kg) __attribute__((always_inline)) {
 #pragma unroll
-            for (int r = 0; r < RB; ++r) B[r] = *reinterpret_cast<const f32x4*>(bp[r] + (size_t)kg * 256);
+            for (int r = 0; r < RB; ++r) B[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, bv, bo[r] + kg * 1024, 0));
 #pragma unroll
-            for (int t = 0; t < LAY_TB; ++t) A[t] = *reinterpret_cast<const f32x4*>(wp[t] + 16 * kg);
+            for (int t = 0; t < LAY_TB; ++t) A[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wv[t], kg * 64, 0));
+        };
+        auto mmk = [&](const f32x4 (&A)[LAY_TB], const f32x4 (&B)[RB]) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -178,9 +207,25 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
 #pragma unroll
                     for (int r = 0; r < RB; ++r) acc[r][t] = mfma16(A[t][j], B[r][j], acc[r][t]);
         };
+        auto kloop = [&](int k0, int k1) __attribute__((always_inline)) {       // k-groups [k0, k1)
+            if (k1 <= k0) return;
+            f32x4 A0[LAY_TB], B0[RB], A1[LAY_TB], B1[RB];
+            ldk(A0, B0, k0);
+            int kg = k0;
+            for (; kg + 2 <= k1; kg += 2) {
+                ldk(A1, B1, kg + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mmk(A0, B0);
+                ldk(A0, B0, kg + 2 < k1 ? kg + 2 : k1 - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mmk(A1, B1);
+            }
+            if (kg < k1) mmk(A0, B0);
+        };
         if (SK) {
+            // (underfilled, latency-bound: eight k-groups of loads in flight per wave rather than two)
 #pragma unroll 8
-            for (int kg = k_lo; kg < k_hi; ++kg) kstep(kg);
+            for (int kg = k_lo; kg < k_hi; ++kg) { f32x4 A[LAY_TB], B[RB]; ldk(A, B, kg); mmk(A, B); }
             // partial tiles -> LDS; wave w finishes the (r, t) pairs with (r * LAY_TB + t) % 4 == w, summing the waves in fixed order
 #pragma unroll
             for (int r = 0; r < RB; ++r)
@@ -198,8 +243,7 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
                     acc[r][t] = s4;
                 }
         } else {
-#pragma unroll 4
-            for (int kg = 0; kg < KG; ++kg) kstep(kg);
+            kloop(0, KG);
         }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -210,13 +254,43 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
                 if (SK && (r * LAY_TB + t) % 4 != wave) continue;
                 f32x4 v;
                 const int u0 = 16 * (t0 + t) + 4 * g;
+                const bool whole = 16 * (t0 + t) + 16 <= n_units;          // wave-uniform: no padding, no ones slot in this tile
+                // (the activation switch is taken once per tile, not per element: act is wave-uniform)
                 if (MODE == 0) {
+                    f32x4 z = acc[r][t];
+                    switch (act) {
+                        case TBNN_ACT_RELU:
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = u0 + j < n_units ? act_fwd(acc[r][t][j], act) : (u0 + j == ones_slot ? 1.f : 0.f);
+                            for (int j = 0; j < 4; ++j) z[j] = fmaxf(z[j], 0.f);
+                            break;
+                        case TBNN_ACT_NONE: break;
+                        default:
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) z[j] = act_fwd(z[j], act);
+                    }
+                    if (whole) v = z;
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = u0 + j < n_units ? z[j] : (u0 + j == ones_slot ? 1.f : 0.f);
+                    }
                 } else {
                     const f32x4 a = *reinterpret_cast<const f32x4*>(aux + ((size_t)(rt0 + r) * auxT + t0 + t) * 256 + i16 * 16 + 4 * g);
+                    f32x4 z = acc[r][t];
+                    switch (act) {
+                        case TBNN_ACT_RELU:
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = u0 + j < n_units ? acc[r][t][j] * act_bwd(a[j], act) : 0.f;
+                            for (int j = 0; j < 4; ++j) z[j] = a[j] > 0.f ? z[j] : 0.f;
+                            break;
+                        case TBNN_ACT_NONE: break;
+                        default:
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) z[j] = z[j] * act_bwd(a[j], act);
+                    }
+                    if (whole) v = z;
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = u0 + j < n_units ? z[j] : 0.f;
+                    }
                 }
                 lay_block_store(outb + ((size_t)(rt0 + r) * MT + t0 + t) * 256 + i16 * 16 + 4 * g, v);
             }
@@ -289,13 +363,65 @@ __global__ __launch_bounds__(256) void k_lay_lik(NetDev nd, const float* __restr
 }
 
 // dW_l[u][k] = sum over rows dz_l[row][u] [a_l, 1][row][k], every layer, over this workgroup's row tiles; output tiles in
-// blocks of up to LAY_DB x LAY_DB (an operand block feeds LAY_DB MFMAs), dealt out over the waves (and over grid.y); every
+// blocks of up to LAY_DBU x LAY_DBK (an operand block feeds LAY_DBK resp. LAY_DBU MFMAs), dealt out over the waves (and over grid.y); every
 // entry of the slab is written by exactly one wave.
-#define LAY_DB 4
-static inline int lay_dw_items(const LayPlan& p) {
-    int c = 0;
-    for (int l = 0; l < p.nl; ++l) c += ((p.TM[l] + LAY_DB - 1) / LAY_DB) * ((p.TK[l] + LAY_DB - 1) / LAY_DB);
-    return c;
+// The row loop of one item.  Every operand is a buffer load: the resource is rebuilt per row tile from a wave-uniform pointer
+// (SALU), the lane's offset is one of four constant VGPRs (lane-linear read of a block + 256 B per k-step), the block inside the
+// item an SGPR offset -- no vector instruction computes an address.  (Round 3 indexed global pointers: 2.1 VALU and 3.2 SALU
+// instructions per MFMA, the MFMA pipe 52 % busy: on this chip the f32 MFMA and the VALU share their issue.)
+template <int NU, int NK>
+__device__ __forceinline__ void lay_dw_rows(const float* dz0, const float* a0, long TMs, long TKs, long cnt, int lane, f32x4 (&acc)[LAY_DBU][LAY_DBK]) {
+    int vo[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vo[s] = lane * 4 + 256 * s;
+    // two operand sets: the next row tile's loads are issued BEFORE this one's MFMAs (the waves of a SIMD then need not cover a
+    // whole memory round trip per row tile: 2048 waves ran at 155 us, 4096 at 123 us before this)
+    auto ld = [&](float (&A)[NU][4], float (&B)[NK][4], long rt) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz0 + rt * TMs), 0, NU * 1024, LAY_RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a0 + rt * TKs), 0, NK * 1024, LAY_RSRC_FLAGS);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int a = 0; a < NU; ++a) A[a][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, vo[s], 1024 * a, 0));
+#pragma unroll
+            for (int b = 0; b < NK; ++b) B[b][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, vo[s], 1024 * b, 0));
+        }
+    };
+    auto mma = [&](const float (&A)[NU][4], const float (&B)[NK][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int a = 0; a < NU; ++a)
+#pragma unroll
+                for (int b = 0; b < NK; ++b) acc[a][b] = mfma16(A[a][s], B[b][s], acc[a][b]);
+    };
+    float A0[NU][4], B0[NK][4], A1[NU][4], B1[NK][4];
+    ld(A0, B0, 0);
+    long rt = 0;
+    for (; rt + 2 <= cnt; rt += 2) {
+        ld(A1, B1, rt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(A0, B0);
+        ld(A0, B0, rt + 2 < cnt ? rt + 2 : cnt - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(A1, B1);
+    }
+    if (rt < cnt) mma(A0, B0);
+}
+// the block's size is wave-uniform: one instantiation per (nu, nk), so that no MFMA is tested and no operand block is loaded in vain
+__device__ __forceinline__ void lay_dw_rows_any(int nu, int nk, const float* dz0, const float* a0, long TMs, long TKs, long cnt, int lane,
+                                                f32x4 (&acc)[LAY_DBU][LAY_DBK]) {
+#define LAY_DW_CASE(U, K) case (U) * 8 + (K): lay_dw_rows<U, K>(dz0, a0, TMs, TKs, cnt, lane, acc); break;
+#define LAY_DW_ROW(U) LAY_DW_CASE(U, 1) LAY_DW_CASE(U, 2) LAY_DW_CASE(U, 3) LAY_DW_CASE(U, 4)
+    switch (nu * 8 + nk) {
+        LAY_DW_ROW(1) LAY_DW_ROW(2) LAY_DW_ROW(3) LAY_DW_ROW(4)
+#if LAY_DBU == 8
+        LAY_DW_ROW(5) LAY_DW_ROW(6) LAY_DW_ROW(7) LAY_DW_ROW(8)
+#endif
+        default: break;
+    }
+#undef LAY_DW_ROW
+#undef LAY_DW_CASE
 }
 __global__ __launch_bounds__(256) void k_lay_dw(NetDev nd, LayPlan p, const float* __restrict__ store, float* __restrict__ slabs, int pitch) {
     const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -304,47 +430,27 @@ __global__ __launch_bounds__(256) void k_lay_dw(NetDev nd, LayPlan p, const floa
     float* slab = slabs + (size_t)blockIdx.x * pitch;
     for (int item = wave + 4 * blockIdx.y; item < p.dw_items; item += 4 * gridDim.y) {
         int l = 0, rem = item;
-        for (; l < p.nl; ++l) { const int c = ((p.TM[l] + LAY_DB - 1) / LAY_DB) * ((p.TK[l] + LAY_DB - 1) / LAY_DB); if (rem < c) break; rem -= c; }
-        const int KB = (p.TK[l] + LAY_DB - 1) / LAY_DB;
-        const int tu0 = LAY_DB * (rem / KB), tk0 = LAY_DB * (rem % KB);
+        for (; l < p.nl; ++l) { const int c = ((p.TM[l] + LAY_DBU - 1) / LAY_DBU) * ((p.TK[l] + LAY_DBK - 1) / LAY_DBK); if (rem < c) break; rem -= c; }
+        const int KB = (p.TK[l] + LAY_DBK - 1) / LAY_DBK;
+        const int tu0 = LAY_DBU * (rem / KB), tk0 = LAY_DBK * (rem % KB);
         const int TMl = p.TM[l], TKl = p.TK[l];
-        const int nu = TMl - tu0 < LAY_DB ? TMl - tu0 : LAY_DB, nk = TKl - tk0 < LAY_DB ? TKl - tk0 : LAY_DB;     // wave-uniform
-        const float* dzb = store + p.dOff[l] + lane;
-        const float* ab = store + p.aOff[l] + lane;
-        f32x4 acc[LAY_DB][LAY_DB];
+        const int nu = TMl - tu0 < LAY_DBU ? TMl - tu0 : LAY_DBU, nk = TKl - tk0 < LAY_DBK ? TKl - tk0 : LAY_DBK;     // wave-uniform
+        f32x4 acc[LAY_DBU][LAY_DBK];
 #pragma unroll
-        for (int a = 0; a < LAY_DB; ++a)
+        for (int a = 0; a < LAY_DBU; ++a)
 #pragma unroll
-            for (int b = 0; b < LAY_DB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (long rt = lo; rt < hi; ++rt) {
-            const float* d0 = dzb + ((size_t)rt * TMl + tu0) * 256;
-            const float* a0 = ab + ((size_t)rt * TKl + tk0) * 256;
-            float A[LAY_DB][4], B[LAY_DB][4];
-            // unconditional loads (blocks past the end clamped: their MFMAs are skipped, wave-uniformly)
-#pragma unroll
-            for (int a = 0; a < LAY_DB; ++a)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    A[a][s] = d0[256 * (a < nu ? a : nu - 1) + 64 * s];
-                    B[a][s] = a0[256 * (a < nk ? a : nk - 1) + 64 * s];
-                }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int a = 0; a < LAY_DB; ++a) {
-                    if (a >= nu) continue;
-#pragma unroll
-                    for (int b = 0; b < LAY_DB; ++b)
-                        if (b < nk) acc[a][b] = mfma16(A[a][s], B[b][s], acc[a][b]);
-                }
+            for (int b = 0; b < LAY_DBK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (hi > lo) {
+            const float* dz0 = store + p.dOff[l] + ((size_t)lo * TMl + tu0) * 256;
+            const float* a0 = store + p.aOff[l] + ((size_t)lo * TKl + tk0) * 256;
+            lay_dw_rows_any(nu, nk, dz0, a0, (long)TMl * 256, (long)TKl * 256, hi - lo, lane, acc);
         }
         // D[m][n]: lane (i, g) reg j = dW[unit 16 tu + 4 g + j][slot 16 tk + i]
         const int in = nd.in[l], out = nd.out[l];
 #pragma unroll
-        for (int a = 0; a < LAY_DB; ++a)
+        for (int a = 0; a < LAY_DBU; ++a)
 #pragma unroll
-            for (int b = 0; b < LAY_DB; ++b) {
+            for (int b = 0; b < LAY_DBK; ++b) {
                 if (a >= nu || b >= nk) continue;
                 const int k = 16 * (tk0 + b) + i16;
 #pragma unroll
@@ -526,7 +632,7 @@ static inline int lay_launch(const NetDev& nd, const LayPlan& p, hipStream_t st,
         lb = (p.l0 > 1 ? p.l0 : 1) - 1;
     } else {
         lay_forward_chain(nd, p, st, img, store);
-        hipLaunchKernelGGL(k_lay_lik, dim3(p.NS), dim3(256), 0, st, nd, eta, (const float*)(store + p.aOff[nd.nl]), Y, n, p.TM[L], store + p.dOff[L], pstat);
+        hipLaunchKernelGGL(k_lay_lik, dim3(p.NLK), dim3(256), 0, st, nd, eta, (const float*)(store + p.aOff[nd.nl]), Y, n, p.TM[L], store + p.dOff[L], pstat);
         lb = L;
     }
     for (int l = lb; l >= 1; --l)

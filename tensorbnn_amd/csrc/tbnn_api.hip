@@ -37,7 +37,6 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define NEED(h)                                                                                \
     do { if (!(h)) return fail(-1, "null handle"); } while (0)
 
-#define PSTAT_CAP 512                     // entries of the per-workgroup statistic buffer (>= any grid)
 
 struct tbnn_comm {
     ncclComm_t comm = nullptr;
@@ -56,6 +55,7 @@ struct tbnn_ctx {
     int fast_ver = 1;                     // 1: kernels_fast.hpp, 3: kernels_fast3.hpp (fringe units off the 16x16 tiles)
     int mid_id = -1;                      // >= 0: kernels_mid.hpp (mid-width fused kernel; narrow-family workspace and launch signature)
     bool lay = false; LayPlan lplan{}; float* lstore = nullptr;   // kernels_layered.hpp: run-time-shape MFMA kernels, activations through HBM
+    float* lfwd = nullptr; size_t lfwd_floats = 0;                // its forward-only store (predict / metrics / ensembles): pooled, grown as needed
     std::string kernel_name;
     // data
     float* dX = nullptr; float* dY = nullptr; bool own_data = false; long n = 0;
@@ -212,6 +212,7 @@ extern "C" int tbnn_destroy(tbnn_handle h) {
     if (h->sc) hipFree(h->sc);
     if (h->sc_out) hipFree(h->sc_out);
     if (h->lstore) hipFree(h->lstore);
+    if (h->lfwd) hipFree(h->lfwd);
     if (h->trace) hipFree(h->trace);
     if (h->d_recs) hipFree(h->d_recs);
     if (h->h_recs) hipHostFree(h->h_recs);
@@ -772,11 +773,20 @@ static int narrow_forward(tbnn_ctx* h, int nets, const float* imgs, long img_str
 // the layered family's forward chain (network.predict) on a store of its own: the rows are packed once, then any number of
 // networks run over them
 struct LayFwd { LayPlan pp{}; float* st = nullptr; long n = 0; };
+// (the store is pooled on the chain, like the record buffers of tbnn_hmc_run: network.train predicts and scores every displayed
+// epoch, and an allocation + a device synchronisation + a free per call is what that cost before round 4; everything runs in
+// order on the chain's one stream, so the next call may overwrite it)
 static int lay_fwd_prepare(tbnn_ctx* h, const float* dX, long n, LayFwd& lf) {
     const NetDev& nd = h->nd;
     lf.pp = h->lplan; lf.n = n;
     lay_plan_rows(nd, n, lf.pp);
-    HIPCHK(hipMalloc(&lf.st, (size_t)(lf.pp.aOff[nd.nl] + lf.pp.ntiles * 256 * lf.pp.TM[nd.nl - 1]) * sizeof(float)));
+    const size_t need = (size_t)(lf.pp.aOff[nd.nl] + lf.pp.ntiles * 256 * lf.pp.TM[nd.nl - 1]);
+    if (h->lfwd_floats < need) {
+        if (h->lfwd) { hipFree(h->lfwd); h->lfwd = nullptr; h->lfwd_floats = 0; }
+        HIPCHK(hipMalloc(&h->lfwd, need * sizeof(float)));
+        h->lfwd_floats = need;
+    }
+    lf.st = h->lfwd;
     hipLaunchKernelGGL(k_lay_pack_x, dim3((int)std::min<long>(lf.pp.ntiles * lf.pp.TK[0], 4096)), dim3(256), 0, h->stream, dX, n, nd.d_in, lf.pp.TK[0],
                        lf.pp.ntiles, lf.st + lf.pp.aOff[0]);
     HIPCHK(hipGetLastError());
@@ -791,7 +801,6 @@ static int lay_fwd_run(tbnn_ctx* h, const LayFwd& lf, const float* q, float* dOu
     if (hipGetLastError() != hipSuccess) return fail(-2, "layered forward launch failed");
     return 0;
 }
-static void lay_fwd_release(LayFwd& lf) { if (lf.st) hipFree(lf.st); lf.st = nullptr; }
 
 // forward pass of the network at the weights q (device) over dX[n][d_in] -> dOut[d_out][n], on h->stream
 static int launch_forward(tbnn_ctx* h, const float* q, const float* dX, long n, float* dOut) {
@@ -810,8 +819,6 @@ static int launch_forward(tbnn_ctx* h, const float* q, const float* dX, long n, 
         LayFwd lf;
         int rc = lay_fwd_prepare(h, dX, n, lf);
         if (!rc) rc = lay_fwd_run(h, lf, q, dOut);
-        hipStreamSynchronize(h->stream);
-        lay_fwd_release(lf);
         return rc;
     }
     if (narrow_fwd_ok(h)) {
@@ -947,8 +954,6 @@ extern "C" int tbnn_forward_many(tbnn_handle h, const float* thetas, int32_t m, 
             LayFwd lf;
             rc = lay_fwd_prepare(h, dX, rows, lf);
             for (int i = 0; i < c && !rc; ++i) rc = lay_fwd_run(h, lf, dTh + (size_t)i * nd.P, dOut + (size_t)i * per_net);
-            hipStreamSynchronize(h->stream);
-            lay_fwd_release(lf);
         } else {
             for (int i = 0; i < c && !rc; ++i) rc = launch_forward(h, dTh + (size_t)i * nd.P, dX, rows, dOut + (size_t)i * per_net);
         }

@@ -148,9 +148,19 @@ def source(dims, hact, lact, bern, family) -> str:
             f'extern "C" int tbnn_jit_ops(FusedOps* o) {{ JitNarrow<S, {f3}>::fill(o); return 0; }}\n')
 
 
+_WARNED = set()
+
+
 def _warn_generic(dims, why):
-    print(f"tensorbnn_amd: note: network {dims} runs on the layered run-time-shape MFMA kernels (kernels_layered.hpp), not on a fused "
-          f"kernel: {why}", file=sys.stderr, flush=True)
+    """once per shape and process, as a RuntimeWarning (visible to `-W error`, logging.captureWarnings, pytest): the layered
+    family is 2-3x slower than a fused kernel where both apply, and only the kernel's name would tell otherwise"""
+    import warnings
+    key = (tuple(dims), why.split(":")[0])
+    if key in _WARNED:
+        return
+    _WARNED.add(key)
+    warnings.warn(f"tensorbnn_amd: network {list(dims)} runs on the layered run-time-shape MFMA kernels (kernels_layered.hpp), "
+                  f"not on a fused kernel: {why}", RuntimeWarning, stacklevel=3)
 
 
 def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Optional[str]:

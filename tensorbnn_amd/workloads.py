@@ -51,13 +51,13 @@ WORKLOADS = {
 }
 for _w in WORKLOADS.values():
     _w.setdefault("prior", nat.PRIOR_CAUCHY)
-_GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
-def burned_state(cfg: str):
-    """the committed burned-in chain state of a config (tools/make_burned.py), or None: dict with theta, eta, eps, L,
-    accept and, for configs[4], the dual-averaging state of the hyper step size"""
-    path = os.path.join(_GOLDEN, f"{cfg}_burned.npz")
+def burned_state(cfg: str, directory: str):
+    """a burned-in chain state of a config written by tools/make_burned.py into `directory` (the caller says where its fixtures
+    live: bench.py passes tests/golden), or None: dict with theta, eta, eps, L, accept and, for configs[4], the dual-averaging
+    state of the hyper step size"""
+    path = os.path.join(directory, f"{cfg}_burned.npz")
     if not os.path.exists(path):
         return None
     z = np.load(path)

@@ -38,3 +38,28 @@ def pytest_collection_modifyitems(config, items):
 def native():
     from tensorbnn_amd import _native
     return _native
+
+
+def wait_gpu_quiet(timeout=30.0):
+    """Multi-process tests share ONE card with this process, and the GPU box admits only a few processes on it at once: before
+    starting ranks, wait until no process but this one holds the GPU any more (the ranks of the previous test may still be
+    tearing their contexts down, and a launcher that merely imported torch holds /dev/kfd too)."""
+    import time
+    me = os.getpid()
+    t0 = time.time()
+    while True:
+        others = []
+        for p in os.listdir("/proc"):
+            if not p.isdigit() or int(p) == me:
+                continue
+            try:
+                for fd in os.listdir(f"/proc/{p}/fd"):
+                    tgt = os.readlink(f"/proc/{p}/fd/{fd}")
+                    if tgt.endswith("/kfd") or "renderD" in tgt:
+                        others.append(int(p))
+                        break
+            except OSError:
+                continue
+        if not others or time.time() - t0 > timeout:
+            return others
+        time.sleep(0.25)

@@ -33,6 +33,8 @@ def build_stub():
 
 
 def run_world(mode, world, tmp_path):
+    from conftest import wait_gpu_quiet
+    wait_gpu_quiet()
     env = dict(os.environ, TBNN_RCCL_LIB=build_stub(), TBNN_JIT="0")
     idfile = str(tmp_path / f"{mode}.id")
     procs = []
@@ -65,7 +67,7 @@ def test_gather_two_ranks(tmp_path):
 
 
 def test_gather_four_ranks(tmp_path):
-    """the same at world = 4 (as many ranks as the GPU box's process limit leaves room for next to this process)"""
+    """the same at world = 4 (the GPU box admits six processes on its card: this one and four ranks leave one to spare)"""
     res = run_world("gather", 4, tmp_path)
     for it in range(3):
         g0 = res[0][f"g{it}"]

@@ -325,7 +325,7 @@ def test_burned_fixtures_are_consistent():
     from tensorbnn_amd.workloads import WORKLOADS, burned_state
     gold = os.path.join(ROOT, "tests", "golden")
     for cfg, wl in WORKLOADS.items():
-        b = burned_state(cfg)
+        b = burned_state(cfg, os.path.join(ROOT, "tests", "golden"))
         assert b is not None, cfg
         dims = wl["dims"]
         P = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
