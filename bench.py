@@ -374,6 +374,39 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
     return line
 
 
+def run_chain_group(name, n_chains, steps, warmup, dev):
+    """`n_chains` independent chains of workload `name` on ONE GPU behind one handle (tbnn_create_multi: the per-chain kernels of all
+    chains are one launch each, gridDim.y = chain; every chain is bit for bit its solo self, tests/test_gpu_multichain.py).  A
+    SECONDARY figure: the headline configs are one chain per GPU by definition.  Small problems -- the reference's own examples --
+    are bound by launch latency with most of the GPU idle; this is what a user who wants several chains gets on one card."""
+    import numpy as np
+    import torch
+    from tensorbnn_amd import _native as nat
+    from tensorbnn_amd.workloads import WORKLOADS, burned_state, synth_problem
+    wl = WORKLOADS[name]
+    layers, lik, X, Y, theta0, eta0 = synth_problem(wl["dims"], wl["n"], prior=wl["prior"], likelihood=wl["lik"])
+    b = burned_state(name, os.path.join(ROOT, "tests", "golden"))
+    theta0, eta0, eps = b["theta"].astype(np.float32), b["eta"].astype(np.float32), float(b["eps"])
+    g = nat.ChainGroup(layers, n_chains, likelihood=lik, device=dev, seed=50, chain_id=0)
+    dX, dY = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
+    torch.cuda.synchronize()
+    g.set_data_device(dX.data_ptr(), dY.data_ptr(), wl["n"]); g.set_state(theta0); g.set_hypers(eta0)
+    g.hmc_run(eps, wl["L"], warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = g.hmc_run(eps, wl["L"], steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kname = g.kernel_name
+    g.close()
+    del dX, dY
+    return {"value": round(n_chains * steps * wl["L"] / dt, 1), "unit": "leapfrog steps/s (all chains of the group)", "chains_on_one_gpu": n_chains,
+            "per_chain": round(steps * wl["L"] / dt, 1), "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+            "accept_ratio": round(float(np.mean([o["accept_prob"] for c in outs for o in c])), 4),
+            "config": {"workload": wl["text"], "leapfrog_per_step": wl["L"], "eps": eps, "kernel": kname,
+                       "how": "tbnn_create_multi: one handle, gridDim.y = chain; chain c == the solo chain with chain_id c"}}
+
+
 def _short_cpu(c):
     if not c:
         return None
@@ -418,6 +451,9 @@ def compact_line(line):
         for key, r in line["secondary"].items():
             if "error" in r:
                 sec[key] = r
+                continue
+            if "chains_on_one_gpu" in r:
+                sec["configs[0]x64"] = {"value": r["value"], "chains": r["chains_on_one_gpu"], "per_chain": r["per_chain"], "accept": r["accept_ratio"]}
                 continue
             e = {"value": r["value"], "ms_per_step": r["ms_per_step"], "accept": r["accept_ratio"], "L": r["config"]["leapfrog_per_step"]}
             rf = r.get("roofline") or {}
@@ -557,6 +593,10 @@ def main():
                 sec[CONFIG_KEY[name]] = r
             except Exception as e:           # a secondary line must never take the headline line down with it
                 sec[CONFIG_KEY[name]] = {"error": repr(e)[:300]}
+        try:                                 # several chains on one GPU (secondary: small problems are launch-bound)
+            sec["configs[0] x64 chains on one GPU"] = run_chain_group("c1", 64, 100, 10, dev)
+        except Exception as e:
+            sec["configs[0] x64 chains on one GPU"] = {"error": repr(e)[:300]}
         line["secondary"] = sec
     if rank == 0:
         # the whole record (long `sample` / `workload` texts, thread scans, torch cross-check) goes to stderr and to

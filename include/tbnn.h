@@ -99,6 +99,19 @@ int tbnn_device_count(void);
  * tf.random.set_seed(50) (network.py:562). */
 int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed, uint32_t chain_id,
                 tbnn_handle* out);
+/* Several independent chains of one network on ONE device behind one handle (round 4).  SURVEY 8(e) puts one chain on each
+ * GPU; small problems -- the reference's own examples: Examples/trainRegression.py:33 has 11 rows -- leave most of a GPU idle
+ * and are bound by launch latency, so the per-chain kernels of all n_chains chains run as ONE launch each (gridDim.y = chain).
+ * Chain c is bit for bit the chain tbnn_create(desc, device, seed, chain_id + c) would be, at the same step size and leapfrog
+ * count for all (they advance in lockstep).  On such a handle
+ *   tbnn_set_state / tbnn_get_state take [n_chains][P] floats, tbnn_set_hypers / tbnn_get_hypers [n_chains][H];
+ *   tbnn_hmc_run fills outs[chain][epoch], tbnn_hmc_step and tbnn_hyper_step out[chain] (no injected draws, no trace);
+ *   tbnn_set_data[_device], tbnn_set_validation, tbnn_forward / tbnn_predict / tbnn_metrics with an explicit theta,
+ *   tbnn_forward_many and tbnn_hyper_probs_many work as usual; everything that addresses ONE chain's state (tbnn_logp_grad,
+ *   tbnn_hyper_logp_grad, theta == NULL predictions, tbnn_gather_samples, tbnn_set_row_shard) returns an error. */
+int tbnn_create_multi(const tbnn_net_desc* desc, int device, uint64_t seed, uint32_t chain_id, int32_t n_chains,
+                      tbnn_handle* out);
+int tbnn_chain_count(tbnn_handle h);  /* 1 for tbnn_create */
 int tbnn_destroy(tbnn_handle h);
 int tbnn_param_count(tbnn_handle h);  /* P */
 int tbnn_hyper_count(tbnn_handle h);  /* H */

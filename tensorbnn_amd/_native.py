@@ -57,6 +57,8 @@ SYMBOLS = [
     ("tbnn_build_id", C.c_char_p, []),
     ("tbnn_device_count", C.c_int, []),
     ("tbnn_create", C.c_int, [C.POINTER(NetDesc), C.c_int, C.c_uint64, C.c_uint32, C.POINTER(_H)]),
+    ("tbnn_create_multi", C.c_int, [C.POINTER(NetDesc), C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.POINTER(_H)]),
+    ("tbnn_chain_count", C.c_int, [_H]),
     ("tbnn_destroy", C.c_int, [_H]),
     ("tbnn_param_count", C.c_int, [_H]),
     ("tbnn_hyper_count", C.c_int, [_H]),
@@ -338,6 +340,92 @@ class Chain:
     def set_row_shard(self, comm: Optional["Comm"], n_total: int = 0):
         """row-sharded single chain: this rank's set_data rows are one block of n_total rows (None: back to unsharded)"""
         _check(lib.tbnn_set_row_shard(self._h, comm._c if comm is not None else None, int(n_total)))
+
+
+class ChainGroup:
+    """n_chains independent chains of one network on ONE device behind one handle (tbnn_create_multi): chain c is bit for bit
+    what Chain(..., chain_id=chain_id + c) would be; their per-chain kernels run as one launch each (gridDim.y = chain), so
+    small problems -- bound by launch latency, most of the GPU idle -- advance n_chains chains in the time of one."""
+
+    def __init__(self, layers: Sequence[tuple], n_chains: int, likelihood: int = LIK_GAUSSIAN, fixed_sd: float = 0.1,
+                 device: int = 0, seed: int = 50, chain_id: int = 0, kernel: int = KERNEL_AUTO, jit: Optional[bool] = None):
+        arr = (LayerDesc * len(layers))(*[LayerDesc(*map(int, l)) for l in layers])
+        self._layers_keepalive = arr
+        desc = NetDesc(len(layers), arr, int(likelihood), float(fixed_sd), int(kernel), 0)
+        if kernel != KERNEL_GENERIC:
+            from . import jit as _jit
+            if (jit if jit is not None else _jit.enabled()) and lib.tbnn_fused_kernel_available(C.byref(desc)) == 0:
+                _jit.ensure_registered(layers, likelihood)
+        h = _H()
+        _check(lib.tbnn_create_multi(C.byref(desc), int(device), int(seed), int(chain_id), int(n_chains), C.byref(h)))
+        self._h = h
+        self.C = lib.tbnn_chain_count(h)
+        self.P = lib.tbnn_param_count(h)
+        self.H = lib.tbnn_hyper_count(h)
+        self.d_in, self.d_out, self.n = int(layers[0][0]), int(layers[-1][1]), 0
+
+    @property
+    def kernel_name(self) -> str:
+        return lib.tbnn_kernel_name(self._h).decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.tbnn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_data(self, X, Y):
+        X = _f32(X).reshape(-1, self.d_in)
+        Y = _f32(Y).reshape(X.shape[0], self.d_out)
+        self.n = X.shape[0]
+        _check(lib.tbnn_set_data(self._h, _p(X), _p(Y), self.n))
+
+    def set_data_device(self, dX_ptr: int, dY_ptr: int, n: int):
+        self.n = int(n)
+        _check(lib.tbnn_set_data_device(self._h, C.c_void_p(dX_ptr), C.c_void_p(dY_ptr), self.n))
+
+    def set_state(self, thetas):
+        """[n_chains, P], or [P] for every chain alike"""
+        th = np.ascontiguousarray(np.broadcast_to(_f32(thetas).reshape(-1, self.P), (self.C, self.P)))
+        _check(lib.tbnn_set_state(self._h, _p(th)))
+
+    def get_state(self) -> np.ndarray:
+        out = np.empty((self.C, self.P), dtype=np.float32)
+        _check(lib.tbnn_get_state(self._h, _p(out)))
+        return out
+
+    def set_hypers(self, etas):
+        et = np.ascontiguousarray(np.broadcast_to(_f32(etas).reshape(-1, self.H), (self.C, self.H)))
+        _check(lib.tbnn_set_hypers(self._h, _p(et)))
+
+    def get_hypers(self) -> np.ndarray:
+        out = np.empty((self.C, self.H), dtype=np.float32)
+        _check(lib.tbnn_get_hypers(self._h, _p(out)))
+        return out
+
+    def hmc_run(self, eps: float, L: int, n_epochs: int):
+        """n_epochs transitions of every chain with no host round trip: list over chains of lists of records"""
+        outs = (StepOut * (self.C * n_epochs))()
+        _check(lib.tbnn_hmc_run(self._h, float(eps), int(L), int(n_epochs), outs))
+        return [[outs[c * n_epochs + e].as_dict() for e in range(n_epochs)] for c in range(self.C)]
+
+    def hmc_step(self, eps: float, L: int):
+        outs = (StepOut * self.C)()
+        _check(lib.tbnn_hmc_step(self._h, float(eps), int(L), None, None, outs, None))
+        return [o.as_dict() for o in outs]
+
+    def hyper_step(self, eps_h: float, L_h: int):
+        outs = (StepOut * self.C)()
+        _check(lib.tbnn_hyper_step(self._h, float(eps_h), int(L_h), None, None, outs))
+        return [o.as_dict() for o in outs]
+
+    def set_epoch(self, epoch: int):
+        _check(lib.tbnn_set_epoch(self._h, int(epoch)))
 
 
 COMM_ID_BYTES = 128

@@ -56,6 +56,11 @@ __device__ __forceinline__ void store16(float* ptr, const tb_f32x4& v) {
     else *reinterpret_cast<tb_f32x4*>(ptr) = v;
 }
 
+// Several chains in one launch (round 4): a handle created with tbnn_create_multi keeps its C chains' buffers as [C][...]
+// arrays and launches the per-chain kernels with gridDim.y = C; blockIdx.y picks the chain.  Strides the kernels cannot derive
+// from NetDev travel in this struct (all zero for one chain: blockIdx.y is 0 then anyway).
+struct ChainStride { long img, eta, slab; };
+
 // Per-chain scalar record kept on the device (doubles: energies are summed
 // and differenced in fp64 -- strictly more accurate than the reference's fp32).
 struct Scal {

@@ -6,7 +6,7 @@
 #include "common.hpp"
 #include "wide_api.hpp"
 
-#define TBNN_JIT_ABI 3
+#define TBNN_JIT_ABI 4
 enum { TBNN_FAMILY_NARROW = 1, TBNN_FAMILY_WIDE = 2 };
 
 struct FusedOps {
@@ -19,8 +19,9 @@ struct FusedOps {
     void (*image_map)(int* map /* 2P */);
     // narrow family: one kernel, one gradient slab per workgroup
     int (*grid)(long n);
+    // nchains / cs: gridDim.y = chains of a multi-chain handle, their image / eta / slab strides (1 and zeros for one chain)
     int (*launch)(int grid, hipStream_t st, const NetDev* nd, const float* qimg, const float* eta, const float* X,
-                  const float* Y, long n, float* slabs, int pitch, double* pstat);
+                  const float* Y, long n, float* slabs, int pitch, double* pstat, int nchains, ChainStride cs);
     // narrow family, optional: forward only for `nets` networks (images img_stride floats apart), fout[net][d_out][n]
     int (*nforward)(int gx, int nets, hipStream_t st, const float* qimgs, long img_stride, const float* X, long n, float* fouts,
                     long out_stride);

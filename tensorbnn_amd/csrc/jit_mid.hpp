@@ -9,8 +9,8 @@ template <class S>
 struct JitMid {
     static int grid(long n) { return mid_grid(n); }
     static int launch(int g, hipStream_t st, const NetDev* nd, const float* qimg, const float* eta, const float* X, const float* Y,
-                      long n, float* slabs, int pitch, double* pstat) {
-        return mid_launch_t<S>(g, st, *nd, qimg, eta, X, Y, n, slabs, pitch, pstat);
+                      long n, float* slabs, int pitch, double* pstat, int nchains, ChainStride cs) {
+        return mid_launch_t<S>(g, st, *nd, qimg, eta, X, Y, n, slabs, pitch, pstat, nchains, cs);
     }
     static int nforward(int gx, int nets, hipStream_t st, const float* qimgs, long img_stride, const float* X, long n, float* fouts,
                         long out_stride) {

@@ -12,13 +12,13 @@ struct JitNarrow {
         return (int)(wgs < 256 ? wgs : 256);
     }
     static int launch(int g, hipStream_t st, const NetDev* nd, const float* qimg, const float* eta, const float* X, const float* Y,
-                      long n, float* slabs, int pitch, double* pstat) {
+                      long n, float* slabs, int pitch, double* pstat, int nchains, ChainStride cs) {
         if constexpr (F3)
-            hipLaunchKernelGGL(k_fwd_bwd_fast3<S>, dim3(g), dim3(FAST_THREADS), 0, st, *nd, qimg, eta, X, Y, n, slabs, pitch, pstat,
-                               (unsigned long long*)nullptr);
+            hipLaunchKernelGGL(k_fwd_bwd_fast3<S>, dim3(g, nchains), dim3(FAST_THREADS), 0, st, *nd, qimg, eta, X, Y, n, slabs, pitch, pstat,
+                               (unsigned long long*)nullptr, cs);
         else
-            hipLaunchKernelGGL(k_fwd_bwd_fast<S>, dim3(g), dim3(FAST_THREADS), 0, st, *nd, qimg, eta, X, Y, n, slabs, pitch, pstat,
-                               (unsigned long long*)nullptr);
+            hipLaunchKernelGGL(k_fwd_bwd_fast<S>, dim3(g, nchains), dim3(FAST_THREADS), 0, st, *nd, qimg, eta, X, Y, n, slabs, pitch, pstat,
+                               (unsigned long long*)nullptr, cs);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     static int nforward(int gx, int nets, hipStream_t st, const float* qimgs, long img_stride, const float* X, long n, float* fouts,

@@ -694,9 +694,11 @@ template <class S>
 __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_fwd_bwd_fast(
     NetDev nd, const float* __restrict__ qimg, const float* __restrict__ eta,
     const float* __restrict__ X, const float* __restrict__ Y, long n,
-    float* __restrict__ slabs, int pitch, double* __restrict__ pstat, unsigned long long* __restrict__ stamps)
+    float* __restrict__ slabs, int pitch, double* __restrict__ pstat, unsigned long long* __restrict__ stamps, ChainStride cs)
 {
     using C = FastCfg<S>;
+    // gridDim.y = chains of a multi-chain handle (tbnn_create_multi): this workgroup's chain
+    qimg += (size_t)blockIdx.y * cs.img; eta += (size_t)blockIdx.y * cs.eta; slabs += (size_t)blockIdx.y * cs.slab; pstat += (size_t)blockIdx.y * PSTAT_CAP;
 #define TB_STAMP(i) do { if (stamps && threadIdx.x == 0 && blockIdx.x == 0) { stamps[i] = wall_clock64(); stamps[8 + i] = clock64(); } } while (0)
     TB_STAMP(0);
     static_assert(C::WB_FLOATS % 4 == 0 && C::STATIC_FLOATS % 4 == 0 && C::WAVE_FLOATS % 4 == 0, "images must be float4-addressable");
@@ -905,12 +907,12 @@ static inline int fast_grid(int, long n) {
 // qimg: the padded weight image of the position to evaluate
 static inline int fast_launch(int id, int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
                               const float* X, const float* Y, long n, float* slabs, int pitch, double* pstat,
-                              unsigned long long* stamps = nullptr) {
+                              unsigned long long* stamps = nullptr, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0}) {
     switch (id) {
-        case 0: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC2>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
-        case 1: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC1>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
-        case 2: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeTR>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
-        case 3: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeT3>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        case 0: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC2>, dim3(grid, nchains), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps, cs); break;
+        case 1: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC1>, dim3(grid, nchains), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps, cs); break;
+        case 2: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeTR>, dim3(grid, nchains), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps, cs); break;
+        case 3: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeT3>, dim3(grid, nchains), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps, cs); break;
         default: return -1;
     }
     return 0;

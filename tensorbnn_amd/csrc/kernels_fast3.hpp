@@ -1172,9 +1172,11 @@ template <class S>
 __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_fwd_bwd_fast3(
     NetDev nd, const float* __restrict__ qimg, const float* __restrict__ eta,
     const float* __restrict__ X, const float* __restrict__ Y, long n,
-    float* __restrict__ slabs, int pitch, double* __restrict__ pstat, unsigned long long* __restrict__ stamps)
+    float* __restrict__ slabs, int pitch, double* __restrict__ pstat, unsigned long long* __restrict__ stamps, ChainStride cs)
 {
     using C = F3Cfg<S>;
+    // gridDim.y = chains of a multi-chain handle (tbnn_create_multi): this workgroup's chain
+    qimg += (size_t)blockIdx.y * cs.img; eta += (size_t)blockIdx.y * cs.eta; slabs += (size_t)blockIdx.y * cs.slab; pstat += (size_t)blockIdx.y * PSTAT_CAP;
     static_assert(C::VL && C::NF(C::NL - 1) == C::out(C::NL - 1) && C::MTF(C::NL - 1) == 0, "fast3: last layer must be all-fringe");
     using CO = Coop3<S>;
     static_assert((C::LDS3_FLOATS + (CO::ENABLED ? 2 * CO::XB : 4)) * 4 + 64 <= 160 * 1024, "LDS budget");
@@ -1484,11 +1486,11 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 static inline bool fast3_available(int id) { return id == 0 || id == 1 || id == 2; }
 static inline int fast3_launch(int id, int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
                                const float* X, const float* Y, long n, float* slabs, int pitch, double* pstat,
-                               unsigned long long* stamps = nullptr) {
+                               unsigned long long* stamps = nullptr, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0}) {
     switch (id) {
-        case 0: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeC2>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
-        case 1: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeC1>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
-        case 2: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeTR>, dim3(grid), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps); break;
+        case 0: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeC2>, dim3(grid, nchains), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps, cs); break;
+        case 1: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeC1>, dim3(grid, nchains), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps, cs); break;
+        case 2: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeTR>, dim3(grid, nchains), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps, cs); break;
         default: return -1;
     }
     return 0;

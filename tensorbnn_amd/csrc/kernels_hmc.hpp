@@ -16,8 +16,16 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     const float* __restrict__ slabs, int nslab, int pitch,
     const float* __restrict__ q_cur, const float* __restrict__ g_cur,
     float* __restrict__ q, float* __restrict__ p, float* __restrict__ g,
-    const int* __restrict__ imgmap, float* __restrict__ qimg, float* __restrict__ gd = nullptr)
+    const int* __restrict__ imgmap, float* __restrict__ qimg, float* __restrict__ gd = nullptr, int img_floats = 0)
 {
+    // gridDim.y = chains of a multi-chain handle: [C][P] state arrays, [C][H] hypers, [C][nslab][pitch] slabs, [C][img_floats] images
+    if (blockIdx.y) {
+        const size_t c = blockIdx.y, cp = c * (size_t)nd.P;
+        eta += c * nd.H; slabs += c * (size_t)nslab * pitch;
+        q_cur += cp; g_cur += cp; q += cp; p += cp; g += cp;
+        if (qimg) qimg += c * (size_t)img_floats;
+        if (gd) gd += cp;
+    }
     // gd (optional): the DATA term of the gradient alone (the reduced slabs, before the prior is added), stored SIGMA-FREE
     // (times sigma^2 for the Gaussian likelihood): kept next to the state so that a hyper transition, which changes only
     // the prior and the likelihood's sigma, can refresh the cached (log-prob, gradient) of the current state without
@@ -155,9 +163,17 @@ __device__ __forceinline__ double prior_logp_partial(const NetDev& nd, const flo
 // Single-workgroup kernel: momentum draw + K0 + log u.
 __global__ __launch_bounds__(1024) void k_begin(
     NetDev nd, const float* __restrict__ p0_inj, const float* __restrict__ logu_inj,
-    uint32_t epoch, uint32_t key0, uint32_t key1, float* __restrict__ p, Scal* __restrict__ sc)
+    uint32_t epoch, uint32_t key0, uint32_t key1, float* __restrict__ p, Scal* __restrict__ sc, uint32_t seed_hi = 0)
 {
     __shared__ double red[16];
+    // gridDim.y = chains of a multi-chain handle: chain c draws from the Philox key (seed, chain0 + c) -- key1 = chain_id ^ seed_hi
+    if (blockIdx.y) {
+        const uint32_t c = blockIdx.y;
+        key1 = (((key1 ^ seed_hi) + c) ^ seed_hi);
+        p += (size_t)c * nd.P; sc += c;
+        if (p0_inj) p0_inj += (size_t)c * nd.P;
+        if (logu_inj) logu_inj += c;
+    }
     double k = 0.0;
     if (p0_inj) {
         for (int j = threadIdx.x; j < nd.P; j += blockDim.x) { const float v = p0_inj[j]; p[j] = v; k += (double)v * (double)v; }
@@ -193,6 +209,17 @@ __global__ __launch_bounds__(1024) void k_energy(
 {
     __shared__ double red[16];
     __shared__ int s_acc;
+    // gridDim.y = chains of a multi-chain handle (no trace there: trace_slot is null)
+    if (blockIdx.y) {
+        const size_t c = blockIdx.y, cp = c * (size_t)nd.P;
+        eta += c * nd.H; q += cp; p += cp; q_cur += cp; partial_stat += c * PSTAT_CAP; sc += c;
+        if (commit_out) commit_out += c;
+        if (g) g += cp;
+        if (q_cur_w) q_cur_w += cp;
+        if (g_cur) g_cur += cp;
+        if (gd) gd += cp;
+        if (gd_cur) gd_cur += cp;
+    }
     double st = 0.0;
     if (which != EN_REFRESH) {
         for (int w = threadIdx.x; w < nslab; w += blockDim.x) st += partial_stat[w];

@@ -112,9 +112,11 @@ template <class S, int NW, bool FWD = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_fwd_bwd_tall(
     NetDev nd, const float* __restrict__ qimgs, long img_stride, const float* __restrict__ eta,
     const float* __restrict__ X, const float* __restrict__ Y, long n,
-    float* __restrict__ slabs, int pitch, double* __restrict__ pstat, float* __restrict__ fouts, long out_stride)
+    float* __restrict__ slabs, int pitch, double* __restrict__ pstat, float* __restrict__ fouts, long out_stride, ChainStride cs)
 {
     using C = TallCfg<S, NW>;
+    // gridDim.y: networks of an ensemble (FWD) or chains of a multi-chain handle (tbnn_create_multi; cs.img == img_stride then)
+    if constexpr (!FWD) { eta += (size_t)blockIdx.y * cs.eta; slabs += (size_t)blockIdx.y * cs.slab; pstat += (size_t)blockIdx.y * PSTAT_CAP; }
     static_assert(C::LDS_OK, "LDS budget");
     constexpr int TALL_WAVES = NW, TALL_THREADS = 64 * NW;
     constexpr bool ACC_A = true;       // accumulators pinned to AccVGPRs by asm MFMAs (as in kernels_mid.hpp)
@@ -550,10 +552,10 @@ static inline int tall_grid(long n) {
 }
 template <class S>
 static inline int tall_launch_t(int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta, const float* X,
-                                const float* Y, long n, float* slabs, int pitch, double* pstat) {
+                                const float* Y, long n, float* slabs, int pitch, double* pstat, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0}) {
     constexpr int NW = TallPick<S>::NW;
-    hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, false>), dim3(grid), dim3(64 * NW), 0, st, nd, qimg, 0L, eta, X, Y, n, slabs, pitch, pstat,
-                       (float*)nullptr, 0L);
+    hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, false>), dim3(grid, nchains), dim3(64 * NW), 0, st, nd, qimg, cs.img, eta, X, Y, n, slabs, pitch, pstat,
+                       (float*)nullptr, 0L, cs);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // forward only: `nets` networks (grid.y; images img_stride floats apart), fouts[net][d_out][n]
@@ -563,6 +565,6 @@ static inline int tall_forward_t(int gx, int nets, hipStream_t st, const float* 
     NetDev nd{};
     constexpr int NW = TallPick<S>::NW;
     hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, true>), dim3(gx, nets), dim3(64 * NW), 0, st, nd, qimgs, img_stride, (const float*)nullptr, X,
-                       (const float*)nullptr, n, (float*)nullptr, 0, (double*)nullptr, fouts, out_stride);
+                       (const float*)nullptr, n, (float*)nullptr, 0, (double*)nullptr, fouts, out_stride, ChainStride{0, 0, 0});
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -36,6 +36,9 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 #define NEED(h)                                                                                \
     do { if (!(h)) return fail(-1, "null handle"); } while (0)
+// entry points that address ONE chain's state have no meaning on a multi-chain handle
+#define ONE_CHAIN(h, what)                                                                     \
+    do { if ((h)->C > 1) return fail(-1, what ": not available on a multi-chain handle (tbnn_create_multi)"); } while (0)
 
 
 struct tbnn_comm {
@@ -50,6 +53,8 @@ struct tbnn_ctx {
     hipStream_t stream = nullptr;
     NetDev nd{};
     uint32_t key0 = 0, key1 = 0, epoch = 0;
+    int C = 1;                            // chains of this handle (tbnn_create_multi): every per-chain buffer is a [C][...] array, the per-chain
+    uint32_t seed_hi = 0;                 // kernels run with gridDim.y = C; chain c draws from the Philox key (seed, chain_id + c)
     int kernel = TBNN_KERNEL_GENERIC;     // resolved variant
     int fast_id = -1;
     int fast_ver = 1;                     // 1: kernels_fast.hpp, 3: kernels_fast3.hpp (fringe units off the 16x16 tiles)
@@ -226,8 +231,19 @@ extern "C" int tbnn_destroy(tbnn_handle h) {
     return 0;
 }
 
-extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed, uint32_t chain_id,
-                           tbnn_handle* out) {
+static int create_impl(const tbnn_net_desc* desc, int device, uint64_t seed, uint32_t chain_id, int n_chains, tbnn_handle* out);
+extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed, uint32_t chain_id, tbnn_handle* out) {
+    return create_impl(desc, device, seed, chain_id, 1, out);
+}
+// Several independent chains of one network on ONE device behind one handle (SURVEY 8(e) puts one chain on each GPU; small
+// problems -- the reference's own examples -- leave most of a GPU idle and are bound by launch latency): chain c is exactly the chain
+// tbnn_create(..., chain_id + c) would be, and the per-chain kernels of all of them run as ONE launch with gridDim.y = n_chains.
+extern "C" int tbnn_create_multi(const tbnn_net_desc* desc, int device, uint64_t seed, uint32_t chain_id, int32_t n_chains, tbnn_handle* out) {
+    if (n_chains < 1 || n_chains > 1024) return fail(-1, "n_chains must be in [1, 1024]");
+    return create_impl(desc, device, seed, chain_id, n_chains, out);
+}
+extern "C" int tbnn_chain_count(tbnn_handle h) { NEED(h); return h->C; }
+static int create_impl(const tbnn_net_desc* desc, int device, uint64_t seed, uint32_t chain_id, int n_chains, tbnn_handle* out) {
     if (!out) return fail(-1, "null out");
     *out = nullptr;
     NetDev nd;
@@ -245,31 +261,34 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
     HIPCHK(hipSetDevice(device));
     tbnn_ctx* h = new (std::nothrow) tbnn_ctx();
     if (!h) return fail(-4, "out of host memory");
-    h->device = device; h->nd = nd;
+    h->device = device; h->nd = nd; h->C = n_chains;
     // Philox key = (seed, chain_id); the high seed word is folded into the key
     h->key0 = (uint32_t)(seed & 0xFFFFFFFFull);
-    h->key1 = chain_id ^ (uint32_t)(seed >> 32);
+    h->seed_hi = (uint32_t)(seed >> 32);
+    h->key1 = chain_id ^ h->seed_hi;
+    const size_t NC = (size_t)n_chains;
     auto bail = [&](int code, const std::string& m) { tbnn_destroy(h); return fail(code, m); };
 #define HIPB(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(-2, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
     HIPB(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    const size_t PB = (size_t)nd.P * sizeof(float);
+    const size_t PB = NC * (size_t)nd.P * sizeof(float);               // per-chain arrays: [C][P] (one chain: [P])
     HIPB(hipMalloc(&h->q_cur, PB)); HIPB(hipMalloc(&h->g_cur, PB)); HIPB(hipMalloc(&h->q, PB));
     HIPB(hipMalloc(&h->p, PB)); HIPB(hipMalloc(&h->g, PB));
     HIPB(hipMalloc(&h->p0_inj, (size_t)std::max(nd.P, nd.H) * sizeof(float)));   // injected momentum of either transition (H > P for tiny networks)
-    HIPB(hipMalloc(&h->tmp, PB + (size_t)nd.H * sizeof(float)));
-    HIPB(hipMalloc(&h->eta, (size_t)nd.H * sizeof(float)));
-    HIPB(hipMalloc(&h->eta_prev, (size_t)nd.H * sizeof(float)));
+    HIPB(hipMalloc(&h->tmp, PB + NC * (size_t)nd.H * sizeof(float)));
+    HIPB(hipMalloc(&h->eta, NC * (size_t)nd.H * sizeof(float)));
+    HIPB(hipMalloc(&h->eta_prev, NC * (size_t)nd.H * sizeof(float)));
     HIPB(hipMalloc(&h->gd, PB)); HIPB(hipMalloc(&h->gd_cur, PB));
     HIPB(hipMalloc(&h->logu_inj, sizeof(float)));
-    HIPB(hipMalloc(&h->sc, sizeof(Scal))); HIPB(hipMalloc(&h->sc_out, sizeof(Scal)));
-    HIPB(hipHostMalloc(&h->sc_host, sizeof(Scal)));
-    HIPB(hipHostMalloc(&h->pin, ((size_t)nd.P + nd.H) * sizeof(float), hipHostMallocMapped));
+    HIPB(hipMalloc(&h->sc, NC * sizeof(Scal))); HIPB(hipMalloc(&h->sc_out, NC * sizeof(Scal)));
+    HIPB(hipHostMalloc(&h->sc_host, NC * sizeof(Scal)));
+    HIPB(hipHostMalloc(&h->pin, NC * ((size_t)nd.P + nd.H) * sizeof(float), hipHostMallocMapped));
     HIPB(hipHostGetDevicePointer((void**)&h->pin_dev, h->pin, 0));
-    HIPB(hipMemset(h->sc, 0, sizeof(Scal)));
+    HIPB(hipMemset(h->sc, 0, NC * sizeof(Scal)));
     HIPB(hipMemset(h->q_cur, 0, PB));
     HIPB(hipEventCreate(&h->ev0)); HIPB(hipEventCreate(&h->ev1));
-    HIPB(hipMalloc(&h->hyp_ws, hyper_ws_bytes(nd)));
-    std::vector<float> eta; default_eta(nd, eta);
+    HIPB(hipMalloc(&h->hyp_ws, NC * hyper_ws_bytes(nd)));
+    std::vector<float> eta1, eta; default_eta(nd, eta1);
+    for (size_t c = 0; c < NC; ++c) eta.insert(eta.end(), eta1.begin(), eta1.end());
     HIPB(hipMemcpy(h->eta, eta.data(), eta.size() * sizeof(float), hipMemcpyHostToDevice));
     // fused-kernel variant
     h->kernel = TBNN_KERNEL_GENERIC; h->kernel_name = "generic";
@@ -288,10 +307,10 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
         mid_image_map_id(mid, map.data());
         HIPB(hipMalloc(&h->imgmap, map.size() * sizeof(int)));
         HIPB(hipMemcpy(h->imgmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPB(hipMalloc(&h->qimg, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMalloc(&h->qimg_cur, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMemset(h->qimg, 0, (size_t)h->img_floats * sizeof(float)));       // padding stays zero for ever
-        HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg_cur, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg, 0, NC * (size_t)h->img_floats * sizeof(float)));       // padding stays zero for ever
+        HIPB(hipMemset(h->qimg_cur, 0, NC * (size_t)h->img_floats * sizeof(float)));
     }
     if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && jo) {
         h->kernel = TBNN_KERNEL_FAST; h->jit = jo; h->kernel_name = jo->name;
@@ -301,10 +320,10 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
         jo->image_map(map.data());
         HIPB(hipMalloc(&h->imgmap, map.size() * sizeof(int)));
         HIPB(hipMemcpy(h->imgmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPB(hipMalloc(&h->qimg, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMalloc(&h->qimg_cur, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMemset(h->qimg, 0, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg_cur, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg, 0, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg_cur, 0, NC * (size_t)h->img_floats * sizeof(float)));
     }
     if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && wid >= 0) {
         h->kernel = TBNN_KERNEL_FAST; h->wide_id = wid; h->kernel_name = wide_name(wid);
@@ -314,10 +333,10 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
         wide_image_map_id(wid, map.data());
         HIPB(hipMalloc(&h->imgmap, map.size() * sizeof(int)));
         HIPB(hipMemcpy(h->imgmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPB(hipMalloc(&h->qimg, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMalloc(&h->qimg_cur, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMemset(h->qimg, 0, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg_cur, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg, 0, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg_cur, 0, NC * (size_t)h->img_floats * sizeof(float)));
     }
     if ((want == TBNN_KERNEL_AUTO || want == TBNN_KERNEL_FAST) && fid >= 0) {
         h->kernel = TBNN_KERNEL_FAST; h->fast_id = fid; h->kernel_name = fast_name(fid);
@@ -333,10 +352,10 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
         fast_image_map(fid, map.data());
         HIPB(hipMalloc(&h->imgmap, map.size() * sizeof(int)));
         HIPB(hipMemcpy(h->imgmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPB(hipMalloc(&h->qimg, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMalloc(&h->qimg_cur, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMemset(h->qimg, 0, (size_t)h->img_floats * sizeof(float)));       // padding stays zero for ever
-        HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg_cur, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg, 0, NC * (size_t)h->img_floats * sizeof(float)));       // padding stays zero for ever
+        HIPB(hipMemset(h->qimg_cur, 0, NC * (size_t)h->img_floats * sizeof(float)));
     }
     // no shape-specialised kernel (and none registered at run time): the layered MFMA family takes any architecture
     // (TBNN_LAYERED=0: the thread-per-row kernel, as before round 3)
@@ -352,10 +371,10 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
         lay_image_map(nd, h->lplan, map.data());
         HIPB(hipMalloc(&h->imgmap, map.size() * sizeof(int)));
         HIPB(hipMemcpy(h->imgmap, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIPB(hipMalloc(&h->qimg, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMalloc(&h->qimg_cur, (size_t)h->img_floats * sizeof(float)));
-        HIPB(hipMemset(h->qimg, 0, (size_t)h->img_floats * sizeof(float)));       // padding stays zero for ever
-        HIPB(hipMemset(h->qimg_cur, 0, (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMalloc(&h->qimg_cur, NC * (size_t)h->img_floats * sizeof(float)));
+        HIPB(hipMemset(h->qimg, 0, NC * (size_t)h->img_floats * sizeof(float)));       // padding stays zero for ever
+        HIPB(hipMemset(h->qimg_cur, 0, NC * (size_t)h->img_floats * sizeof(float)));
     }
     { const char* e1 = getenv("TBNN_FAST_SINGLE"); if (e1 && atoi(e1)) h->nd.reserved_flags |= 1; }
     { const char* e2 = getenv("TBNN_MERGE_ENDS"); h->merge_ends = !(e2 && atoi(e2) == 0); }
@@ -423,11 +442,11 @@ static int alloc_workspace(tbnn_ctx* h, long n) {
     h->grid = grid;
     h->pitch = (nd.P + 3) & ~3;                  // float4-readable slabs
     h->nslab = h->wide_id >= 0 ? 1 : (h->lay ? h->lplan.NS : grid);
-    HIPCHK(hipMalloc(&h->slabs, (size_t)h->nslab * h->pitch * sizeof(float)));
-    HIPCHK(hipMemset(h->slabs, 0, (size_t)h->nslab * h->pitch * sizeof(float)));
+    HIPCHK(hipMalloc(&h->slabs, (size_t)h->C * h->nslab * h->pitch * sizeof(float)));          // [C][nslab][pitch]
+    HIPCHK(hipMemset(h->slabs, 0, (size_t)h->C * h->nslab * h->pitch * sizeof(float)));
     if (grid > PSTAT_CAP) return fail(-2, "grid exceeds PSTAT_CAP");
-    HIPCHK(hipMalloc(&h->pstat, (size_t)PSTAT_CAP * sizeof(double)));
-    HIPCHK(hipMemset(h->pstat, 0, (size_t)PSTAT_CAP * sizeof(double)));      // entries >= grid stay zero
+    HIPCHK(hipMalloc(&h->pstat, (size_t)h->C * PSTAT_CAP * sizeof(double)));                   // [C][PSTAT_CAP]
+    HIPCHK(hipMemset(h->pstat, 0, (size_t)h->C * PSTAT_CAP * sizeof(double)));      // entries >= grid stay zero
     if (h->pstat_red) { hipFree(h->pstat_red); h->pstat_red = nullptr; }
     HIPCHK(hipMalloc(&h->pstat_red, (size_t)PSTAT_CAP * sizeof(double)));
     HIPCHK(hipMemset(h->pstat_red, 0, (size_t)PSTAT_CAP * sizeof(double)));
@@ -468,7 +487,7 @@ extern "C" int tbnn_set_data(tbnn_handle h, const float* X, const float* Y, int6
 extern "C" int tbnn_set_state(tbnn_handle h, const float* theta) {
     NEED(h); if (!theta) return fail(-1, "null theta");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpyAsync(h->q_cur, theta, (size_t)h->nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->q_cur, theta, (size_t)h->C * h->nd.P * sizeof(float), hipMemcpyHostToDevice, h->stream));     // [C][P]
     HIPCHK(hipStreamSynchronize(h->stream));
     h->cur_valid = false;
     return 0;
@@ -478,16 +497,17 @@ extern "C" int tbnn_get_state(tbnn_handle h, float* theta) {
     HIPCHK(hipSetDevice(h->device));
     // a kernel writes theta straight into the (device-mapped) pinned buffer: a D2H copy engine transfer of this size
     // has ~160 us of latency, the zero-copy store a few us
-    hipLaunchKernelGGL(k_copy_f32, dim3((h->nd.P + 255) / 256), dim3(256), 0, h->stream, h->nd.P, (const float*)h->q_cur, h->pin_dev);
+    const int PC = h->C * h->nd.P;
+    hipLaunchKernelGGL(k_copy_f32, dim3((PC + 255) / 256), dim3(256), 0, h->stream, PC, (const float*)h->q_cur, h->pin_dev);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    memcpy(theta, h->pin, (size_t)h->nd.P * sizeof(float));
+    memcpy(theta, h->pin, (size_t)PC * sizeof(float));
     return 0;
 }
 extern "C" int tbnn_set_hypers(tbnn_handle h, const float* eta) {
     NEED(h); if (!eta) return fail(-1, "null eta");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpyAsync(h->eta, eta, (size_t)h->nd.H * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->eta, eta, (size_t)h->C * h->nd.H * sizeof(float), hipMemcpyHostToDevice, h->stream));        // [C][H]
     HIPCHK(hipStreamSynchronize(h->stream));
     h->cur_valid = false;
     return 0;
@@ -495,9 +515,10 @@ extern "C" int tbnn_set_hypers(tbnn_handle h, const float* eta) {
 extern "C" int tbnn_get_hypers(tbnn_handle h, float* eta) {
     NEED(h); if (!eta) return fail(-1, "null eta");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpyAsync(h->pin + h->nd.P, h->eta, (size_t)h->nd.H * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    float* stage = h->pin + (size_t)h->C * h->nd.P;
+    HIPCHK(hipMemcpyAsync(stage, h->eta, (size_t)h->C * h->nd.H * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    memcpy(eta, h->pin + h->nd.P, (size_t)h->nd.H * sizeof(float));
+    memcpy(eta, stage, (size_t)h->C * h->nd.H * sizeof(float));
     return 0;
 }
 
@@ -587,6 +608,7 @@ extern "C" int tbnn_comm_destroy(tbnn_comm_handle c) {
 }
 extern "C" int tbnn_gather_samples(tbnn_handle h, tbnn_comm_handle c, float* d_out, float* host_out) {
     NEED(h); if (!c) return fail(-1, "null communicator");
+    ONE_CHAIN(h, "tbnn_gather_samples");
     HIPCHK(hipSetDevice(h->device));
     const size_t per = (size_t)h->nd.P + h->nd.H, tot = per * c->world;
     if (!d_out) {
@@ -607,6 +629,7 @@ extern "C" int tbnn_gather_samples(tbnn_handle h, tbnn_comm_handle c, float* d_o
 }
 extern "C" int tbnn_set_row_shard(tbnn_handle h, tbnn_comm_handle c, int64_t n_total) {
     NEED(h);
+    ONE_CHAIN(h, "tbnn_set_row_shard");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (c && n_total < 1) return fail(-1, "n_total must be >= 1");
@@ -628,10 +651,12 @@ static inline int grad_nslab(const tbnn_ctx* h) { return h->shard ? 1 : h->nslab
 // any other q gets its image built here (h->qimg_cur).
 static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
     const float* img = nullptr;
+    const int C = h->C;
+    const long imgS = h->img_floats, slabS = (long)h->nslab * h->pitch;
     if (h->kernel == TBNN_KERNEL_FAST) {
         if (q == h->q && h->q_img_valid) img = h->qimg;
         else {
-            hipLaunchKernelGGL(k_make_image, dim3((h->nd.P + 255) / 256), dim3(256), 0, h->stream, h->nd.P, q, h->imgmap, h->qimg_cur);
+            hipLaunchKernelGGL(k_make_image, dim3((h->nd.P + 255) / 256, C), dim3(256), 0, h->stream, h->nd.P, q, h->imgmap, h->qimg_cur, (long)h->nd.P, imgS);
             img = h->qimg_cur;
         }
     }
@@ -644,26 +669,37 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
         a = h->pev[h->pev_used]; b = h->pev[h->pev_used + 1]; h->pev_used += 2;
         hipEventRecord(a, h->stream);
     }
+    // the one-slab-per-workgroup families take all chains of a multi-chain handle in ONE launch (gridDim.y = chain); the others
+    // (two-kernel wide path, layered family, thread-per-row kernel: not what small problems run on) chain by chain through the
+    // same activation store
+    const ChainStride cs = {imgS, (long)h->nd.H, slabS};
     if (h->lay) {
-        if (lay_launch(h->nd, h->lplan, h->stream, img, eta, h->dY, h->n, h->lstore, h->slabs, h->pitch, h->pstat))
-            return fail(-2, "layered kernel launch failed");
+        for (int c = 0; c < C; ++c)
+            if (lay_launch(h->nd, h->lplan, h->stream, img + c * imgS, eta + (size_t)c * h->nd.H, h->dY, h->n, h->lstore, h->slabs + c * slabS, h->pitch,
+                           h->pstat + (size_t)c * PSTAT_CAP))
+                return fail(-2, "layered kernel launch failed");
     } else if (h->wide_id >= 0) {
-        const int rc = h->jit ? h->jit->wlaunch(&h->wplan, h->stream, &h->nd, img, eta, h->dX, h->dY, h->n, h->wstore, h->wslabA, h->wslabB, h->pstat, h->slabs)
-                              : wide_launch(h->wplan, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->wstore, h->wslabA, h->wslabB, h->pstat, h->slabs);
-        if (rc) return fail(-2, "wide kernel launch failed");
+        for (int c = 0; c < C; ++c) {
+            const float* ic = img + c * imgS; const float* ec = eta + (size_t)c * h->nd.H;
+            double* pc = h->pstat + (size_t)c * PSTAT_CAP; float* sl = h->slabs + c * slabS;
+            const int rc = h->jit ? h->jit->wlaunch(&h->wplan, h->stream, &h->nd, ic, ec, h->dX, h->dY, h->n, h->wstore, h->wslabA, h->wslabB, pc, sl)
+                                  : wide_launch(h->wplan, h->stream, h->nd, ic, ec, h->dX, h->dY, h->n, h->wstore, h->wslabA, h->wslabB, pc, sl);
+            if (rc) return fail(-2, "wide kernel launch failed");
+        }
     } else if (h->kernel == TBNN_KERNEL_FAST && h->jit) {
-        if (h->jit->launch(h->grid, h->stream, &h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat))
+        if (h->jit->launch(h->grid, h->stream, &h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, C, cs))
             return fail(-2, "registered kernel launch failed");
     } else if (h->kernel == TBNN_KERNEL_FAST && h->mid_id >= 0) {
-        if (mid_launch(h->mid_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat))
+        if (mid_launch(h->mid_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, C, cs))
             return fail(-2, "mid kernel launch failed");
     } else if (h->kernel == TBNN_KERNEL_FAST) {
-        int rc = h->fast_ver == 3 ? fast3_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat)
-                                  : fast_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat);
+        int rc = h->fast_ver == 3 ? fast3_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, nullptr, C, cs)
+                                  : fast_launch(h->fast_id, h->grid, h->stream, h->nd, img, eta, h->dX, h->dY, h->n, h->slabs, h->pitch, h->pstat, nullptr, C, cs);
         if (rc) return fail(-2, "fast kernel launch failed");
     } else {
-        hipLaunchKernelGGL(k_fwd_bwd_generic, dim3(h->grid), dim3(GEN_RB), 0, h->stream, h->nd, q, eta, h->dX,
-                           h->dY, h->n, h->scratch, h->scratchPerWG, h->slabs, h->pitch, h->pstat);
+        for (int c = 0; c < C; ++c)
+            hipLaunchKernelGGL(k_fwd_bwd_generic, dim3(h->grid), dim3(GEN_RB), 0, h->stream, h->nd, q + (size_t)c * h->nd.P, eta + (size_t)c * h->nd.H, h->dX,
+                               h->dY, h->n, h->scratch, h->scratchPerWG, h->slabs + c * slabS, h->pitch, h->pstat + (size_t)c * PSTAT_CAP);
     }
     if (h->shard) {
         // ONE collective per fused pass: the dense data-term gradient row (P values; the wide path already has one) and the
@@ -689,14 +725,15 @@ static void launch_update(tbnn_ctx* h, int mode, float eps, const float* eta, fl
     const bool img = h->kernel == TBNN_KERNEL_FAST && q == h->q;
     // the data-term gradient goes with its state: the proposal's (h->gd) or, for the bootstrap evaluation, the current one's
     float* gd = g == h->g_cur ? h->gd_cur : (g == h->g ? h->gd : nullptr);
-    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, h->nd, mode, eps, eta, grad_slabs(h), grad_nslab(h),
-                       h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg, gd);
+    hipLaunchKernelGGL(k_update, dim3(gx, h->C), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, h->nd, mode, eps, eta, grad_slabs(h), grad_nslab(h),
+                       h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg, gd, h->img_floats);
     if (img && (mode == UPD_FIRST || mode == UPD_MID)) h->q_img_valid = true;
 }
 static void launch_energy(tbnn_ctx* h, int which, const float* eta, const float* q, double* slot) {
-    hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, h->nd, which, eta, q, h->p, h->q_cur, stat_ptr(h),
+    hipLaunchKernelGGL(k_energy, dim3(1, h->C), dim3(1024), 0, h->stream, h->nd, which, eta, q, h->p, h->q_cur, stat_ptr(h),
                        stat_entries(h), rows_total(h), h->sc, slot);
 }
+
 // make (logp, grad, stat) at q_cur valid
 static int ensure_current(tbnn_ctx* h, double* slot) {
     if (h->cur_valid) return 0;
@@ -721,6 +758,7 @@ static float drain_profile(tbnn_ctx* h) {
 extern "C" int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* eta, double* logp, float* grad,
                               double* stat) {
     NEED(h);
+    ONE_CHAIN(h, "tbnn_logp_grad");
     if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
     HIPCHK(hipSetDevice(h->device));
     const NetDev& nd = h->nd;
@@ -842,6 +880,7 @@ static int launch_forward(tbnn_ctx* h, const float* q, const float* dX, long n, 
 
 extern "C" int tbnn_forward(tbnn_handle h, const float* theta, const float* X, int64_t n, float* out) {
     NEED(h);
+    if (!theta) ONE_CHAIN(h, "tbnn_forward at the chain's own state");
     if (!X || !out || n < 1) return fail(-1, "forward: null pointer or n < 1");
     HIPCHK(hipSetDevice(h->device));
     const NetDev& nd = h->nd;
@@ -878,6 +917,7 @@ extern "C" int tbnn_set_validation(tbnn_handle h, const float* X, const float* Y
 // predictions over the staged training (which = 0) or validation (1) rows into h->fbuf[d_out][n]
 static int predict_resident(tbnn_ctx* h, int which, const float* theta, long* n_out) {
     const NetDev& nd = h->nd;
+    if (!theta) ONE_CHAIN(h, "tbnn_predict / tbnn_metrics at the chain's own state");
     const float* dX = which ? h->dXv : h->dX;
     const long n = which ? h->nv : h->n;
     if (!dX || n < 1) return fail(-1, which ? "tbnn_set_validation has not been called" : "tbnn_set_data has not been called");
@@ -1005,7 +1045,7 @@ static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, 
     int rc = ensure_current(h, d_trace);
     if (rc) return rc;
     if (d_trace && cached) hipLaunchKernelGGL(k_trace_logp_cur, dim3(1), dim3(64), 0, h->stream, (const Scal*)h->sc, d_trace);
-    hipLaunchKernelGGL(k_begin, dim3(1), dim3(1024), 0, h->stream, nd, d_p0, d_logu, h->epoch, h->key0, h->key1, h->p, h->sc);
+    hipLaunchKernelGGL(k_begin, dim3(1, h->C), dim3(1024), 0, h->stream, nd, d_p0, d_logu, h->epoch, h->key0, h->key1, h->p, h->sc, h->seed_hi);
     launch_update(h, UPD_FIRST, eps, h->eta, h->q, h->g);
     for (int t = 1; t <= L; ++t) {
         rc = launch_fwd_bwd(h, h->q, h->eta);
@@ -1020,14 +1060,17 @@ static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, 
     // the Metropolis decision, the host record and the commit in ONE single-workgroup launch for networks whose state that
     // workgroup copies in a few trips (TBNN_MERGE_ENDS=0: three launches, as before round 3)
     if (h->merge_ends && nd.P <= 32768) {
-        hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, h->nd, (int)EN_NEW, (const float*)h->eta, (const float*)h->q, (const float*)h->p,
+        hipLaunchKernelGGL(k_energy, dim3(1, h->C), dim3(1024), 0, h->stream, h->nd, (int)EN_NEW, (const float*)h->eta, (const float*)h->q, (const float*)h->p,
                            (const float*)h->q_cur, stat_ptr(h), stat_entries(h), rows_total(h), h->sc, d_trace ? d_trace + L : (double*)nullptr,
                            d_out, (const float*)h->g, h->q_cur, h->g_cur, (const float*)h->gd, h->gd_cur);
     } else {
         launch_energy(h, EN_NEW, h->eta, h->q, d_trace ? d_trace + L : nullptr);
-        hipLaunchKernelGGL(k_commit, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, h->sc, h->q, h->g, h->q_cur, h->g_cur,
-                           (const float*)h->gd, h->gd_cur);
-        hipLaunchKernelGGL(k_commit_scal, dim3(1), dim3(64), 0, h->stream, h->sc, d_out);
+        for (int c = 0; c < h->C; ++c) {
+            const size_t cp = (size_t)c * nd.P;
+            hipLaunchKernelGGL(k_commit, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, h->sc + c, h->q + cp, h->g + cp, h->q_cur + cp, h->g_cur + cp,
+                               (const float*)(h->gd + cp), h->gd_cur + cp);
+            hipLaunchKernelGGL(k_commit_scal, dim3(1), dim3(64), 0, h->stream, h->sc + c, d_out + c);
+        }
     }
     HIPCHK(hipGetLastError());
     h->epoch += 1;
@@ -1048,6 +1091,7 @@ extern "C" int tbnn_hmc_step(tbnn_handle h, float eps, int32_t L, const float* p
     NEED(h);
     if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
     if (L < 1) return fail(-1, "L must be >= 1");
+    if (h->C > 1 && (p0 || log_u || trace_logp)) return fail(-1, "hmc_step on a multi-chain handle: no injected draws, no trace (out: one record per chain)");
     HIPCHK(hipSetDevice(h->device));
     const NetDev& nd = h->nd;
     const float* d_p0 = nullptr; const float* d_lu = nullptr;
@@ -1068,12 +1112,13 @@ extern "C" int tbnn_hmc_step(tbnn_handle h, float eps, int32_t L, const float* p
     int rc = enqueue_transition(h, eps, L, d_p0, d_lu, d_trace, h->sc_out);
     if (rc) return rc;
     HIPCHK(hipEventRecord(h->ev1, h->stream));
-    HIPCHK(hipMemcpyAsync(h->sc_host, h->sc_out, sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sc_host, h->sc_out, (size_t)h->C * sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
     if (trace_logp) HIPCHK(hipMemcpyAsync(trace_logp, h->trace, (size_t)(L + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1);
     const float fb = h->profile ? drain_profile(h) : 0.f;
-    if (out) fill_out(*h->sc_host, L, ms * 1000.f, fb, out);
+    if (out)
+        for (int c = 0; c < h->C; ++c) fill_out(h->sc_host[c], L, ms * 1000.f, fb, out + c);
     return 0;
 }
 
@@ -1084,32 +1129,35 @@ extern "C" int tbnn_hmc_run(tbnn_handle h, float eps, int32_t L, int32_t n_epoch
     HIPCHK(hipSetDevice(h->device));
     // per-epoch records: a pooled device buffer and a pooled pinned host mirror (no allocator call -- hipFree synchronises
     // the device -- inside a caller's timed loop once the pool has grown to the largest n_epochs seen)
-    if (h->recs_cap < n_epochs) {
+    const int C = h->C;                                  // records: [epoch][chain] on the device, outs[chain][epoch] for the caller
+    if (h->recs_cap < n_epochs * C) {
         if (h->d_recs) hipFree(h->d_recs);
         if (h->h_recs) hipHostFree(h->h_recs);
         h->d_recs = nullptr; h->h_recs = nullptr; h->recs_cap = 0;
-        const int cap = std::max(n_epochs, 64);
+        const int cap = std::max(n_epochs * C, 64);
         HIPCHK(hipMalloc(&h->d_recs, (size_t)cap * sizeof(Scal)));
         HIPCHK(hipHostMalloc(&h->h_recs, (size_t)cap * sizeof(Scal)));
         h->recs_cap = cap;
     }
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int e = 0; e < n_epochs; ++e) {
-        int rc = enqueue_transition(h, eps, L, nullptr, nullptr, nullptr, h->d_recs + e);
+        int rc = enqueue_transition(h, eps, L, nullptr, nullptr, nullptr, h->d_recs + (size_t)e * C);
         if (rc) return rc;
     }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
-    HIPCHK(hipMemcpyAsync(h->h_recs, h->d_recs, (size_t)n_epochs * sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_recs, h->d_recs, (size_t)n_epochs * C * sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1);
     const float fb = h->profile ? drain_profile(h) : 0.f;
     if (outs)
-        for (int e = 0; e < n_epochs; ++e) fill_out(h->h_recs[e], L, ms * 1000.f / n_epochs, fb, outs + e);
+        for (int c = 0; c < C; ++c)
+            for (int e = 0; e < n_epochs; ++e) fill_out(h->h_recs[(size_t)e * C + c], L, ms * 1000.f / n_epochs, fb, outs + (size_t)c * n_epochs + e);
     return 0;
 }
 
 extern "C" int tbnn_hyper_logp_grad(tbnn_handle h, const float* eta, double* logp, float* grad) {
     NEED(h);
+    ONE_CHAIN(h, "tbnn_hyper_logp_grad");
     if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
     HIPCHK(hipSetDevice(h->device));
     const NetDev& nd = h->nd;
@@ -1134,35 +1182,50 @@ extern "C" int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const fl
     NEED(h);
     if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
     if (L_h < 1) return fail(-1, "L_h must be >= 1");
+    if (h->C > 1 && (p0 || log_u)) return fail(-1, "hyper_step on a multi-chain handle: no injected draws (out: one record per chain)");
     HIPCHK(hipSetDevice(h->device));
     const NetDev& nd = h->nd;
+    const int C = h->C;
     int rc = ensure_current(h, nullptr);
     if (rc) return rc;
     const float* d_p0 = nullptr; const float* d_lu = nullptr;
     if (p0) { HIPCHK(hipMemcpyAsync(h->p0_inj, p0, (size_t)nd.H * sizeof(float), hipMemcpyHostToDevice, h->stream)); d_p0 = h->p0_inj; }
     if (log_u) { HIPCHK(hipMemcpyAsync(h->logu_inj, log_u, sizeof(float), hipMemcpyHostToDevice, h->stream)); d_lu = h->logu_inj; }
-    HIPCHK(hipMemcpyAsync(h->eta_prev, h->eta, (size_t)nd.H * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->eta_prev, h->eta, (size_t)C * nd.H * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     // the hyper transition uses the epoch counter of the weight transition that preceded it
     const uint32_t ep = h->epoch > 0 ? h->epoch - 1 : 0;
-    hipLaunchKernelGGL(k_hyper, dim3(1), dim3(HYP_THREADS), 0, h->stream, nd, (int)HYP_STEP, eps_h, (int)L_h, h->eta, h->q_cur,
-                       rows_total(h), d_p0, d_lu, ep, h->key0, h->key1, h->sc, h->hyp_ws, h->sc_out);
+    // (a single-workgroup kernel per chain: the chains of a multi-chain handle go one after the other on the stream)
+    const size_t wsf = hyper_ws_bytes(nd) / sizeof(float);
+    for (int c = 0; c < C; ++c)
+        hipLaunchKernelGGL(k_hyper, dim3(1), dim3(HYP_THREADS), 0, h->stream, nd, (int)HYP_STEP, eps_h, (int)L_h, h->eta + (size_t)c * nd.H,
+                           (const float*)(h->q_cur + (size_t)c * nd.P), rows_total(h), d_p0, d_lu, ep, h->key0, ((h->key1 ^ h->seed_hi) + (uint32_t)c) ^ h->seed_hi,
+                           h->sc + c, h->hyp_ws + c * wsf, h->sc_out + c);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
-    HIPCHK(hipMemcpyAsync(h->sc_host, h->sc_out, sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->sc_host, h->sc_out, (size_t)C * sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1);
-    if (out) fill_out(*h->sc_host, L_h, ms * 1000.f, 0.f, out);
+    if (out)
+        for (int c = 0; c < C; ++c) fill_out(h->sc_host[c], L_h, ms * 1000.f, 0.f, out + c);
     // eta changed => the weight target changed.  The prediction does not depend on eta: the cached statistic stays, the
     // data-term gradient rescales with sigma, the prior terms are recomputed -- O(P), no pass over the rows
     // (TBNN_HYPER_FULL_REFRESH=1: the round-1 behaviour, a whole bootstrap evaluation)
-    if (h->sc_host->accepted) {
+    bool any = false;
+    for (int c = 0; c < C; ++c) any = any || h->sc_host[c].accepted;
+    if (any) {
         static const bool full = getenv("TBNN_HYPER_FULL_REFRESH") && atoi(getenv("TBNN_HYPER_FULL_REFRESH"));
         if (full || !h->cur_valid) h->cur_valid = false;
         else {
-            hipLaunchKernelGGL(k_refresh_grad_after_hyper, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd,
-                               (const float*)h->eta, (const float*)h->q_cur, (const float*)h->gd_cur, h->g_cur);
-            launch_energy(h, EN_REFRESH, h->eta, h->q_cur, nullptr);
+            for (int c = 0; c < C; ++c) {
+                if (!h->sc_host[c].accepted) continue;           // (a rejected chain keeps its cached gradient bit for bit)
+                const size_t cp = (size_t)c * nd.P;
+                hipLaunchKernelGGL(k_refresh_grad_after_hyper, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd,
+                                   (const float*)(h->eta + (size_t)c * nd.H), (const float*)(h->q_cur + cp), (const float*)(h->gd_cur + cp), h->g_cur + cp);
+                hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, nd, (int)EN_REFRESH, (const float*)(h->eta + (size_t)c * nd.H),
+                                   (const float*)(h->q_cur + cp), (const float*)(h->p + cp), (const float*)(h->q_cur + cp),
+                                   stat_ptr(h) + (size_t)c * PSTAT_CAP, stat_entries(h), rows_total(h), h->sc + c, (double*)nullptr);
+            }
             HIPCHK(hipGetLastError());
         }
     }
@@ -1209,6 +1272,7 @@ extern "C" int tbnn_hyper_probs_many(tbnn_handle h, const int32_t* priors, const
 
 extern "C" int tbnn_export_sample_device(tbnn_handle h, float* d_out) {
     NEED(h); if (!d_out) return fail(-1, "null d_out");
+    ONE_CHAIN(h, "tbnn_export_sample_device");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(d_out, h->q_cur, (size_t)h->nd.P * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(d_out + h->nd.P, h->eta, (size_t)h->nd.H * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
@@ -1238,7 +1302,7 @@ extern "C" int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, 
 extern "C" int tbnn_debug_stamps(tbnn_handle h, uint64_t* out5) {
     if (!out5) return fail(-1, "null out16");
     NEED(h);
-    if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0 || h->mid_id >= 0 || h->jit || h->lay || !h->dX) return fail(-1, "debug_stamps: narrow fast kernel + data required");
+    if (h->kernel != TBNN_KERNEL_FAST || h->wide_id >= 0 || h->mid_id >= 0 || h->jit || h->lay || !h->dX || h->C > 1) return fail(-1, "debug_stamps: narrow fast kernel + data required");
     HIPCHK(hipSetDevice(h->device));
     unsigned long long* d = nullptr;
     HIPCHK(hipMalloc(&d, 16 * sizeof(unsigned long long)));

@@ -48,9 +48,9 @@ int mid_image_floats(int id) { int r = 0; MID_DISPATCH(id, r = MidCfg<S>::IMG_FL
 void mid_image_map_id(int id, int* map) { MID_DISPATCH(id, mid_image_map<S>(map)); }
 int mid_grid_id(int, long n) { return mid_grid(n); }
 int mid_launch(int id, int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta, const float* X,
-               const float* Y, long n, float* slabs, int pitch, double* pstat) {
+               const float* Y, long n, float* slabs, int pitch, double* pstat, int nchains, ChainStride cs) {
     int rc = -1;
-    MID_DISPATCH(id, rc = mid_launch_t<S>(grid, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat));
+    MID_DISPATCH(id, rc = mid_launch_t<S>(grid, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, nchains, cs));
     return rc;
 }
 int mid_forward(int id, int gx, int nets, hipStream_t st, const float* qimgs, long img_stride, const float* X, long n,

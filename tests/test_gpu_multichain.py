@@ -1,0 +1,90 @@
+"""GPU: several chains behind one handle (tbnn_create_multi, round 4).  Chain c of a group is BIT FOR BIT the chain
+tbnn_create(..., chain_id + c) is: same Philox key, same kernels, same summation order -- only that the per-chain kernels of
+all chains are one launch each (gridDim.y = chain).  Compared over free-running transitions with accepts and rejects, a hyper
+transition in between, on every kernel family (the batched ones and the chain-by-chain ones)."""
+import numpy as np
+import pytest
+
+import tbnn_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    "fast3_c1": ([1, 10, 10, 1], 1000, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),            # batched: narrow family (configs[0])
+    "fast3_trainreg": ([1, 10, 10, 10, 1], 11, o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_FIXED_GAUSSIAN),
+    "fast_sigmoid": ([4, 7, 3], 130, o.ACT_SIGMOID, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),           # k_fwd_bwd_fast (three outputs on MFMA tiles)
+    "mid": ([4, 24, 40, 1], 517, o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN),                 # batched: mid-width family
+    "tall": ([128, 16, 2], 333, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),                    # batched: tall-fan-in family
+    "wide": ([3, 20, 36, 2], 517, o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN),                # chain by chain: two-kernel wide path
+    "layered": ([40, 24, 24, 3], 600, o.ACT_TANH, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),              # chain by chain: layered family
+    "bern_mid": ([20, 32, 48, 2], 700, o.ACT_SIGMOID, o.PRIOR_CAUCHY, o.LIK_BERNOULLI),
+}
+REC = ("log_accept_ratio", "accepted", "logp_old", "logp_new", "kinetic_old", "kinetic_new", "sjd", "accept_prob")
+
+
+def layers_of(spec):
+    return [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_group_chains_are_the_solo_chains(native, shape):
+    dims, n, act, prior, lik = SHAPES[shape]
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, act, prior, lik)
+    C, c0, seed = 4, 7, (3 << 32) | 50                         # a high seed word too (folded into the key)
+    rng = np.random.default_rng(2)
+    thetas = (theta[None, :] * (1.0 + 0.05 * rng.standard_normal((C, theta.size)))).astype(np.float32)
+    etas = np.tile(eta, (C, 1)).astype(np.float32) * (1.0 + 0.01 * np.arange(C, dtype=np.float32))[:, None]
+    eps_ok, eps_bad = (2e-3 if lik == o.LIK_FIXED_GAUSSIAN else 2e-5), 0.3
+    grp = native.ChainGroup(layers_of(spec), C, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, seed=seed, chain_id=c0, jit=False)
+    grp.set_data(X, Y); grp.set_state(thetas); grp.set_hypers(etas)
+    g1 = grp.hmc_run(eps_ok, 5, 4)
+    g2 = grp.hmc_run(eps_bad, 3, 3)                              # diverging proposals: rejects
+    gh = grp.hyper_step(1e-4, 7) if spec.n_hypers else None
+    g3 = grp.hmc_step(eps_ok, 4)
+    g_state, g_hyp = grp.get_state(), grp.get_hypers()
+    kname = grp.kernel_name
+    grp.close()
+    acc_seen = set()
+    for c in range(C):
+        ch = native.Chain(layers_of(spec), likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, seed=seed, chain_id=c0 + c, jit=False)
+        assert ch.kernel_name == kname
+        ch.set_data(X, Y); ch.set_state(thetas[c]); ch.set_hypers(etas[c])
+        s1 = ch.hmc_run(eps_ok, 5, 4)
+        s2 = ch.hmc_run(eps_bad, 3, 3)
+        sh = ch.hyper_step(1e-4, 7) if spec.n_hypers else None
+        s3 = ch.hmc_step(eps_ok, 4)
+        for got, want in list(zip(g1[c] + g2[c], s1 + s2)) + [(g3[c], s3)] + ([(gh[c], sh)] if sh else []):
+            np.testing.assert_array_equal(np.array([got[k] for k in REC], dtype=np.float64), np.array([want[k] for k in REC], dtype=np.float64))
+            acc_seen.add(int(want["accepted"]))
+        np.testing.assert_array_equal(g_state[c], ch.get_state())
+        np.testing.assert_array_equal(g_hyp[c], ch.get_hypers())
+        ch.close()
+    assert acc_seen == {0, 1}, acc_seen                          # both decisions occurred
+    assert np.abs(g_state[0] - g_state[1]).max() > 0             # and the chains are different chains
+
+
+def test_group_guards(native):
+    spec, X, Y, theta, eta = o.synth_problem([1, 10, 10, 1], 200)
+    grp = native.ChainGroup(layers_of(spec), 3, likelihood=spec.likelihood)
+    grp.set_data(X, Y); grp.set_state(theta); grp.set_hypers(eta)
+    assert grp.C == 3 and grp.get_state().shape == (3, spec.n_params)
+    np.testing.assert_array_equal(grp.get_state(), np.tile(theta, (3, 1)))          # [P] broadcast to every chain
+    import ctypes as C
+    lp = C.c_double()
+    rc = native.lib.tbnn_logp_grad(grp._h, None, None, C.byref(lp), None, None)
+    assert rc < 0 and b"multi-chain" in native.lib.tbnn_last_error()
+    p0 = np.zeros(spec.n_params, dtype=np.float32)
+    out = (native.StepOut * 3)()
+    rc = native.lib.tbnn_hmc_step(grp._h, 1e-5, 2, p0.ctypes.data_as(C.POINTER(C.c_float)), None, out, None)
+    assert rc < 0 and b"multi-chain" in native.lib.tbnn_last_error()
+    with pytest.raises(native.TbnnError):
+        native.ChainGroup(layers_of(spec), 0)
+    # same seed, same chain ids: identical draws whatever the group size
+    a = grp.hmc_run(1e-4, 3, 2)
+    grp.close()
+    g5 = native.ChainGroup(layers_of(spec), 5, likelihood=spec.likelihood)
+    g5.set_data(X, Y); g5.set_state(theta); g5.set_hypers(eta)
+    b = g5.hmc_run(1e-4, 3, 2)
+    for c in range(3):
+        assert [r["log_accept_ratio"] for r in a[c]] == [r["log_accept_ratio"] for r in b[c]]
+    g5.close()
