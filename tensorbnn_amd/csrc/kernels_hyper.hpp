@@ -230,8 +230,15 @@ __device__ __forceinline__ void hyper_owned(const NetDev& nd, int t, int& j0, in
 __global__ __launch_bounds__(HYP_THREADS) void k_hyper(
     NetDev nd, int mode, float eps, int L, float* __restrict__ eta, const float* __restrict__ q, long n,
     const float* __restrict__ p0_inj, const float* __restrict__ logu_inj, uint32_t epoch, uint32_t key0, uint32_t key1,
-    const Scal* __restrict__ sc, float* __restrict__ ws, Scal* __restrict__ out)
+    const Scal* __restrict__ sc, float* __restrict__ ws, Scal* __restrict__ out, uint32_t seed_hi = 0)
 {
+    // gridDim.x = chains of a multi-chain handle (one workgroup runs one chain's whole transition): chain c's [H] hypers, [P] weights,
+    // record, work space, and its Philox key (seed, chain0 + c) -- key1 = chain_id ^ seed_hi
+    if (blockIdx.x) {
+        const uint32_t c = blockIdx.x;
+        eta += (size_t)c * nd.H; q += (size_t)c * nd.P; sc += c; out += c; ws += (size_t)c * 4 * nd.H;
+        key1 = ((key1 ^ seed_hi) + c) ^ seed_hi;
+    }
     __shared__ double part[HYP_WAVES][HYP_MAXG * 3];
     __shared__ double vpart[HYP_MAXG + 1];
     __shared__ float e[HYP_MAXH], e0[HYP_MAXH], p[HYP_MAXH], g[HYP_MAXH];

@@ -1195,12 +1195,10 @@ extern "C" int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const fl
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     // the hyper transition uses the epoch counter of the weight transition that preceded it
     const uint32_t ep = h->epoch > 0 ? h->epoch - 1 : 0;
-    // (a single-workgroup kernel per chain: the chains of a multi-chain handle go one after the other on the stream)
-    const size_t wsf = hyper_ws_bytes(nd) / sizeof(float);
-    for (int c = 0; c < C; ++c)
-        hipLaunchKernelGGL(k_hyper, dim3(1), dim3(HYP_THREADS), 0, h->stream, nd, (int)HYP_STEP, eps_h, (int)L_h, h->eta + (size_t)c * nd.H,
-                           (const float*)(h->q_cur + (size_t)c * nd.P), rows_total(h), d_p0, d_lu, ep, h->key0, ((h->key1 ^ h->seed_hi) + (uint32_t)c) ^ h->seed_hi,
-                           h->sc + c, h->hyp_ws + c * wsf, h->sc_out + c);
+    // (one workgroup runs one chain's whole hyper transition: the chains of a multi-chain handle side by side, gridDim.x = chain)
+    static_assert(sizeof(float) * 4 == 16, "hyper work space: 4 H floats per chain (hyper_ws_bytes)");
+    hipLaunchKernelGGL(k_hyper, dim3(C), dim3(HYP_THREADS), 0, h->stream, nd, (int)HYP_STEP, eps_h, (int)L_h, h->eta, (const float*)h->q_cur, rows_total(h),
+                       d_p0, d_lu, ep, h->key0, h->key1, h->sc, h->hyp_ws, h->sc_out, h->seed_hi);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipMemcpyAsync(h->sc_host, h->sc_out, (size_t)C * sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
