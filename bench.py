@@ -473,8 +473,25 @@ def compact_line(line):
 
 
 def visible_gpus():
-    """GPUs this process could use, counted WITHOUT touching the HIP runtime (the parent of the ranks must stay GPU-free): KFD
-    topology nodes with SIMDs, cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES; None when sysfs does not say"""
+    """GPUs a rank could use, found WITHOUT touching the HIP runtime in this process (the parent of the ranks must stay
+    GPU-free): a short-lived CHILD asks the native library (tbnn_device_count = hipGetDeviceCount).  sysfs is not enough: a
+    container may show the host's whole KFD topology (8 nodes) while one GPU is usable, and eight ranks started on that
+    evidence all open the one card.  Falls back to the KFD node count (cut down by *_VISIBLE_DEVICES) when the child cannot
+    run; None when nothing says."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c",
+                            "import ctypes, sys; l = ctypes.CDLL(sys.argv[1]); l.tbnn_device_count.restype = ctypes.c_int; print(l.tbnn_device_count())",
+                            os.path.join(ROOT, "tensorbnn_amd", "libtbnn.so")], capture_output=True, text=True, timeout=120)
+        n = int(r.stdout.strip().splitlines()[-1])
+        if r.returncode == 0 and n >= 0:
+            return n
+    except Exception:
+        pass
+    return _kfd_gpu_nodes()
+
+
+def _kfd_gpu_nodes():
     try:
         base = "/sys/class/kfd/kfd/topology/nodes"
         cnt = 0
@@ -529,8 +546,8 @@ def main():
     # --gpus N > 1 without a launcher around us: start the N ranks ourselves (one process per GPU) as a CHILD
     # torch.distributed.run and relay rank 0's line.  Nothing in this process has touched the GPU (or imported torch) yet.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        have = visible_gpus()
-        if os.environ.get("TBNN_BENCH_SINGLE_GPU", "0") != "1" and have is not None and have < args.gpus:
+        have = None if os.environ.get("TBNN_BENCH_SINGLE_GPU", "0") == "1" else visible_gpus()
+        if have is not None and have < args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible on this node (one rank per GPU; nothing was started)")
         raise SystemExit(spawn_ranks(args.gpus))
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:      # ranks started by a launcher: same thread caps as spawn_ranks sets

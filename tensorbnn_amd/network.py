@@ -44,6 +44,49 @@ class DualAveraging(object):
         return accept
 
 
+class _SampleFiles(object):
+    """The on-disk sample format of network.train (network.py:546-559, :609-663): <n>.<k>.txt per state tensor, hypers<k>.txt,
+    architecture.txt, summary.txt, rotated every networksPerFile kept samples.  One instance per chain folder."""
+
+    def __init__(self, filePath, states, layers):
+        self.filePath = filePath
+        os.makedirs(filePath, exist_ok=True)
+        self.n_states = len(states)
+        self.files = [open(filePath + "/" + str(n) + ".0" + ".txt", "wb") for n in range(self.n_states)]          # :549-552
+        self.files.append(open(filePath + "/hypers" + "0" + ".txt", "wb"))
+        with open(filePath + "/architecture.txt", "wb") as f:                                                     # :555-559
+            for layer in layers:
+                f.write((layer.name + "\n").encode("utf-8"))
+
+    def after_epoch(self, iter_, startSampling, samplingStep, networksPerFile, states, hyperStates):
+        """iter_: the epoch counter AFTER its increment (network.py:592)"""
+        indexShift = iter_ - startSampling - 1                           # :609-646
+        indexInterval = networksPerFile * samplingStep
+        if iter_ > startSampling and indexShift % indexInterval == 0:
+            for file in self.files:
+                file.close()
+            idx = int((iter_ - startSampling) // (networksPerFile * samplingStep))
+            self.files = [open(self.filePath + "/" + str(n) + "." + str(idx) + ".txt", "wb") for n in range(self.n_states)]
+            self.files.append(open(self.filePath + "/hypers" + str(idx) + ".txt", "wb"))
+            with open(self.filePath + "/summary.txt", "wb") as file:
+                for n in range(self.n_states):
+                    file.write((" ".join(str(s) for s in states[n].shape).strip() + "\n").encode("utf-8"))
+                numNetworks = indexShift // samplingStep
+                numFiles = numNetworks // networksPerFile
+                if numNetworks % networksPerFile != 0:
+                    numFiles += 1
+                file.write((str(numNetworks) + " " + str(numFiles) + " " + str(self.n_states) + "\n").encode("utf-8"))
+                file.write(str(int(sum(h.size for h in hyperStates))).encode("utf-8"))
+        if iter_ > startSampling and iter_ % samplingStep == 0:          # :648-663
+            for n in range(len(self.files) - 1):
+                np.savetxt(self.files[n], states[n])
+            np.savetxt(self.files[-1], [np.reshape(h, (1,)) for h in hyperStates])
+
+    def close(self):
+        for file in self.files:
+            file.close()
+
+
 class network(object):
     def __init__(self, dtype, inputDims, trainX, trainY, validateX, validateY, device=0, chain_id=0, seed=50,
                  kernel=nat.KERNEL_AUTO):
@@ -211,16 +254,9 @@ class network(object):
         ch.set_state(self._theta())
         ch.set_hypers(np.concatenate(self.hyperStates) if self.hyperStates else np.zeros(0, np.float32))
 
-        filePath, files = None, []
+        writer = None
         if folderName is not None:                                           # :546-559
-            filePath = os.path.join(os.getcwd(), folderName)
-            os.makedirs(filePath, exist_ok=True)
-            for n in range(len(self.states)):
-                files.append(open(filePath + "/" + str(n) + ".0" + ".txt", "wb"))
-            files.append(open(filePath + "/hypers" + "0" + ".txt", "wb"))
-            with open(filePath + "/architecture.txt", "wb") as f:
-                for layer in self.layers:
-                    f.write((layer.name + "\n").encode("utf-8"))
+            writer = _SampleFiles(os.path.join(os.getcwd(), folderName), self.states, self.layers)
 
         iter_ = 0
         self.mainAccept = np.float32(0)
@@ -256,35 +292,81 @@ class network(object):
                 self.step_size, self.leapfrog = np.float32(step), np.int32(leap)
                 rec["sjd"] = self.adapt.lastSJD
 
-            indexShift = iter_ - startSampling - 1                           # :609-646
-            indexInterval = networksPerFile * samplingStep
-            if filePath is not None and iter_ > startSampling and indexShift % indexInterval == 0:
-                for file in files:
-                    file.close()
-                idx = int((iter_ - startSampling) // (networksPerFile * samplingStep))
-                files = [open(filePath + "/" + str(n) + "." + str(idx) + ".txt", "wb") for n in range(len(self.states))]
-                files.append(open(filePath + "/hypers" + str(idx) + ".txt", "wb"))
-                with open(filePath + "/summary.txt", "wb") as file:
-                    for n in range(len(self.states)):
-                        file.write((" ".join(str(s) for s in self.states[n].shape).strip() + "\n").encode("utf-8"))
-                    numNetworks = indexShift // samplingStep
-                    numFiles = numNetworks // networksPerFile
-                    if numNetworks % networksPerFile != 0:
-                        numFiles += 1
-                    file.write((str(numNetworks) + " " + str(numFiles) + " " + str(len(self.states)) + "\n").encode("utf-8"))
-                    file.write(str(int(sum(h.size for h in self.hyperStates))).encode("utf-8"))
-            if iter_ > startSampling and iter_ % samplingStep == 0:          # :648-663
-                if filePath is not None:
-                    for n in range(len(files) - 1):
-                        np.savetxt(files[n], self.states[n])
-                    np.savetxt(files[-1], [np.reshape(h, (1,)) for h in self.hyperStates])
-                if gather is not None:
-                    gather(ch, iter_)
+            if writer is not None:                                           # :609-663
+                writer.after_epoch(iter_, startSampling, samplingStep, networksPerFile, self.states, self.hyperStates)
+            if gather is not None and iter_ > startSampling and iter_ % samplingStep == 0:
+                gather(ch, iter_)
             if verbose and iter_ % displaySkip == 0:                         # :664-667
                 likelihood.display(self.hyperStates)
                 print("Time elapsed:", time.time() - startTime)
                 startTime = time.time()
             records.append(rec)
-        for file in files:
-            file.close()
+        if writer is not None:
+            writer.close()
+        return records
+
+    def trainChains(self, chains, epochs, samplingStep, likelihood, adjustHypers=True, folderName=None, networksPerFile=1000,
+                    verbose=False):
+        """NEW (no counterpart in the reference, which runs one chain): `chains` independent chains of this network on the one
+        GPU behind one native handle (tbnn_create_multi): chain c has the Philox stream of chain_id + c and is bit for bit what a
+        single-chain run with that chain_id would be at the same (eps, L) schedule.  All chains start from the network's
+        current state and advance in lockstep; the (eps, L) adapter and the hyper step's dual averaging are driven by chain 0
+        (one schedule for all).  Samples go to folderName/chain<c>/ in the reference's format (readable by `predictor`).
+        For problems that leave the GPU idle -- the reference's examples: tens to thousands of rows -- C chains cost about what
+        one costs.  Returns the per-epoch records (rec["main"]: one transition record per chain)."""
+        startSampling = self.burnin
+        self.likelihood = likelihood
+        if self._lik_hypers:
+            del self.hyperStates[-self._lik_hypers:]
+        for val in likelihood.hypers:
+            self.hyperStates.append(np.asarray(val, dtype=np.float32).reshape(1))
+        self._lik_hypers = len(likelihood.hypers)
+        grp = nat.ChainGroup(self._dense, int(chains), likelihood=likelihood.kind, fixed_sd=float(getattr(likelihood, "fixed_sd", 0.1)),
+                             device=self.device, seed=self.seed, chain_id=self.chain_id, kernel=self.kernel)
+        if verbose:
+            print("tensorbnn_amd: fused kernel", grp.kernel_name, "x", grp.C, "chains")
+        grp.set_data(self.trainX, self.trainY.reshape(len(self.trainX), -1))
+        grp.set_state(self._theta())
+        grp.set_hypers(np.concatenate(self.hyperStates) if self.hyperStates else np.zeros(0, np.float32))
+        shapes = [s_.shape for s_ in self.states]
+
+        def split(theta):
+            out, o = [], 0
+            for shp in shapes:
+                size = int(np.prod(shp))
+                out.append(theta[o:o + size].reshape(shp).copy())
+                o += size
+            return out
+
+        writers = None
+        if folderName is not None:
+            writers = [_SampleFiles(os.path.join(os.getcwd(), folderName, "chain%d" % c), self.states, self.layers) for c in range(grp.C)]
+        records, iter_ = [], 0
+        try:
+            while iter_ < epochs:
+                outs = grp.hmc_step(float(self.step_size), int(self.leapfrog))
+                rec = {"iter": iter_, "eps": float(self.step_size), "L": int(self.leapfrog), "main": outs}
+                if adjustHypers and grp.H > 0:
+                    houts = grp.hyper_step(float(self.hyper_step_size), int(self.hyperLeapfrog))
+                    self.hyperAccept = self._dual_averaging(iter_, houts[0]["log_accept_ratio"])
+                    rec["hyper"] = houts
+                    rec["hyper_step_size"] = float(self.hyper_step_size)
+                thetas, etas = grp.get_state(), grp.get_hypers()
+                self._set_states_from(thetas[0])                          # the network object mirrors chain 0
+                self.hyperStates = [etas[0][i:i + 1].copy() for i in range(etas.shape[1])]
+                self.mainAccept = np.float32(np.mean([o_["accept_prob"] for o_ in outs]))
+                iter_ += 1
+                if self.adapt_enabled:
+                    step, leap = self.adapt.update(self.states)
+                    self.step_size, self.leapfrog = np.float32(step), np.int32(leap)
+                if writers is not None:
+                    for c, w in enumerate(writers):
+                        w.after_epoch(iter_, startSampling, samplingStep, networksPerFile, split(thetas[c]),
+                                      [etas[c][i:i + 1] for i in range(etas.shape[1])])
+                records.append(rec)
+        finally:
+            if writers is not None:
+                for w in writers:
+                    w.close()
+            grp.close()
         return records

@@ -88,3 +88,49 @@ def test_group_guards(native):
     for c in range(3):
         assert [r["log_accept_ratio"] for r in a[c]] == [r["log_accept_ratio"] for r in b[c]]
     g5.close()
+
+
+def test_train_chains_flow(tmp_path, monkeypatch, native):
+    """network.trainChains (new): the literal trainRegression problem (11 rows) as 5 chains on the one GPU through the drop-in
+    Python API -- one (eps, L) schedule from chain 0's adapter, per-chain sample folders in the reference's format that
+    `predictor` reads back; chain 0 of the group IS the single-chain `train` run of the same network (same records)."""
+    import math
+    from tensorbnn_amd.activationFunctions import Tanh
+    from tensorbnn_amd.layer import GaussianDenseLayer
+    from tensorbnn_amd.likelihood import FixedGaussianLikelihood
+    from tensorbnn_amd.network import network
+    from tensorbnn_amd.predictor import predictor
+    monkeypatch.chdir(tmp_path)
+    trainIn = np.linspace(-2, 2, num=11)
+    valIn = np.linspace(-2 + 2 / 30, 2.0 - 2 / 30, num=30)
+    trainOut = np.sin(trainIn * math.pi * 2) * trainIn - np.cos(trainIn * math.pi)
+    valOut = np.sin(valIn * math.pi * 2) * valIn - np.cos(valIn * math.pi)
+
+    def make():
+        net = network(np.float32, 1, trainIn, trainOut.T, valIn, valOut.T)
+        seed = 1000
+        net.add(GaussianDenseLayer(1, 10, seed=seed)); net.add(Tanh()); seed += 1000
+        for _ in range(2):
+            net.add(GaussianDenseLayer(10, 10, seed=seed)); net.add(Tanh()); seed += 1000
+        net.add(GaussianDenseLayer(10, 1, seed=seed))
+        net.setupMCMC(stepSizeStart=1e-3, stepSizeMin=1e-4, stepSizeMax=1e-2, stepSizeOptions=20, leapfrogStart=50,
+                      leapfogMin=10, leapFrogMax=100, leapfrogIncrement=10, hyperStepSize=0.001, hyperLeapfrog=20,
+                      burnin=20, averagingSteps=5)
+        return net
+
+    C = 5
+    rec = make().trainChains(C, 41, 10, FixedGaussianLikelihood(sd=0.1), adjustHypers=True, folderName="multi", networksPerFile=2)
+    assert len(rec) == 41 and all(len(r["main"]) == C for r in rec)
+    solo = make().train(41, 10, FixedGaussianLikelihood(sd=0.1), adjustHypers=True, folderName="solo", networksPerFile=2, verbose=False)
+    for rg, rs in zip(rec, solo):                                     # chain 0 of the group == the single-chain run, epoch by epoch
+        assert rg["eps"] == rs["eps"] and rg["L"] == rs["L"]
+        assert rg["main"][0]["log_accept_ratio"] == rs["main"]["log_accept_ratio"] and rg["main"][0]["accepted"] == rs["main"]["accepted"]
+        assert rg["hyper"][0]["log_accept_ratio"] == rs["hyper"]["log_accept_ratio"]
+    ps = predictor(str(tmp_path / "solo") + "/")
+    finals = []
+    for c in range(C):
+        p = predictor(str(tmp_path / "multi" / ("chain%d" % c)) + "/")
+        assert p.numNetworks == ps.numNetworks == 2 and p.hypers[0].shape == (16,)
+        finals.append(p.vectors[-1])
+    np.testing.assert_array_equal(finals[0], ps.vectors[-1])          # same samples on disk
+    assert all(np.abs(finals[c] - finals[0]).max() > 0 for c in range(1, C))       # the other chains went their own way

@@ -449,7 +449,7 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     assert e.value.code == 7 and seen
 
 
-def test_visible_gpus_respects_visibility_masks(monkeypatch, tmp_path):
+def test_visible_gpus(monkeypatch, tmp_path):
     sys.path.insert(0, ROOT)
     import bench
     nodes = tmp_path / "nodes"
@@ -462,6 +462,10 @@ def test_visible_gpus_respects_visibility_masks(monkeypatch, tmp_path):
     monkeypatch.setattr(builtins, "open", lambda p, *a, **k: real_open(str(p).replace("/sys/class/kfd/kfd/topology/nodes", str(nodes)), *a, **k))
     for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         monkeypatch.delenv(v, raising=False)
-    assert bench.visible_gpus() == 3
+    assert bench._kfd_gpu_nodes() == 3
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
-    assert bench.visible_gpus() == 2
+    assert bench._kfd_gpu_nodes() == 2
+    # the count that decides comes from a CHILD asking the native library (this process never touches HIP): no device here
+    import builtins as _b
+    monkeypatch.setattr(_b, "open", real_open); monkeypatch.setattr(os, "listdir", real_listdir)
+    assert bench.visible_gpus() in (0, None)
