@@ -457,18 +457,18 @@ def compact_line(line):
                 continue
             e = {"value": r["value"], "ms_per_step": r["ms_per_step"], "accept": r["accept_ratio"], "L": r["config"]["leapfrog_per_step"]}
             rf = r.get("roofline") or {}
-            for k in ("frac", "frac_rocprof", "kernel_us", "traffic"):
+            for k in ("frac", "frac_rocprof", "traffic"):
                 if rf.get(k) is not None:
                     e[k] = rf[k]
             c = r.get("cpu_baseline")
             if c:
-                e["cpu"] = c["value"]; e["cpu_cores"] = c["cores"]
+                e["cpu"] = c["value"]
             if "hyper_accept_ratio" in r:
                 e["hyper_accept"] = r["hyper_accept_ratio"]
                 e["hyper_step"] = float("%.3g" % r["hyper_step_size"]["last"]) if r.get("hyper_step_size") else None
             sec[key.replace(" with GaussianDenseLayer priors", "g")] = e
         out["secondary"] = sec
-        out["secondary_note"] = "configs[4]: Cauchy priors (improper hyper target, Q1); [4]g: Gaussian priors; full record: gpurun_out/bench_full.json"
+        out["secondary_note"] = "[4]: Cauchy priors (improper hyper target, Q1); [4]g: Gaussian priors; [0]x64: 64 chains on ONE GPU; full: gpurun_out/bench_full.json"
     return out
 
 
