@@ -161,3 +161,52 @@ def test_mid_long_fan_in(native, dims, n, act, lik):
     lar_tol = 2e-2 + 1e-4 * abs(ref.log_accept_ratio) + 1e-6 * abs(ref.trace_logp[0])       # (resolution term: see test_transition_tall)
     assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= lar_tol, (out["log_accept_ratio"], ref.log_accept_ratio, ref.trace_logp[0])
     ch.close()
+
+
+def _free_running(native, dims, n, lik, X_scale, eps, epochs, L, family, jit=None):
+    """a free-running chain on the HIP kernel against oracle/c with the same draws, each carrying its OWN state forward"""
+    import c_oracle
+    from test_gpu_fullsize import away_from, lar_tol
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, o.ACT_RELU, o.PRIOR_CAUCHY, lik)
+    if X_scale:
+        X = (np.abs(X) * X_scale).astype(np.float32)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    ch = native.Chain(layers, likelihood=spec.likelihood, jit=jit)
+    assert family in ch.kernel_name, ch.kernel_name
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    co = c_oracle.COracle(spec, X, Y)
+    rng = np.random.default_rng(2025)
+    th_c = theta.copy()
+    acc_g, acc_c, dlar, agree = [], [], [], 0
+    for ep in range(epochs):
+        p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+        q_c, lar_c, lp0_c, _ = co.hmc_propose(th_c, eta, eps, L, p0)
+        lu = away_from(rng, lar_c)
+        if lu < lar_c:
+            th_c = q_c
+        out = ch.hmc_step(eps, L, p0=p0, log_u=lu)
+        agree += int(bool(out["accepted"]) == (lu < lar_c))
+        if np.isfinite(lar_c) and lar_c > -50.0:                       # (a diverged trajectory: both arms reject, the value is not compared)
+            dlar.append(abs(out["log_accept_ratio"] - lar_c) / lar_tol(lar_c, lp0_c))
+        else:
+            assert not out["accepted"]
+        acc_g.append(out["accept_prob"]); acc_c.append(min(1.0, float(np.exp(min(lar_c, 0.0)))))
+    mg, mc = float(np.mean(acc_g)), float(np.mean(acc_c))
+    dist = float(np.abs(ch.get_state() - th_c).max() / np.abs(th_c).max())
+    print(f"free-running {dims} on {ch.kernel_name}: accept ratio HIP {mg:.4f} oracle/c {mc:.4f}; decisions {agree}/{epochs}; "
+          f"max |dlar| / lar_tol {max(dlar):.3f}; state distance {dist:.1e}")
+    ch.close()
+    assert abs(mg - mc) <= 0.02, (mg, mc)
+    assert agree == epochs and dlar and max(dlar) <= 1.0, (agree, max(dlar) if dlar else None)
+    return mg, mc
+
+
+def test_free_running_mnist_shape_on_the_tall_kernel(native):
+    """north_star's "accept-ratio parity +-0.02" on the round's new family: 784 -> 20 -> 20 -> 1, 12,000 pixel-like rows, 30 free-running
+    epochs of L = 10 against the C restatement (same p0 and log u; every decision equal)"""
+    _free_running(native, [784, 20, 20, 1], 12000, o.LIK_BERNOULLI, 1.0 / 28.0, 5e-3, 30, 10, "tall<")
+
+
+def test_free_running_long_fan_in_on_the_mid_kernel(native):
+    """the mid-width family beyond fan-in 32: 100 -> 50 -> 50 -> 1 at BASELINE configs[1]'s row count (1e5), 12 free-running epochs"""
+    _free_running(native, [100, 50, 50, 1], 100_000, o.LIK_GAUSSIAN, None, 2e-5, 12, 5, "mid<", jit=True)     # (the initial state is a cliff: 2.8e-5 accepts everything, 3.2e-5 nothing)
