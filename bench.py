@@ -218,7 +218,8 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
     # the route, so a rank that cannot load / join says so through torch.distributed before anyone enters a collective
     comm, gather_kind = None, "none"
     sample = gathered = None
-    if world > 1:
+    dist_on = ctx["dist"]                 # world > 1, or TBNN_BENCH_FORCE_DIST=1: the N > 1 code path at world = 1 (real RCCL on one GPU)
+    if dist_on:
         cdev = ctx["cdev"]
         ok = 1
         try:
@@ -263,7 +264,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
             else:
                 outs += ch.hmc_run(eps, L, k)
             done += k
-            if world > 1:                      # checkpoint-time gather over RCCL/xGMI
+            if dist_on:                        # checkpoint-time gather over RCCL/xGMI
                 if comm is not None:
                     ch.gather_samples(comm)
                 else:
@@ -275,7 +276,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
         return outs
 
     def fence():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -296,7 +297,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
     fence()
     dt = time.perf_counter() - t0
     ranks = None
-    if world > 1:
+    if dist_on:
         cdev = ctx["cdev"]
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -586,9 +587,13 @@ def main():
         raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
     dev = 0 if single_gpu else local_rank
     torch.cuda.set_device(dev)
-    ctx = {"single_gpu": single_gpu, "cdev": "cpu" if single_gpu else "cuda"}
-    if world > 1:
+    # TBNN_BENCH_FORCE_DIST=1 (test hook): run the N > 1 code path -- process group, native communicator, gather inside the timed
+    # region, per-rank diagnostics -- at world = 1, i.e. against the REAL RCCL on a one-GPU box
+    force_dist = os.environ.get("TBNN_BENCH_FORCE_DIST", "0") == "1"
+    ctx = {"single_gpu": single_gpu, "cdev": "cpu" if single_gpu else "cuda", "dist": world > 1 or force_dist}
+    if ctx["dist"]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if single_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -628,7 +633,7 @@ def main():
         except OSError:
             pass
         print(json.dumps(compact_line(line)), flush=True)
-    if world > 1:
+    if ctx["dist"]:
         dist.destroy_process_group()
 
 

@@ -192,6 +192,29 @@ def test_bench_three_ranks_rehearsal(tmp_path):
     print(f"3-rank rehearsal: {time.time() - t0:.0f} s, per-rank steps/s {full['ranks']['steps_per_s']}")
 
 
+def test_bench_distributed_path_on_the_real_rccl(tmp_path):
+    """The N > 1 code path of bench.py against the REAL collective library, as far as one GPU allows: world = 1 with
+    TBNN_BENCH_FORCE_DIST=1 -- torch's "nccl" process group (RCCL) on the device, the unique id through broadcast_object_list,
+    ncclCommInitRank / ncclAllGather / ncclCommCount through the C ABI's own plumbing inside the timed region, the per-rank
+    diagnostics gathered over the process group.  (More than one rank needs more than one GPU: RCCL refuses two ranks per device.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = _bench_env(TBNN_BENCH_FORCE_DIST="1")
+    env.pop("TBNN_RCCL_LIB", None)                                   # the real librccl.so (torch's copy is re-used)
+    env.pop("TBNN_BENCH_SINGLE_GPU", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--sampling-step", "2",
+           "--no-secondary", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["sample_gather"].startswith("tbnn_gather_samples (RCCL")
+    assert d["ranks"]["nccl_comm_count"] == [1] and d["ranks"]["native_gather"] is True and d["value"] > 0
+    full = [json.loads(l) for l in r.stderr.splitlines() if l.startswith("{")][-1]
+    assert full["ranks"]["collective_library"] == "librccl (RCCL)"
+
+
 def test_bench_rank_death_is_a_nonzero_exit(tmp_path):
     """a rank that dies inside the timed region (test hook TBNN_BENCH_FAIL_RANK) takes the whole job down: non-zero exit code,
     no result line, no hang"""

@@ -32,6 +32,7 @@ def test_comm_world1_gather(native):
     ch = chain_of(native, spec)
     ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
     comm = native.Comm(ch, 1, 0, native.comm_unique_id())
+    assert comm.count() == 1                     # ncclCommCount through the real RCCL (what bench.py reports per rank at N > 1)
     g = ch.gather_samples(comm)
     assert g.shape == (1, spec.n_params + spec.n_hypers)
     np.testing.assert_array_equal(g[0, :spec.n_params], theta)
