@@ -193,6 +193,15 @@ __device__ __forceinline__ void mfma16_acc(f32x4& c, float a, float b) {
     c = mfma16(a, b, c);
 #endif
 }
+template <bool FAR>
+__device__ __forceinline__ void mfma4_acc(f32x4& c, float a, float b) {        // the 16-block 4x4x1 form, accumulator pinned like mfma16_acc
+#if TBNN_ACC_AGPR
+    if constexpr (FAR) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else c = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+#else
+    c = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+#endif
+}
 __device__ __forceinline__ void mfma_drain() {
 #if TBNN_ACC_AGPR
     asm volatile("s_nop 15\n\ts_nop 15");
@@ -297,6 +306,18 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // would cost four v_mov to splat it, one v_add afterwards is cheaper)
 __device__ __forceinline__ float gsum_mfma(float p) {
     return mfma16(1.f, p, f32x4{0.f, 0.f, 0.f, 0.f})[0];
+}
+
+
+// sum over the 4 lane groups (same lane&15) with the gfx950 row-swap instructions: VALU only, no
+// LDS round trip (ds_bpermute would put ~2 x 100 cycles of latency on the layer chain)
+__device__ __forceinline__ float gsum(float p) {
+    const unsigned a = __float_as_uint(p);
+    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);   // lanes l and l^32
+    const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const unsigned b = __float_as_uint(s);
+    const auto q = __builtin_amdgcn_permlane16_swap(b, b, false, false);   // rows r and r^1
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
 

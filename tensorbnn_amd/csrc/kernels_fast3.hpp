@@ -88,17 +88,6 @@ struct Tile3 {
     float x0[C::KS0];
 };
 
-// sum over the 4 lane groups (same lane&15) with the gfx950 row-swap instructions: VALU only, no
-// LDS round trip (ds_bpermute would put ~2 x 100 cycles of latency on the layer chain)
-__device__ __forceinline__ float gsum(float p) {
-    const unsigned a = __float_as_uint(p);
-    const auto r = __builtin_amdgcn_permlane32_swap(a, a, false, false);   // lanes l and l^32
-    const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    const unsigned b = __float_as_uint(s);
-    const auto q = __builtin_amdgcn_permlane16_swap(b, b, false, false);   // rows r and r^1
-    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
-}
-
 // TBNN_F3_M4 (default): the fringe dot products on the 16-block v_mfma_f32_4x4x1_f32 instead of VALU FMAs.
 // Block b = lane/4 = (lane group g, row quad i16/4) multiplies A[m = i16&3] = W[fringe unit m][k-slot of group g] by
 // B[n = i16&3] = a[k-slot][row i16] -- the D-layout activation register as it stands -- so after one instruction per

@@ -56,6 +56,14 @@ struct TallCfg {
     static constexpr int MAXT = maxT();
     // layer 0: the rows' columns in their own order (slot = column, the ones slot at column d_in), split over the waves
     static constexpr int MT0 = TR(1);
+    // fringe: a first layer of 16 T + F units with 1 <= F <= 4 (20 = 16 + 4: the MNIST example) computes units 16 T .. 16 T + F - 1
+    // on the 16-block v_mfma_f32_4x4x1 (8 cycles instead of 32 per k-step and column tile), in the forward pass and in dW_0
+#ifndef TALL_FRINGE
+#define TALL_FRINGE 1
+#endif
+    static constexpr int F0 = out(0) % 16;
+    static constexpr bool FR0 = TALL_FRINGE && F0 >= 1 && F0 <= 4;
+    static constexpr int MTF = FR0 ? MT0 - 1 : MT0;                     // full tiles of layer 0's units
     static constexpr int NT0 = cdiv(d_in + 1, 16);                      // column tiles of [x, 1]
     static constexpr int CH = cdiv(NT0, NW);                            // column tiles per wave
     static constexpr int NTP = NW * CH;                         // padded tile count of the W_0 image
@@ -170,7 +178,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
     fetch(tile, xn);
 
     // ---- prologue: this wave's chunk of W_0 -> registers; the small image -> LDS; the per-wave blocks zeroed
+    // (fringe tile: the 4x4x1 MFMA's A operand of lane l is W_0[unit 16 T + (l & 3)][k-phase l / 16] -- fringe unit e sits in slot
+    // 16 T + 4 e (slot_of), i.e. in image lane 16 (l / 16) + 4 (l & 3))
     f32x4 Wr[MT0][CH];
+    const int flane = (lane & 48) | ((lane & 3) << 2);
     {
         const f32x4* w4 = reinterpret_cast<const f32x4*>(qimg);
 #pragma unroll
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 #ifdef TALL_DBG_NOPRO          // diagnostic build: what the W_0 chunk's loads cost
             for (int c = 0; c < CH; ++c) Wr[t][c] = f32x4{0.001f * lane, 0.002f, 0.003f * c, 0.004f * t};
 #else
-            for (int c = 0; c < CH; ++c) Wr[t][c] = w4[(size_t)(t * C::NTP + kt0 + c) * 64 + lane];
+            for (int c = 0; c < CH; ++c) Wr[t][c] = w4[(size_t)(t * C::NTP + kt0 + c) * 64 + ((C::FR0 && t == C::MTF) ? flane : lane)];
 #endif
     }
     float* wl = lds + C::WAVE_OFF + wave * C::WAVE_FLOATS;
@@ -241,13 +252,27 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int t = 0; t < MT0; ++t) acc0[c & 1][t] = mfma16(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
+                for (int t = 0; t < MT0; ++t) {
+                    if (C::FR0 && t == C::MTF) acc0[c & 1][t] = mfma4(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
+                    else acc0[c & 1][t] = mfma16(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
+                }
         // the next tile's rows: x's registers are free from here on, the loads land under the rest of this tile
         fetch(tile + gridDim.x, xn);
         {
             f32x4* ex = reinterpret_cast<f32x4*>(lds + C::EX_OFF) + buf * (TALL_WAVES * MT0 * 64);
 #pragma unroll
-            for (int t = 0; t < MT0; ++t) ex[(wave * MT0 + t) * 64 + lane] = acc0[0][t] + acc0[1][t];
+            for (int t = 0; t < MT0; ++t) {
+                f32x4 z = acc0[0][t] + acc0[1][t];
+                if (C::FR0 && t == C::MTF) {
+                    // block b = lane / 4 = (k-phase g, row quad): register m of lane (row, g) = unit 16 T + m over the k-slots of phase
+                    // g; summed over the four phases, unit 16 T + g dropped into register 0 of lane group g (its slot, 16 T + 4 g)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) z[m] = gsum(z[m]);
+                    const float sel = g == 0 ? z[0] : (g == 1 ? z[1] : (g == 2 ? z[2] : z[3]));
+                    z = f32x4{sel, 0.f, 0.f, 0.f};
+                }
+                ex[(wave * MT0 + t) * 64 + lane] = z;
+            }
         }
         __syncthreads();
         f32x4 a[C::MAXT];                  // the current layer's input a_l, D layout: tile t reg j of lane (r, g) = slot 16t+4g+j of row r
@@ -391,13 +416,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
             for (int s = 0; s < 4; ++s) {
                 float Aop[MT0], Bop[CH];
 #pragma unroll
-                for (int t = 0; t < MT0; ++t) Aop[t] = db0[t * 256 + 64 * s + lane];
+                for (int t = 0; t < MT0; ++t) {
+                    // fringe tile: block b = (row phase g, column quad), A[m] = delta_0[row 4 s + g][unit 16 T + m] (slot 4 m of the
+                    // block); B is the full tiles' operand as it stands; register m = dW_0[16 T + m][column] over the rows of phase g
+                    if (C::FR0 && t == C::MTF) Aop[t] = db0[t * 256 + (4 * s + g) * 16 + 4 * (lane & 3)];
+                    else Aop[t] = db0[t * 256 + 64 * s + lane];
+                }
 #pragma unroll
                 for (int c = 0; c < CH; ++c) Bop[c] = xb[c * 256 + 64 * s + lane];
 #pragma unroll
                 for (int t = 0; t < MT0; ++t)
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) mfma16_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
+                    for (int c = 0; c < CH; ++c) {
+                        if (C::FR0 && t == C::MTF) mfma4_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
+                        else mfma16_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
+                    }
             }
         }
         }   // !FWD
@@ -426,10 +459,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                     for (int r = 0; r < 4; ++r) stg[c * 256 + (4 * g + r) * 16 + i16] = v[r];
                 });
                 const int m = lane >> 2, n4 = (lane & 3) * 4;
-                const int row = unit_of(out0, 16 * t + m, false);
+                constexpr bool FT = C::FR0 && t == C::MTF;             // fringe tile: staged as [row phase g][unit m = r], summed over the phases here
+                const int row = FT ? (m < C::F0 ? 16 * t + m : -1) : unit_of(out0, 16 * t + m, false);
 #pragma unroll
                 for (int c = 0; c < CH; ++c) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(stg + c * 256 + 4 * lane);
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + c * 256 + 4 * (FT ? lane & 15 : lane));
+                    if constexpr (FT) {
+#pragma unroll
+                        for (int ph = 1; ph < 4; ++ph) v += *reinterpret_cast<const f32x4*>(stg + c * 256 + 64 * ph + 4 * (lane & 15));
+                    }
                     const int col = 16 * (kt0 + c) + n4;
                     if (row >= 0) {
 #ifdef TALL_DBG_NOSTORE        // diagnostic build: what the dW_0 slab stores cost
@@ -444,10 +482,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 sfor<0, CH>(SFOR_LAMBDA(c) {
                     constexpr int c = SFOR_VAL(c);
                     const int col = 16 * (kt0 + c) + i16;
-                    const f32x4 v = dW0[t * CH + c];
+                    f32x4 v = dW0[t * CH + c];
+                    constexpr bool FT = C::FR0 && t == C::MTF;
+                    if constexpr (FT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gsum(v[r]);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = unit_of(out0, 16 * t + 4 * g + r, false);
+                        const int row = FT ? ((g == 0 && r < C::F0) ? 16 * t + r : -1) : unit_of(out0, 16 * t + 4 * g + r, false);
                         if (row >= 0 && col <= d_in)
                             slab_store<WT>(slab + (col < d_in ? row * d_in + col : d_in * out0 + row), v[r]);
                     }

@@ -152,7 +152,9 @@ static const FusedOps* find_jit(const NetDev& nd) {
 }
 // a FusedOps table for this network: a run-time registered library first, then the ahead-of-time tall-fan-in instantiations
 static const FusedOps* find_ops(const NetDev& nd) {
-    const FusedOps* o = find_jit(nd);
+    // TBNN_REGISTERED=0 (the layered family's tests): tbnn_create ignores kernel libraries registered earlier in the process
+    const bool jit_on = !(getenv("TBNN_REGISTERED") && atoi(getenv("TBNN_REGISTERED")) == 0);
+    const FusedOps* o = jit_on ? find_jit(nd) : nullptr;
     if (o) return o;
     // TBNN_TALL=0 (diagnostic / A-B runs, the layered family's tests): shapes the tall-fan-in registry covers take the layered path
     const bool tall_on = !(getenv("TBNN_TALL") && atoi(getenv("TBNN_TALL")) == 0);
@@ -183,7 +185,7 @@ extern "C" int tbnn_fused_kernel_available(const tbnn_net_desc* desc) {
     if (rc) return rc;
     if (fast_lookup(nd) >= 0 || mid_lookup(nd) >= 0) return 1;
     if (wide_lookup(nd) >= 0) return 2;
-    if (find_ops(nd)) return find_jit(nd) ? 3 : 1;
+    if (const FusedOps* o = find_ops(nd)) return o == find_jit(nd) ? 3 : 1;
     return 0;
 }
 

@@ -55,6 +55,7 @@ def layered_family_only(monkeypatch):
     """this module tests the layered family: the 784 -> 20 -> 20 -> 1 cases stay on it although the tall-fan-in fused kernel
     (kernels_tall.hpp, tests/test_gpu_tall.py) is what a chain gets for that shape by default"""
     monkeypatch.setenv("TBNN_TALL", "0")
+    monkeypatch.setenv("TBNN_REGISTERED", "0")   # nor on a kernel library another test module registered in this process
 
 
 def make_chain(native, spec, kernel, **kw):

@@ -180,7 +180,7 @@ def _free_running(native, dims, n, lik, X_scale, eps, epochs, L, family, jit=Non
     co = c_oracle.COracle(spec, X, Y)
     rng = np.random.default_rng(2025)
     th_c = theta.copy()
-    acc_g, acc_c, dlar, agree = [], [], [], 0
+    acc_g, acc_c, dlar, agree, dist = [], [], [], 0, 0.0
     for ep in range(epochs):
         p0 = rng.standard_normal(spec.n_params).astype(np.float32)
         q_c, lar_c, lp0_c, _ = co.hmc_propose(th_c, eta, eps, L, p0)
@@ -189,18 +189,23 @@ def _free_running(native, dims, n, lik, X_scale, eps, epochs, L, family, jit=Non
             th_c = q_c
         out = ch.hmc_step(eps, L, p0=p0, log_u=lu)
         agree += int(bool(out["accepted"]) == (lu < lar_c))
+        # lar is a function of the state the epoch starts from: the two values are held against the fp32 band while the two chains
+        # are at the same state to fp32 resolution.  Two fp32 evaluations with different summation orders drift apart over free-running
+        # epochs (a relu unit flipping on one side is enough: 784 -> 20 -> 20 -> 1 goes from 2e-7 to 5e-4 in 30 epochs, with the fused
+        # kernel's fringe units on the 4x4x1 MFMA as without); what is compared THROUGHOUT is every decision and the accept ratio
         if np.isfinite(lar_c) and lar_c > -50.0:                       # (a diverged trajectory: both arms reject, the value is not compared)
-            dlar.append(abs(out["log_accept_ratio"] - lar_c) / lar_tol(lar_c, lp0_c))
+            if dist <= 2e-5:
+                dlar.append(abs(out["log_accept_ratio"] - lar_c) / lar_tol(lar_c, lp0_c))
         else:
             assert not out["accepted"]
         acc_g.append(out["accept_prob"]); acc_c.append(min(1.0, float(np.exp(min(lar_c, 0.0)))))
+        dist = float(np.abs(ch.get_state() - th_c).max() / np.abs(th_c).max())
     mg, mc = float(np.mean(acc_g)), float(np.mean(acc_c))
-    dist = float(np.abs(ch.get_state() - th_c).max() / np.abs(th_c).max())
     print(f"free-running {dims} on {ch.kernel_name}: accept ratio HIP {mg:.4f} oracle/c {mc:.4f}; decisions {agree}/{epochs}; "
-          f"max |dlar| / lar_tol {max(dlar):.3f}; state distance {dist:.1e}")
+          f"max |dlar| / lar_tol {max(dlar):.3f} over the {len(dlar)} epochs entered at the same state; final state distance {dist:.1e}")
     ch.close()
     assert abs(mg - mc) <= 0.02, (mg, mc)
-    assert agree == epochs and dlar and max(dlar) <= 1.0, (agree, max(dlar) if dlar else None)
+    assert agree == epochs and len(dlar) >= min(10, epochs) and max(dlar) <= 1.0, (agree, len(dlar), max(dlar) if dlar else None)
     return mg, mc
 
 
