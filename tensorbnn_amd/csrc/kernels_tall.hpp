@@ -28,6 +28,16 @@
 #pragma once
 #include "kernels_mid.hpp"
 
+// diagnostic build (-DTBNN_TILE_STAMPS, tools/experiments/tall_stamps.py): shader-clock stamps of workgroup 0 / wave 0 along its
+// SECOND tile (k < 16) and along the launch (k >= 16)
+#ifdef TBNN_TILE_STAMPS
+#define TALL_STAMP_TILE(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && tile == (long)gridDim.x) g_tile_stamps[k] = clock64(); } while (0)
+#define TALL_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) g_tile_stamps[k] = clock64(); } while (0)
+#else
+#define TALL_STAMP_TILE(k) do {} while (0)
+#define TALL_STAMP(k) do {} while (0)
+#endif
+
 // Waves per workgroup = ways the fan-in is split: four, one per SIMD.  (Eight -- two per SIMD, 256 registers each, all
 // accumulators in ArchVGPRs because the compiler halves a wave's budget as soon as one AccVGPR is asked for -- was built and
 // measured in round 4: 784 -> 20 -> 20 -> 1 at 12,000 rows 29.2 us against 28.4 us.  The two waves of a SIMD run the same program
@@ -175,6 +185,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
     };
     f32x4 xn[CH];
     long tile = blockIdx.x;
+    TALL_STAMP(16);
     fetch(tile, xn);
 
     // ---- prologue: this wave's chunk of W_0 -> registers; the small image -> LDS; the per-wave blocks zeroed
@@ -204,6 +215,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
     }
     __syncthreads();
 
+    TALL_STAMP(17);
     const float sigma = FWD ? 1.f : lik_sigma(nd, eta);
     const float inv_var = 1.f / (sigma * sigma);
     double stat = 0.0;
@@ -227,12 +239,46 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int t = 0; t < C::TR(LL); ++t) wL[o][t] = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
 
+    // one k-step (rows 4 s .. 4 s + 3) of dW_0 += delta_0^T [x, 1], this wave's column tiles
+    auto dw0_step = [&](int s) __attribute__((always_inline)) {
+        if constexpr (!FWD) {
+            const float* db0 = wl + C::dboff(0);
+            const float* xb = wl + C::XB_OFF;
+            float Aop[MT0], Bop[CH];
+#pragma unroll
+            for (int t = 0; t < MT0; ++t) {
+                // fringe tile: block b = (row phase g, column quad), A[m] = delta_0[row 4 s + g][unit 16 T + m] (slot 4 m of the
+                // block); B is the full tiles' operand as it stands; register m = dW_0[16 T + m][column] over the rows of phase g
+                if (C::FR0 && t == C::MTF) Aop[t] = db0[t * 256 + (4 * s + g) * 16 + 4 * (lane & 3)];
+                else Aop[t] = db0[t * 256 + 64 * s + lane];
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) Bop[c] = xb[c * 256 + 64 * s + lane];
+#pragma unroll
+            for (int t = 0; t < MT0; ++t)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if (C::FR0 && t == C::MTF) mfma4_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
+                    else mfma16_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
+                }
+        }
+    };
+
     int buf = 0;
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const bool rvalid = tile * 16 + i16 < n;
+        TALL_STAMP_TILE(0);
         f32x4 x[CH];
+        // (only the wave that holds the end of the rows has anything to fix: a real branch -- left to the compiler it becomes four
+        // selects per column tile in every wave, and on this chip a vector instruction costs what an MFMA pass costs)
+        if (16 * (kt0 + CH) > d_in) {
+            asm volatile("; tail wave");
 #pragma unroll
-        for (int c = 0; c < CH; ++c) x[c] = fix(xn[c], c);
+            for (int c = 0; c < CH; ++c) x[c] = fix(xn[c], c);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) x[c] = xn[c];
+        }
         float y[d_out];
 #pragma unroll
         for (int o = 0; o < d_out; ++o) y[o] = (!FWD && rvalid) ? Y[(tile * 16 + i16) * d_out + o] : 0.f;
@@ -240,6 +286,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int c = 0; c < CH; ++c) *reinterpret_cast<f32x4*>(wl + C::XB_OFF + c * 256 + i16 * 16 + 4 * g) = x[c];
         }
+        TALL_STAMP_TILE(1);
         // ---- layer 0, this wave's share of the fan-in: two accumulator sets (even / odd column tiles) keep the MFMA chain
         // four deep (a lone pair of accumulators is revisited after 32 cycles, 8 short of the dependent latency)
         f32x4 acc0[2][MT0];
@@ -256,6 +303,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                     if (C::FR0 && t == C::MTF) acc0[c & 1][t] = mfma4(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
                     else acc0[c & 1][t] = mfma16(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
                 }
+        TALL_STAMP_TILE(2);
         // the next tile's rows: x's registers are free from here on, the loads land under the rest of this tile
         fetch(tile + gridDim.x, xn);
         {
@@ -274,8 +322,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 ex[(wave * MT0 + t) * 64 + lane] = z;
             }
         }
+        TALL_STAMP_TILE(3);
         __syncthreads();
         f32x4 a[C::MAXT];                  // the current layer's input a_l, D layout: tile t reg j of lane (r, g) = slot 16t+4g+j of row r
+        TALL_STAMP_TILE(4);
         {
             const f32x4* ex = reinterpret_cast<const f32x4*>(lds + C::EX_OFF) + buf * (TALL_WAVES * MT0 * 64);
 #pragma unroll
@@ -293,6 +343,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
             }
         }
 
+        TALL_STAMP_TILE(5);
         // ---- middle layers, forward (every wave, redundantly): a_l -> a_{l+1}; a_l (+ ones slot) to its blocks for dW_l / act'
         sfor<1, NM + 1>(SFOR_LAMBDA(l) {
             constexpr int l = SFOR_VAL(l);
@@ -326,6 +377,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 for (int r = 0; r < 4; ++r) a[t][r] = actc_fwd<S::HACT>(acc[t][r]);
         });
 
+        TALL_STAMP_TILE(6);
         // ---- last layer on the VALU: f_o = b_o + sum_u W[o][u] a_LL[u]
         constexpr int TP = C::TR(LL);
         float dzl[d_out];
@@ -344,6 +396,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 dzl[o] = rvalid ? lik_delta<S>(fi, y[o], inv_var, g == 0 && wave == 0, stat) : 0.f;
             }
         }
+        TALL_STAMP_TILE(7);
         if constexpr (!FWD) {
         f32x4 dz[C::MAXT];
         {
@@ -368,6 +421,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 dz[t] = actc_bwd_mul4<S::act(LL - 1), false>(d, a[t]);
             }
         }
+        TALL_STAMP_TILE(8);
         // ---- backward through the middle layers l = NM .. 1
         sfor<0, NM>(SFOR_LAMBDA(li) {
             constexpr int l = NM - SFOR_VAL(li);
@@ -406,35 +460,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 dz[u] = actc_bwd_mul4<S::act(l - 1), false>(acc[u], al);
             }
         });
+        TALL_STAMP_TILE(9);
         // ---- dW_0 += delta_0^T [x, 1], this wave's column tiles
         {
             float* db0 = wl + C::dboff(0);
 #pragma unroll
             for (int t = 0; t < MT0; ++t) *reinterpret_cast<f32x4*>(db0 + t * 256 + i16 * 16 + 4 * g) = dz[t];
-            const float* xb = wl + C::XB_OFF;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float Aop[MT0], Bop[CH];
-#pragma unroll
-                for (int t = 0; t < MT0; ++t) {
-                    // fringe tile: block b = (row phase g, column quad), A[m] = delta_0[row 4 s + g][unit 16 T + m] (slot 4 m of the
-                    // block); B is the full tiles' operand as it stands; register m = dW_0[16 T + m][column] over the rows of phase g
-                    if (C::FR0 && t == C::MTF) Aop[t] = db0[t * 256 + (4 * s + g) * 16 + 4 * (lane & 3)];
-                    else Aop[t] = db0[t * 256 + 64 * s + lane];
-                }
-#pragma unroll
-                for (int c = 0; c < CH; ++c) Bop[c] = xb[c * 256 + 64 * s + lane];
-#pragma unroll
-                for (int t = 0; t < MT0; ++t)
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        if (C::FR0 && t == C::MTF) mfma4_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
-                        else mfma16_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
-                    }
-            }
+            for (int s = 0; s < 4; ++s) dw0_step(s);
         }
+        TALL_STAMP_TILE(10);
         }   // !FWD
     }
+    TALL_STAMP(18);
     if constexpr (!FWD) {
     if constexpr (ACC_A) {
         mfma_drain_acc(dW0);
@@ -498,6 +536,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
             }
         });
     }
+    TALL_STAMP(19);
     const double wtot = wave_sum(stat);
     if (lane == 0) red[wave] = wtot;
     // ---- middle layers: the four waves' k-step shares of every tile, summed in fixed order
@@ -557,6 +596,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
             slab_store<WT>(slab + C::offW(LL) + (u < inL ? o * inL + u : inL * d_out + o), (v[0] + v[1]) + (v[2] + v[3]));
         }
     }
+    TALL_STAMP(20);
     if (tid == 0) {
         double t = 0.0;
         for (int w = 0; w < TALL_WAVES; ++w) t += red[w];

@@ -22,3 +22,10 @@ const FusedOps* tall_find(const NetDev& nd) {
     for (const FusedOps& o : g_tall) if (fused_ops_match(o, nd)) return &o;
     return nullptr;
 }
+
+#ifdef TBNN_TILE_STAMPS
+// diagnostic build only: the stamps the last launch of a tall kernel left (kernels_tall.hpp: TALL_STAMP)
+extern "C" int tbnn_tall_debug_stamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_tile_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
