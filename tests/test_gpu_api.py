@@ -279,3 +279,45 @@ def test_classification_flow(tmp_path, monkeypatch, native):
     # same forward as the oracle for a saved network
     spec = o.make_spec([4, 12, 12, 2], o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI, final_act=o.ACT_SIGMOID)
     np.testing.assert_allclose(preds[0], o.forward(spec, p.vectors[0], X[500:], np.float64), rtol=2e-5, atol=2e-5)
+
+
+def _free_device_bytes():
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
+def test_create_destroy_returns_device_memory(native):
+    """tbnn_destroy frees what tbnn_create / tbnn_set_data / the first transition allocated, for every kernel family and for a chain
+    group: five create-run-destroy cycles leave the device's free memory where one cycle left it"""
+    cases = [([5, 50, 50, 50, 1], 20000, o.LIK_GAUSSIAN, "fast3<"), ([20, 100, 100, 2], 8000, o.LIK_BERNOULLI, "mid<"),
+             ([784, 20, 20, 1], 4000, o.LIK_BERNOULLI, "tall<"), ([10, 200, 200, 200, 1], 20000, o.LIK_GAUSSIAN, "wide<"),
+             ([8, 300, 300, 1], 5000, o.LIK_GAUSSIAN, "layered<"), ([3, 7, 2], 900, o.LIK_GAUSSIAN, None)]
+    probs = [(o.synth_problem(d, n, o.ACT_RELU, o.PRIOR_CAUCHY, lik), fam) for d, n, lik, fam in cases]
+
+    def cycle():
+        for (spec, X, Y, theta, eta), fam in probs:
+            layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+            ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, jit=False)
+            if fam:
+                assert fam in ch.kernel_name, ch.kernel_name
+            ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+            ch.hmc_step(1e-6, 2, trace=True)
+            ch.hyper_step(1e-4, 2)
+            ch.set_validation(X[:64], Y[:64]); ch.predict(1)
+            ch.close()
+        spec, X, Y, theta, eta = probs[0][0]
+        layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+        grp = native.ChainGroup(layers, 4, likelihood=spec.likelihood)
+        grp.set_data(X, Y); grp.set_state(np.tile(theta, (4, 1))); grp.set_hypers(np.tile(eta, (4, 1)))
+        grp.hmc_run(1e-6, 2, 2)
+        grp.close()
+
+    cycle()                                    # code objects, pinned staging, the runtime's own pools
+    base = _free_device_bytes()
+    for _ in range(5):
+        cycle()
+    lost = base - _free_device_bytes()
+    assert lost <= 32 << 20, f"{lost / 2**20:.1f} MiB of device memory did not come back"
