@@ -166,6 +166,10 @@ int tbnn_export_sample_device(tbnn_handle h, float* d_out);
  * (epoch, purpose) exactly as tbnn_hmc_step would draw them. */
 int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, int32_t n, float* out_normals,
                     float* out_log_u);
+/* diagnostic (tests/test_gpu_properties.py): the momentum the last trajectory of tbnn_hmc_step ended with (P floats: p_L after the
+ * closing half kick, kept whether or not the proposal was accepted).  With it a test can run the integrator backwards: from q_L
+ * with p0 = -p_L the same L steps must return to q_0 (tfp's leapfrog is time-reversible; call sites network.py:394-408). */
+int tbnn_debug_momentum(tbnn_handle h, float* p_out);
 /* epoch counter that keys the RNG (incremented by every tbnn_hmc_step) */
 int tbnn_set_epoch(tbnn_handle h, uint32_t epoch);
 /* record a hipEvent pair around every stride-th fused fwd+bwd launch on the

@@ -80,6 +80,7 @@ SYMBOLS = [
     ("tbnn_set_epoch", C.c_int, [_H, C.c_uint32]),
     ("tbnn_set_profiling", C.c_int, [_H, C.c_int]),
     ("tbnn_debug_stamps", C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    ("tbnn_debug_momentum", C.c_int, [_H, _fp]),
     ("tbnn_set_validation", C.c_int, [_H, _fp, _fp, C.c_int64]),
     ("tbnn_predict", C.c_int, [_H, C.c_int, _fp, _fp]),
     ("tbnn_forward_many", C.c_int, [_H, _fp, C.c_int32, C.c_int64, C.c_int, _fp, C.c_int64, _fp]),
@@ -207,6 +208,12 @@ class Chain:
     def get_state(self) -> np.ndarray:
         out = np.empty(self.P, dtype=np.float32)
         _check(lib.tbnn_get_state(self._h, _p(out)))
+        return out
+
+    def debug_momentum(self) -> np.ndarray:
+        """the momentum the last hmc_step's trajectory ended with (tests: time reversal)"""
+        out = np.empty(self.P, dtype=np.float32)
+        _check(lib.tbnn_debug_momentum(self._h, _p(out)))
         return out
 
     def set_hypers(self, eta):

@@ -1280,6 +1280,17 @@ extern "C" int tbnn_export_sample_device(tbnn_handle h, float* d_out) {
     return 0;
 }
 
+// diagnostic (tests): the momentum the last trajectory ENDED with (p_L, after the closing half kick), whether or not the proposal
+// was accepted -- what a time-reversal test needs (include/tbnn.h)
+extern "C" int tbnn_debug_momentum(tbnn_handle h, float* p_out) {
+    NEED(h); if (!p_out) return fail(-1, "null p_out");
+    ONE_CHAIN(h, "tbnn_debug_momentum");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(p_out, h->p, (size_t)h->nd.P * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 extern "C" int tbnn_debug_draw(tbnn_handle h, uint32_t epoch, uint32_t purpose, int32_t n, float* out_normals,
                                float* out_log_u) {
     NEED(h);
