@@ -191,22 +191,23 @@ open(os.path.join(sys.argv[2], f"rank{rank}.ok"), "w").write("ok")
 '''
 
 
-def test_two_process_gloo_gather(tmp_path):
-    """N>1 path on CPU: world_size-2 gloo all-gather of the sampled states, chain-major, and the
-    per-chain reference-format folders rank 0 writes."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_multi_process_gloo_gather(tmp_path, world):
+    """N>1 path on CPU: world_size-2 (and 8: BASELINE configs[2]'s chain count) gloo all-gather of the sampled states, chain-major,
+    and the per-chain reference-format folders rank 0 writes."""
     script = tmp_path / "worker.py"
     script.write_text(GLOO_WORKER)
     import socket
     with socket.socket() as sk:                      # a port nobody holds right now
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script), ROOT, str(tmp_path / "out")]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert os.path.exists(tmp_path / "out" / "rank0.ok") and os.path.exists(tmp_path / "out" / "rank1.ok"), r.stdout + r.stderr
-    for c in range(2):
+    assert all(os.path.exists(tmp_path / "out" / f"rank{c}.ok") for c in range(world)), r.stdout + r.stderr
+    for c in range(world):
         mats, hyp = o.load_networks(str(tmp_path / "out" / f"chain{c}"))
         assert mats[0].shape == (3, 2, 2) and mats[1].shape == (3, 2, 1) and len(hyp) == 3
         for k in range(3):
