@@ -4,39 +4,52 @@
 // and the rows (3 KB each) are what the pass streams.  Until round 4 such shapes ran on the layered family (five launches,
 // the rows read twice per gradient).
 //
-// One WORKGROUP = one 16-row tile; the fan-in is split over its four waves (wave w owns the column tiles
-// [w CH, (w+1) CH) of the rows, of W_0 and of dW_0):
-//   * W_0's chunk lives in the wave's REGISTERS for the whole launch, as MFMA A operands (MT0 x CH x 4 VGPRs), fetched once
-//     from the padded image k_update maintains; the chunk of dW_0 in the wave's AccVGPRs (the same count);
-//   * a row tile: every wave multiplies its chunk of the rows (16-B loads: lane (row, g) holds columns 16kt+4g .. +3, which
-//     is the MFMA B operand as it stands) into partial pre-activations, the four partials meet in an LDS exchange buffer
-//     (ONE barrier per tile, two alternating buffers), every wave sums them in the same fixed order and then runs the narrow
-//     rest of the network -- middle layers on MFMAs with the weights in LDS, the <= 2-output last layer on the VALU, the
-//     likelihood and the delta chain -- REDUNDANTLY: it is small next to layer 0, and every wave ends up holding delta_0
-//     for its own chunk of dW_0 without a second exchange;
-//   * the gradient of the narrow layers is shared out without a branch: a dW tile is a sum over the tile's four k-steps
-//     (rows 4s .. 4s+3), wave w contributes k-step w only (its operand address is 64 w + lane); the last layer's per-lane
-//     sums take the rows with (row & 3) == w.  The epilogue's fixed-order sum over the four waves -- the one every fused
-//     family has -- puts the pieces together;
-//   * dW_0 += delta_0^T [x, 1]: both operands through per-wave LDS blocks [16 rows][16 slots] (written as the registers
-//     stand, read lane-linearly), as in kernels_mid.hpp; every wave writes its own column chunk of the slab itself.
+// One WORKGROUP walks GROUPS of G row tiles (G = 1, 2 or 4 by the row count, tall_group_tiles); the fan-in is split over its four
+// waves (wave w owns the column tiles [w CH, (w+1) CH) of the rows, of W_0 and of dW_0).  A group runs in three phases:
+//   A. layer 0 of the group's tiles: W_0's chunk lives in the wave's REGISTERS for the whole launch, as MFMA A operands (MT0 x CH x 4
+//      VGPRs), fetched once from the padded image k_update maintains; every wave multiplies its chunk of a tile's rows (16-B buffer
+//      loads: lane (row, g) holds columns 16kt+4g .. +3, which is the MFMA B operand as it stands) into partial pre-activations
+//      and leaves them in the exchange buffer [tile][wave]; units 16 T .. 16 T + F - 1 (F <= 4) of a 16 T + F unit layer take the
+//      16-block 4x4x1 MFMA; barrier;
+//   B. the narrow rest of the network -- middle layers on MFMAs with the weights in LDS, the <= 2-output last layer on the VALU, the
+//      likelihood, the delta chain, the narrow layers' dW -- for ONE tile per wave (wave w: the group's tile w): the four partials
+//      summed in fixed order; delta_0 goes to the group's shared blocks; barrier.  (Until round 4's last version every wave ran this
+//      stretch for the one tile of its workgroup redundantly: it is latency-bound -- dependent MFMAs, LDS round trips,
+//      transcendentals -- and half of a tile's cycles; shared out over a group it costs a quarter per tile.)
+//   C. dW_0 += delta_0^T [x, 1] for the group's tiles, this wave's column tiles, accumulated in the wave's AccVGPRs (MT0 x CH x 4):
+//      A operand from the shared delta_0 blocks, B operand = the rows once more as the transposed view (4-byte buffer loads, L2
+//      hits, requested two k-steps ahead).
+// The epilogue's fixed-order sum over the four waves -- the one every fused family has -- puts the narrow layers' pieces together;
+// every wave writes its own column chunk of dW_0 (16-byte write-through stores after an LDS transpose).
 // Launch signature, slab layout and FusedOps family are the narrow family's (one gradient slab per workgroup, k_update
-// reduces).  The rows are read ONCE per gradient.
+// reduces).  The rows are read from HBM once per gradient (and once more from L2 for dW_0).
 //
 // Reference math: layer.py:278 (W@a+b), activationFunctions.py:36/49/62, likelihood.py:88-94,226-236,
 // BNN_functions.py:23-32; reverse mode SURVEY A12; the path: network.py:394-408.
 #pragma once
 #include "kernels_mid.hpp"
 
-// diagnostic build (-DTBNN_TILE_STAMPS, tools/experiments/tall_stamps.py): shader-clock stamps of workgroup 0 / wave 0 along its
-// SECOND tile (k < 16) and along the launch (k >= 16)
+// diagnostic build (-DTBNN_TILE_STAMPS, tools/experiments/tall_stamps.py): shader-clock stamps of workgroup 0 / wave 0 along the launch
 #ifdef TBNN_TILE_STAMPS
-#define TALL_STAMP_TILE(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && tile == (long)gridDim.x) g_tile_stamps[k] = clock64(); } while (0)
 #define TALL_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) g_tile_stamps[k] = clock64(); } while (0)
 #else
-#define TALL_STAMP_TILE(k) do {} while (0)
 #define TALL_STAMP(k) do {} while (0)
 #endif
+
+// Row tiles per group (1, 2 or 4: the instantiations of the kernel) at a given tile count.  A workgroup walks a group in three phases: layer 0 of its tiles (a per tile),
+// the narrow stretch of ONE tile per wave (b per group, whatever the tile count), dW_0 of its tiles (part of a): with a ~ 2.3 us and
+// b ~ 5.8 us incl. the two barriers (784 -> 20 -> 20 -> 1) a launch over `ntiles` tiles costs rounds(g) x (g a + b), rounds(g) = ceil(ceil(ntiles / g) / 256
+// workgroups).  Big groups share the narrow stretch out best (3.65 us per tile at g = 4 against 5.0 at g = 1), small ones fill the
+// chip at few rows.  The same function sizes the grid and picks the instantiation.
+__host__ __device__ static inline int tall_group_tiles(long ntiles) {
+    int best = 1; long best_cost = 0;
+    for (int g = 1; g <= 4; g *= 2) {
+        const long groups = (ntiles + g - 1) / g, rounds = (groups + 255) / 256;
+        const long cost = rounds * (23 * g + 58);
+        if (g == 1 || cost < best_cost) { best = g; best_cost = cost; }
+    }
+    return best;
+}
 
 // Waves per workgroup = ways the fan-in is split: four, one per SIMD.  (Eight -- two per SIMD, 256 registers each, all
 // accumulators in ArchVGPRs because the compiler halves a wave's budget as soon as one AccVGPR is asked for -- was built and
@@ -96,14 +109,19 @@ struct TallCfg {
     static constexpr int wmoff(int l) { int o = PERM_FLOATS; for (int m = 1; m < l; ++m) o += 16 * TR(m + 1) * LDM(m); return o; }
     static constexpr int SMALL_FLOATS = r4(wmoff(NM + 1));              // the LDS-resident part
     static constexpr int IMG_FLOATS = W0_FLOATS + SMALL_FLOATS;
-    // ---- LDS: [small image][exchange: 2 buffers x 4 waves x MT0 tiles x 64 lanes x 4][per wave: blocks of 256 floats]
+    // ---- LDS: [small image][exchange: G tiles x 4 waves x MT0 tiles x 64 lanes x 4 | epilogue staging of dW_0: 4 waves x CH blocks]
+    //           [delta_0 of the group's G tiles: MT0 blocks each][per wave: a_l, delta_l blocks of the middle layers]
+    static constexpr int G = NW;                                        // row tiles per group (one per wave for the narrow stretch)
     static constexpr int EX_OFF = SMALL_FLOATS;
-    static constexpr int EX_FLOATS = 2 * NW * MT0 * 256;
-    static constexpr int XB_OFF = 0;                                                              // x (+ ones slot): CH blocks
-    static constexpr int aboff(int l) { int o = XB_OFF + CH * 256; for (int m = 1; m < l; ++m) o += TA(m) * 256; return o; }   // a_l, l = 1..NM
-    static constexpr int dboff(int l) { int o = aboff(NM + 1); for (int m = 0; m < l; ++m) o += TR(m + 1) * 256; return o; }   // delta_l, l = 0..NM
+    static constexpr int EX_FLOATS = G * NW * MT0 * 256;
+    static constexpr int STG_OFF = EX_OFF;
+    static constexpr int STG_FLOATS = NW * CH * 256;
+    static constexpr int DB0_OFF = EX_OFF + (EX_FLOATS > STG_FLOATS ? EX_FLOATS : STG_FLOATS);
+    static constexpr int DB0_FLOATS = G * MT0 * 256;
+    static constexpr int aboff(int l) { int o = 0; for (int m = 1; m < l; ++m) o += TA(m) * 256; return o; }                    // a_l, l = 1..NM
+    static constexpr int dboff(int l) { int o = aboff(NM + 1); for (int m = 1; m < l; ++m) o += TR(m + 1) * 256; return o; }    // delta_l, l = 1..NM
     static constexpr int WAVE_FLOATS = dboff(NM + 1);
-    static constexpr int WAVE_OFF = EX_OFF + EX_FLOATS;
+    static constexpr int WAVE_OFF = DB0_OFF + DB0_FLOATS;
     static constexpr int LDS_MAIN = WAVE_OFF + NW * WAVE_FLOATS;
     // epilogue staging of the middle layers' dW tiles ([wave][tile][lane] x 16 B) and of the last layer's sums
     static constexpr int EP_FLOATS = NW * (DWM_TILES > 0 ? DWM_TILES : 1) * 256;
@@ -126,7 +144,9 @@ struct TallLast {              // per-lane partial sums of the VALU last layer's
 };
 
 // FWD: forward pass only (network.predict, network.py:141-171; predictor.py:132-155 with blockIdx.y = network)
-template <class S, int NW, bool FWD = false>
+// G: row tiles per group (1, 2 or 4 -- tall_group_tiles -- a template parameter: with the group size a run-time value the tile loops
+// of phases A and C end in branches, every tile becomes a scheduling region of its own, and the launch measured 9 % slower)
+template <class S, int NW, bool FWD = false, int G = 4>
 __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_fwd_bwd_tall(
     NetDev nd, const float* __restrict__ qimgs, long img_stride, const float* __restrict__ eta,
     const float* __restrict__ X, const float* __restrict__ Y, long n,
@@ -183,10 +203,23 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         }
         return v;
     };
+    // the rows once more for dW_0, as the transposed operand: lane (column i16, row phase g) of k-step s holds
+    // x[row 4 s + g][column 16 (kt0 + c) + i16] -- 4-byte buffer loads (hits: the group's rows were read for layer 0 a moment ago);
+    // the resource covers the tile's valid rows, the tail wave puts the ones slot / zeros behind the end of the rows
+    const int vT = (g * d_in + 16 * kt0 + i16) * 4;
+    auto rsrc_rows = [&](long tile) __attribute__((always_inline)) {
+        const bool in = tile < ntiles;
+        const long left = n - tile * 16;
+        const int rows = in ? (int)(left < 16 ? left : 16) : 0;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X) + (in ? tile : 0) * 16 * d_in, 0, rows * d_in * 4, 0x00020000);
+    };
+    static_assert(G >= 1 && G <= C::G, "group size");
+    constexpr int Gr = G;
+    const long ngroups = (ntiles + Gr - 1) / Gr;
     f32x4 xn[CH];
-    long tile = blockIdx.x;
+    long grp = blockIdx.x;
     TALL_STAMP(16);
-    fetch(tile, xn);
+    fetch(grp * Gr, xn);
 
     // ---- prologue: this wave's chunk of W_0 -> registers; the small image -> LDS; the per-wave blocks zeroed
     // (fringe tile: the 4x4x1 MFMA's A operand of lane l is W_0[unit 16 T + (l & 3)][k-phase l / 16] -- fringe unit e sits in slot
@@ -239,75 +272,41 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int t = 0; t < C::TR(LL); ++t) wL[o][t] = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
 
-    // one k-step (rows 4 s .. 4 s + 3) of dW_0 += delta_0^T [x, 1], this wave's column tiles
-    auto dw0_step = [&](int s) __attribute__((always_inline)) {
-        if constexpr (!FWD) {
-            const float* db0 = wl + C::dboff(0);
-            const float* xb = wl + C::XB_OFF;
-            float Aop[MT0], Bop[CH];
+    const bool tail_wave = 16 * (kt0 + CH) > d_in;             // (wave-uniform) this wave holds the end of the rows
+    for (; grp < ngroups; grp += gridDim.x) {
+        // ---- A: layer 0 of the group's G row tiles, this wave's share of the fan-in -> partial pre-activations in the exchange buffer.
+        // Two accumulator sets (even / odd column tiles) keep the MFMA chain four deep (a lone pair of accumulators is revisited
+        // after 32 cycles, 8 short of the dependent latency)
 #pragma unroll
-            for (int t = 0; t < MT0; ++t) {
-                // fringe tile: block b = (row phase g, column quad), A[m] = delta_0[row 4 s + g][unit 16 T + m] (slot 4 m of the
-                // block); B is the full tiles' operand as it stands; register m = dW_0[16 T + m][column] over the rows of phase g
-                if (C::FR0 && t == C::MTF) Aop[t] = db0[t * 256 + (4 * s + g) * 16 + 4 * (lane & 3)];
-                else Aop[t] = db0[t * 256 + 64 * s + lane];
+        for (int tg = 0; tg < G; ++tg) {
+            f32x4 x[CH];
+            // (only the tail wave has anything to fix: a real branch -- left to the compiler it becomes four selects per column tile
+            // in every wave, and on this chip a vector instruction costs what an MFMA pass costs)
+            if (tail_wave) {
+                asm volatile("; tail wave");
+#pragma unroll
+                for (int c = 0; c < CH; ++c) x[c] = fix(xn[c], c);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) x[c] = xn[c];
             }
+            f32x4 acc0[2][MT0];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) Bop[c] = xb[c * 256 + 64 * s + lane];
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int t = 0; t < MT0; ++t)
+                for (int t = 0; t < MT0; ++t) acc0[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < CH; ++c) {
-                    if (C::FR0 && t == C::MTF) mfma4_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
-                    else mfma16_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
-                }
-        }
-    };
-
-    int buf = 0;
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-        const bool rvalid = tile * 16 + i16 < n;
-        TALL_STAMP_TILE(0);
-        f32x4 x[CH];
-        // (only the wave that holds the end of the rows has anything to fix: a real branch -- left to the compiler it becomes four
-        // selects per column tile in every wave, and on this chip a vector instruction costs what an MFMA pass costs)
-        if (16 * (kt0 + CH) > d_in) {
-            asm volatile("; tail wave");
+            for (int c = 0; c < CH; ++c)
 #pragma unroll
-            for (int c = 0; c < CH; ++c) x[c] = fix(xn[c], c);
-        } else {
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int c = 0; c < CH; ++c) x[c] = xn[c];
-        }
-        float y[d_out];
-#pragma unroll
-        for (int o = 0; o < d_out; ++o) y[o] = (!FWD && rvalid) ? Y[(tile * 16 + i16) * d_out + o] : 0.f;
-        if constexpr (!FWD) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) *reinterpret_cast<f32x4*>(wl + C::XB_OFF + c * 256 + i16 * 16 + 4 * g) = x[c];
-        }
-        TALL_STAMP_TILE(1);
-        // ---- layer 0, this wave's share of the fan-in: two accumulator sets (even / odd column tiles) keep the MFMA chain
-        // four deep (a lone pair of accumulators is revisited after 32 cycles, 8 short of the dependent latency)
-        f32x4 acc0[2][MT0];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int t = 0; t < MT0; ++t) acc0[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < MT0; ++t) {
-                    if (C::FR0 && t == C::MTF) acc0[c & 1][t] = mfma4(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
-                    else acc0[c & 1][t] = mfma16(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
-                }
-        TALL_STAMP_TILE(2);
-        // the next tile's rows: x's registers are free from here on, the loads land under the rest of this tile
-        fetch(tile + gridDim.x, xn);
-        {
-            f32x4* ex = reinterpret_cast<f32x4*>(lds + C::EX_OFF) + buf * (TALL_WAVES * MT0 * 64);
+                    for (int t = 0; t < MT0; ++t) {
+                        if (C::FR0 && t == C::MTF) acc0[c & 1][t] = mfma4(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
+                        else acc0[c & 1][t] = mfma16(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
+                    }
+            // the next tile's rows (the next group's first tile behind the last): x's registers are free from here on
+            fetch(tg + 1 < Gr ? grp * Gr + tg + 1 : (grp + gridDim.x) * Gr, xn);
+            f32x4* ex = reinterpret_cast<f32x4*>(lds + C::EX_OFF) + (tg * TALL_WAVES + wave) * (MT0 * 64);
 #pragma unroll
             for (int t = 0; t < MT0; ++t) {
                 f32x4 z = acc0[0][t] + acc0[1][t];
@@ -319,15 +318,37 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                     const float sel = g == 0 ? z[0] : (g == 1 ? z[1] : (g == 2 ? z[2] : z[3]));
                     z = f32x4{sel, 0.f, 0.f, 0.f};
                 }
-                ex[(wave * MT0 + t) * 64 + lane] = z;
+                ex[t * 64 + lane] = z;
             }
         }
-        TALL_STAMP_TILE(3);
+        // dW_0's first operands (tile 0, k-step 0): requested here, used behind the narrow stretch
+        float Bq[3][FWD ? 1 : CH];
+        __amdgpu_buffer_rsrc_t rsT = rsrc_rows(grp * Gr);
+        auto ldT = [&](int s, float (&B)[FWD ? 1 : CH]) __attribute__((always_inline)) {
+            if constexpr (!FWD) {
+#pragma unroll
+#ifdef TALL_DBG_NOLDT      // timing experiment only (wrong gradients): what the transposed re-read of the rows costs in phase C
+                for (int c = 0; c < CH; ++c) B[c] = 0.001f * (lane + s + c);
+#else
+                for (int c = 0; c < CH; ++c) B[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, vT, (4 * s * d_in + 16 * c) * 4, 0));
+#endif
+            }
+        };
+        ldT(0, Bq[0]);
+        if (Gr * 4 > 1) ldT(1, Bq[1]);
         __syncthreads();
+
+        // ---- B: the narrow rest of the network for ONE tile per wave (tile = group's tile `wave`): the four partials summed in fixed
+        // order, middle layers on MFMAs from the LDS image, last layer on the VALU, likelihood, delta chain, the narrow layers' dW
+        if (wave < Gr) {
+        const long tile = grp * Gr + wave;
+        const bool rvalid = tile * 16 + i16 < n;
+        float y[d_out];
+#pragma unroll
+        for (int o = 0; o < d_out; ++o) y[o] = (!FWD && rvalid) ? Y[(tile * 16 + i16) * d_out + o] : 0.f;
         f32x4 a[C::MAXT];                  // the current layer's input a_l, D layout: tile t reg j of lane (r, g) = slot 16t+4g+j of row r
-        TALL_STAMP_TILE(4);
         {
-            const f32x4* ex = reinterpret_cast<const f32x4*>(lds + C::EX_OFF) + buf * (TALL_WAVES * MT0 * 64);
+            const f32x4* ex = reinterpret_cast<const f32x4*>(lds + C::EX_OFF) + wave * (TALL_WAVES * MT0 * 64);
 #pragma unroll
             for (int t = 0; t < MT0; ++t) {
                 f32x4 z;
@@ -343,8 +364,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
             }
         }
 
-        TALL_STAMP_TILE(5);
-        // ---- middle layers, forward (every wave, redundantly): a_l -> a_{l+1}; a_l (+ ones slot) to its blocks for dW_l / act'
+        // ---- middle layers, forward: a_l -> a_{l+1}; a_l (+ ones slot) to this wave's blocks for dW_l / act'
         sfor<1, NM + 1>(SFOR_LAMBDA(l) {
             constexpr int l = SFOR_VAL(l);
             if constexpr (!FWD) {
@@ -377,7 +397,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 for (int r = 0; r < 4; ++r) a[t][r] = actc_fwd<S::HACT>(acc[t][r]);
         });
 
-        TALL_STAMP_TILE(6);
         // ---- last layer on the VALU: f_o = b_o + sum_u W[o][u] a_LL[u]
         constexpr int TP = C::TR(LL);
         float dzl[d_out];
@@ -390,26 +409,23 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 for (int r = 0; r < 4; ++r) p = fmaf(wL[o][t][r], a[t][r], p);
             const float fi = actc_fwd<S::LACT>(lane_group_sum(p) + lds[C::BL_OFF + o]);
             if constexpr (FWD) {
-                if (rvalid && g == 0 && wave == 0) fout[(size_t)o * n + tile * 16 + i16] = fi;      // [d_out][n]
+                if (rvalid && g == 0) fout[(size_t)o * n + tile * 16 + i16] = fi;      // [d_out][n]
                 dzl[o] = 0.f;
             } else {
-                dzl[o] = rvalid ? lik_delta<S>(fi, y[o], inv_var, g == 0 && wave == 0, stat) : 0.f;
+                dzl[o] = rvalid ? lik_delta<S>(fi, y[o], inv_var, g == 0, stat) : 0.f;
             }
         }
-        TALL_STAMP_TILE(7);
         if constexpr (!FWD) {
         f32x4 dz[C::MAXT];
         {
-            // the last layer's dW / db sums take the rows with (row & (NW - 1)) == wave; delta_{LL-1} = (W_LL^T dz_LL) * act'(a_LL)
-            const bool mine = (i16 & (NW - 1)) == wave;
+            // the last layer's dW / db sums of this tile's rows; delta_{LL-1} = (W_LL^T dz_LL) * act'(a_LL)
 #pragma unroll
             for (int o = 0; o < d_out; ++o) {
-                const float dm = mine ? dzl[o] : 0.f;
-                LR.accb[o] += dm;
+                LR.accb[o] += dzl[o];
 #pragma unroll
                 for (int t = 0; t < TP; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) LR.acc[o][t][r] = fmaf(dm, a[t][r], LR.acc[o][t][r]);
+                    for (int r = 0; r < 4; ++r) LR.acc[o][t][r] = fmaf(dzl[o], a[t][r], LR.acc[o][t][r]);
             }
 #pragma unroll
             for (int t = 0; t < TP; ++t) {
@@ -421,7 +437,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 dz[t] = actc_bwd_mul4<S::act(LL - 1), false>(d, a[t]);
             }
         }
-        TALL_STAMP_TILE(8);
         // ---- backward through the middle layers l = NM .. 1
         sfor<0, NM>(SFOR_LAMBDA(li) {
             constexpr int l = NM - SFOR_VAL(li);
@@ -430,13 +445,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
             const float* ab = wl + C::aboff(l);
 #pragma unroll
             for (int t = 0; t < TZ; ++t) *reinterpret_cast<f32x4*>(dbl + t * 256 + i16 * 16 + 4 * g) = dz[t];
-            // dW_l += delta_l^T [a_l, 1], this wave's k-step (rows 4 wave .. 4 wave + 3)
-            {
+            // dW_l += delta_l^T [a_l, 1] over this tile's 16 rows (k-step s = rows 4 s .. 4 s + 3)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
                 float Aop[TZ], Bop[TAl];
 #pragma unroll
-                for (int t = 0; t < TZ; ++t) Aop[t] = dbl[t * 256 + 64 * wave + lane];
+                for (int t = 0; t < TZ; ++t) Aop[t] = dbl[t * 256 + 64 * s + lane];
 #pragma unroll
-                for (int u = 0; u < TAl; ++u) Bop[u] = ab[u * 256 + 64 * wave + lane];
+                for (int u = 0; u < TAl; ++u) Bop[u] = ab[u * 256 + 64 * s + lane];
 #pragma unroll
                 for (int t = 0; t < TZ; ++t)
 #pragma unroll
@@ -460,17 +476,53 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 dz[u] = actc_bwd_mul4<S::act(l - 1), false>(acc[u], al);
             }
         });
-        TALL_STAMP_TILE(9);
-        // ---- dW_0 += delta_0^T [x, 1], this wave's column tiles
+        // delta_0 of this wave's tile -> the group's shared blocks
         {
-            float* db0 = wl + C::dboff(0);
+            float* db0 = lds + C::DB0_OFF + wave * (MT0 * 256);
 #pragma unroll
             for (int t = 0; t < MT0; ++t) *reinterpret_cast<f32x4*>(db0 + t * 256 + i16 * 16 + 4 * g) = dz[t];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) dw0_step(s);
         }
-        TALL_STAMP_TILE(10);
         }   // !FWD
+        }   // wave < Gr
+        __syncthreads();
+
+        // ---- C: dW_0 += delta_0^T [x, 1] over the group's tiles, this wave's column tiles; one k-step (rows 4 s .. 4 s + 3 of
+        // tile tg) at a time, its rows requested two k-steps ahead
+        if constexpr (!FWD) {
+#pragma unroll
+            for (int q = 0; q < 4 * G; ++q) {
+                const int tg = q >> 2, s = q & 3;
+                if (q + 2 < 4 * Gr) {                                // two k-steps (52 MFMAs) ahead, three operand sets
+                    if (((q + 2) & 3) == 0) rsT = rsrc_rows(grp * Gr + ((q + 2) >> 2));
+                    ldT((q + 2) & 3, Bq[(q + 2) % 3]);
+                }
+                float (&Bop)[CH] = Bq[q % 3];
+                if (tail_wave) {
+                    asm volatile("; tail wave");
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int col = 16 * (kt0 + c) + i16;
+                        Bop[c] = col < d_in ? Bop[c] : (col == d_in ? 1.f : 0.f);
+                    }
+                }
+                const float* db0 = lds + C::DB0_OFF + tg * (MT0 * 256);
+                float Aop[MT0];
+#pragma unroll
+                for (int t = 0; t < MT0; ++t) {
+                    // fringe tile: block b = (row phase g, column quad), A[m] = delta_0[row 4 s + g][unit 16 T + m] (slot 4 m of the
+                    // block); B is the full tiles' operand as it stands; register m = dW_0[16 T + m][column] over the rows of phase g
+                    if (C::FR0 && t == C::MTF) Aop[t] = db0[t * 256 + (4 * s + g) * 16 + 4 * (lane & 3)];
+                    else Aop[t] = db0[t * 256 + 64 * s + lane];
+                }
+#pragma unroll
+                for (int t = 0; t < MT0; ++t)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        if (C::FR0 && t == C::MTF) mfma4_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
+                        else mfma16_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
+                    }
+            }
+        }
     }
     TALL_STAMP(18);
     if constexpr (!FWD) {
@@ -489,7 +541,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         sfor<0, MT0>(SFOR_LAMBDA(t) {
             constexpr int t = SFOR_VAL(t);
             if constexpr (C::ALIGNED) {
-                float* stg = wl + C::XB_OFF;
+                float* stg = lds + C::STG_OFF + wave * (CH * 256);
                 sfor<0, CH>(SFOR_LAMBDA(c) {
                     constexpr int c = SFOR_VAL(c);
                     const f32x4 v = dW0[t * CH + c];
@@ -628,17 +680,23 @@ static void tall_image_map(int* map) {
     }
 }
 
-// one workgroup per 16-row tile and pass; at most one workgroup per CU, the tiles dealt out evenly
+// one workgroup per group of four 16-row tiles and pass; at most one workgroup per CU, the groups dealt out evenly
 static inline int tall_grid(long n) {
-    const long ntiles = (n + 15) / 16, rounds = (ntiles + 255) / 256;
-    return (int)((ntiles + rounds - 1) / rounds);
+    const long ntiles = (n + 15) / 16, ngroups = (ntiles + tall_group_tiles(ntiles) - 1) / tall_group_tiles(ntiles), rounds = (ngroups + 255) / 256;
+    return (int)((ngroups + rounds - 1) / rounds);
 }
 template <class S>
 static inline int tall_launch_t(int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta, const float* X,
                                 const float* Y, long n, float* slabs, int pitch, double* pstat, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0}) {
     constexpr int NW = TallPick<S>::NW;
-    hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, false>), dim3(grid, nchains), dim3(64 * NW), 0, st, nd, qimg, cs.img, eta, X, Y, n, slabs, pitch, pstat,
-                       (float*)nullptr, 0L, cs);
+#define TALL_LAUNCH(GG) hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, false, GG>), dim3(grid, nchains), dim3(64 * NW), 0, st, nd, qimg, cs.img, eta, X, Y, n, \
+                                           slabs, pitch, pstat, (float*)nullptr, 0L, cs)
+    switch (tall_group_tiles((n + 15) / 16)) {
+        case 1: TALL_LAUNCH(1); break;
+        case 2: TALL_LAUNCH(2); break;
+        default: TALL_LAUNCH(4); break;
+    }
+#undef TALL_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // forward only: `nets` networks (grid.y; images img_stride floats apart), fouts[net][d_out][n]
@@ -647,7 +705,8 @@ static inline int tall_forward_t(int gx, int nets, hipStream_t st, const float* 
                                  float* fouts, long out_stride) {
     NetDev nd{};
     constexpr int NW = TallPick<S>::NW;
-    hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, true>), dim3(gx, nets), dim3(64 * NW), 0, st, nd, qimgs, img_stride, (const float*)nullptr, X,
+    // (forward only: no narrow-stretch redundancy worth sharing out at the price of fewer workgroups -- one tile per group)
+    hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, true, 1>), dim3(gx, nets), dim3(64 * NW), 0, st, nd, qimgs, img_stride, (const float*)nullptr, X,
                        (const float*)nullptr, n, (float*)nullptr, 0, (double*)nullptr, fouts, out_stride, ChainStride{0, 0, 0});
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -128,8 +128,9 @@ def tall_fits(dims) -> bool:
     r4 = lambda a: (a + 3) & ~3
     perm = r4(sum(16 * tr(l + 1) for l in range(nl - 1)) + dims[-1] * 16 * tr(nl - 1) + dims[-1])
     small = r4(perm + sum(16 * tr(l + 1) * (16 * tr(l) + 4) for l in range(1, nl - 1)))
-    wave = (ch + sum(ta(l) for l in range(1, nl - 1)) + sum(tr(l + 1) for l in range(nl - 1))) * 256
-    return (small + 8 * mt0 * 256 + 4 * wave) * 4 + 64 <= 160 * 1024
+    # exchange buffer of a group's 4 tiles | dW_0 staging of the epilogue, delta_0 of the group, per-wave a_l / delta_l blocks of the middle layers
+    wave = (sum(ta(l) for l in range(1, nl - 1)) + sum(tr(l + 1) for l in range(1, nl - 1))) * 256
+    return (small + max(16 * mt0, 4 * ch) * 256 + 4 * mt0 * 256 + 4 * wave) * 4 + 64 <= 160 * 1024
 
 
 def source(dims, hact, lact, bern, family) -> str:

@@ -1,4 +1,4 @@
-"""dev: where a tile's time goes inside k_fwd_bwd_tall (diagnostic build):
+"""dev: prologue / group loop / epilogue of k_fwd_bwd_tall in shader-clock cycles (diagnostic build):
 TBNN_BUILD_TAG=stamps TBNN_TALL_FLAGS=-DTBNN_TILE_STAMPS python -m tensorbnn_amd.build
 TBNN_LIB=$PWD/tensorbnn_amd/libtbnn_stamps.so python tools/experiments/tall_stamps.py 784,20,20,1 12000 bern"""
 import ctypes, os, sys
@@ -19,10 +19,4 @@ buf = (ctypes.c_ulonglong * 64)()
 fn = lib.tbnn_tall_debug_stamps; fn.restype = ctypes.c_int; fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 assert fn(buf) == 0
 v = list(buf)
-names = {0: "tile top", 1: "x fixed + x blocks written", 2: "layer-0 MFMAs issued", 3: "fetch issued + exchange written", 4: "barrier passed",
-         5: "exchange read, a_1", 6: "middle layers forward", 7: "last layer + likelihood", 8: "last layer's dW + delta", 9: "delta chain",
-         10: "dW_0 issued (tile end)"}
-print("second tile of workgroup 0, wave 0 (shader clock cycles):")
-for k in range(1, 11):
-    print(f"  {names[k]:36s} {v[k] - v[k - 1]:7d}   (cum {v[k] - v[0]})")
-print("launch: prologue", v[17] - v[16], " tile loop", v[18] - v[17], " dW_0 epilogue", v[19] - v[18], " rest of epilogue", v[20] - v[19], " total", v[20] - v[16])
+print("launch: prologue", v[17] - v[16], " group loop", v[18] - v[17], " dW_0 epilogue", v[19] - v[18], " rest of epilogue", v[20] - v[19], " total", v[20] - v[16])
