@@ -8,7 +8,7 @@
 
 template <class S>
 struct JitTall {
-    static int grid(long n) { return tall_grid(n); }
+    static int grid(long n) { return tall_grid<S>(n); }
     static int launch(int g, hipStream_t st, const NetDev* nd, const float* qimg, const float* eta, const float* X, const float* Y,
                       long n, float* slabs, int pitch, double* pstat, int nchains, ChainStride cs) {
         return tall_launch_t<S>(g, st, *nd, qimg, eta, X, Y, n, slabs, pitch, pstat, nchains, cs);

@@ -36,16 +36,16 @@
 #define TALL_STAMP(k) do {} while (0)
 #endif
 
-// Row tiles per group (1, 2 or 4: the instantiations of the kernel) at a given tile count.  A workgroup walks a group in three phases: layer 0 of its tiles (a per tile),
+// Row tiles per group (1, 2 or 4 = TallCfg::GMAX: the instantiations of the kernel) at a given tile count.  A workgroup walks a group in three phases: layer 0 of its tiles (a per tile),
 // the narrow stretch of ONE tile per wave (b per group, whatever the tile count), dW_0 of its tiles (part of a): with a ~ 2.3 us and
 // b ~ 5.8 us incl. the two barriers (784 -> 20 -> 20 -> 1) a launch over `ntiles` tiles costs rounds(g) x (g a + b), rounds(g) = ceil(ceil(ntiles / g) / 256
 // workgroups).  Big groups share the narrow stretch out best (3.65 us per tile at g = 4 against 5.0 at g = 1), small ones fill the
 // chip at few rows.  The same function sizes the grid and picks the instantiation.
-__host__ __device__ static inline int tall_group_tiles(long ntiles) {
+__host__ __device__ static inline int tall_group_tiles(long ntiles, int gmax) {
     int best = 1; long best_cost = 0;
-    for (int g = 1; g <= 4; g *= 2) {
+    for (int g = 1; g <= gmax; g *= 2) {
         const long groups = (ntiles + g - 1) / g, rounds = (groups + 255) / 256;
-        const long cost = rounds * (23 * g + 58);
+        const long cost = rounds * (23 * g + 58 + (g > 4 ? 24 * (g / 4 - 1) : 0));      // (g = 8: every wave runs the narrow stretch twice)
         if (g == 1 || cost < best_cost) { best = g; best_cost = cost; }
     }
     return best;
@@ -111,7 +111,20 @@ struct TallCfg {
     static constexpr int IMG_FLOATS = W0_FLOATS + SMALL_FLOATS;
     // ---- LDS: [small image][exchange: G tiles x 4 waves x MT0 tiles x 64 lanes x 4 | epilogue staging of dW_0: 4 waves x CH blocks]
     //           [delta_0 of the group's G tiles: MT0 blocks each][per wave: a_l, delta_l blocks of the middle layers]
-    static constexpr int G = NW;                                        // row tiles per group (one per wave for the narrow stretch)
+    // row tiles per group: at most GMAX.  -DTALL_GMAX=8 (two tiles per wave in the narrow stretch, one after the other, where the LDS holds
+    // eight tiles' exchange buffer) was measured: 60,000 rows 76.0 us against 73.8 with groups of four, 24,000 rows 42.8 against 41.4 --
+    // the second pass through the narrow stretch costs more than the barriers it saves
+    static constexpr int lds_main(int gmax) {
+        const int ex = gmax * NW * MT0 * 256, stg = NW * CH * 256;
+        int wave = 0;
+        for (int m = 1; m <= NM; ++m) wave += (TA(m) + TR(m + 1)) * 256;
+        return SMALL_FLOATS + (ex > stg ? ex : stg) + gmax * MT0 * 256 + NW * wave;
+    }
+#ifndef TALL_GMAX
+#define TALL_GMAX 4
+#endif
+    static constexpr int GMAX = (TALL_GMAX >= 8 && lds_main(8) * 4 + 128 <= 160 * 1024) ? 8 : 4;
+    static constexpr int G = GMAX;
     static constexpr int EX_OFF = SMALL_FLOATS;
     static constexpr int EX_FLOATS = G * NW * MT0 * 256;
     static constexpr int STG_OFF = EX_OFF;
@@ -123,6 +136,7 @@ struct TallCfg {
     static constexpr int WAVE_FLOATS = dboff(NM + 1);
     static constexpr int WAVE_OFF = DB0_OFF + DB0_FLOATS;
     static constexpr int LDS_MAIN = WAVE_OFF + NW * WAVE_FLOATS;
+    static_assert(LDS_MAIN == lds_main(GMAX), "LDS layout");
     // epilogue staging of the middle layers' dW tiles ([wave][tile][lane] x 16 B) and of the last layer's sums
     static constexpr int EP_FLOATS = NW * (DWM_TILES > 0 ? DWM_TILES : 1) * 256;
     static constexpr int LL_FLOATS = NW * d_out * (16 * TR(LL) + 1);
@@ -340,15 +354,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 
         // ---- B: the narrow rest of the network for ONE tile per wave (tile = group's tile `wave`): the four partials summed in fixed
         // order, middle layers on MFMAs from the LDS image, last layer on the VALU, likelihood, delta chain, the narrow layers' dW
-        if (wave < Gr) {
-        const long tile = grp * Gr + wave;
+#pragma unroll
+        for (int tb = 0; tb < (Gr + NW - 1) / NW; ++tb) {
+        const int slot = tb * NW + wave;                      // this wave's tile of the group
+        if (slot < Gr) {
+        const long tile = grp * Gr + slot;
         const bool rvalid = tile * 16 + i16 < n;
         float y[d_out];
 #pragma unroll
         for (int o = 0; o < d_out; ++o) y[o] = (!FWD && rvalid) ? Y[(tile * 16 + i16) * d_out + o] : 0.f;
         f32x4 a[C::MAXT];                  // the current layer's input a_l, D layout: tile t reg j of lane (r, g) = slot 16t+4g+j of row r
         {
-            const f32x4* ex = reinterpret_cast<const f32x4*>(lds + C::EX_OFF) + wave * (TALL_WAVES * MT0 * 64);
+            const f32x4* ex = reinterpret_cast<const f32x4*>(lds + C::EX_OFF) + slot * (TALL_WAVES * MT0 * 64);
 #pragma unroll
             for (int t = 0; t < MT0; ++t) {
                 f32x4 z;
@@ -478,12 +495,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         });
         // delta_0 of this wave's tile -> the group's shared blocks
         {
-            float* db0 = lds + C::DB0_OFF + wave * (MT0 * 256);
+            float* db0 = lds + C::DB0_OFF + slot * (MT0 * 256);
 #pragma unroll
             for (int t = 0; t < MT0; ++t) *reinterpret_cast<f32x4*>(db0 + t * 256 + i16 * 16 + 4 * g) = dz[t];
         }
         }   // !FWD
-        }   // wave < Gr
+        }   // slot < Gr
+        }   // tb
         __syncthreads();
 
         // ---- C: dW_0 += delta_0^T [x, 1] over the group's tiles, this wave's column tiles; one k-step (rows 4 s .. 4 s + 3 of
@@ -681,8 +699,11 @@ static void tall_image_map(int* map) {
 }
 
 // one workgroup per group of four 16-row tiles and pass; at most one workgroup per CU, the groups dealt out evenly
+template <class S>
 static inline int tall_grid(long n) {
-    const long ntiles = (n + 15) / 16, ngroups = (ntiles + tall_group_tiles(ntiles) - 1) / tall_group_tiles(ntiles), rounds = (ngroups + 255) / 256;
+    const long ntiles = (n + 15) / 16;
+    const int g = tall_group_tiles(ntiles, TallCfg<S, TallPick<S>::NW>::GMAX);
+    const long ngroups = (ntiles + g - 1) / g, rounds = (ngroups + 255) / 256;
     return (int)((ngroups + rounds - 1) / rounds);
 }
 template <class S>
@@ -691,10 +712,12 @@ static inline int tall_launch_t(int grid, hipStream_t st, const NetDev& nd, cons
     constexpr int NW = TallPick<S>::NW;
 #define TALL_LAUNCH(GG) hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, false, GG>), dim3(grid, nchains), dim3(64 * NW), 0, st, nd, qimg, cs.img, eta, X, Y, n, \
                                            slabs, pitch, pstat, (float*)nullptr, 0L, cs)
-    switch (tall_group_tiles((n + 15) / 16)) {
+    constexpr int GMAX = TallCfg<S, NW>::GMAX;
+    switch (tall_group_tiles((n + 15) / 16, GMAX)) {
         case 1: TALL_LAUNCH(1); break;
         case 2: TALL_LAUNCH(2); break;
-        default: TALL_LAUNCH(4); break;
+        case 4: TALL_LAUNCH(4); break;
+        default: if constexpr (GMAX >= 8) TALL_LAUNCH(8); break;
     }
 #undef TALL_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -1;
