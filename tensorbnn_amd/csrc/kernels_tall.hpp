@@ -32,8 +32,10 @@
 // diagnostic build (-DTBNN_TILE_STAMPS, tools/experiments/tall_stamps.py): shader-clock stamps of workgroup 0 / wave 0 along the launch
 #ifdef TBNN_TILE_STAMPS
 #define TALL_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) g_tile_stamps[k] = clock64(); } while (0)
+#define TALL_STAMP_G(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && grp == 0) g_tile_stamps[k] = clock64(); } while (0)
 #else
 #define TALL_STAMP(k) do {} while (0)
+#define TALL_STAMP_G(k) do {} while (0)
 #endif
 
 // Row tiles per group (1, 2 or 4 = TallCfg::GMAX: the instantiations of the kernel) at a given tile count.  A workgroup walks a group in three phases: layer 0 of its tiles (a per tile),
@@ -291,6 +293,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         // ---- A: layer 0 of the group's G row tiles, this wave's share of the fan-in -> partial pre-activations in the exchange buffer.
         // Two accumulator sets (even / odd column tiles) keep the MFMA chain four deep (a lone pair of accumulators is revisited
         // after 32 cycles, 8 short of the dependent latency)
+        // The group's rows arrive two tiles ahead of their use: tile 0 was requested a group ago (xn), tile 1 is requested here (xm), tile
+        // t + 2 behind tile t's MFMAs into the set tile t vacated; behind tile G - 2 that is the NEXT group's tile 0, again in xn.  (One
+        // tile ahead -- 2.2 k cycles of MFMAs -- is less than the rows' round trip: phase A took 4 k cycles per tile.)
+        f32x4 xm[G > 1 ? CH : 1];
+        if constexpr (G > 1) fetch(grp * Gr + 1, xm);
 #pragma unroll
         for (int tg = 0; tg < G; ++tg) {
             f32x4 x[CH];
@@ -299,10 +306,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
             if (tail_wave) {
                 asm volatile("; tail wave");
 #pragma unroll
-                for (int c = 0; c < CH; ++c) x[c] = fix(xn[c], c);
+                for (int c = 0; c < CH; ++c) x[c] = fix((tg & 1) ? xm[G > 1 ? c : 0] : xn[c], c);
             } else {
 #pragma unroll
-                for (int c = 0; c < CH; ++c) x[c] = xn[c];
+                for (int c = 0; c < CH; ++c) x[c] = (tg & 1) ? xm[G > 1 ? c : 0] : xn[c];
             }
             f32x4 acc0[2][MT0];
 #pragma unroll
@@ -318,8 +325,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                         if (C::FR0 && t == C::MTF) acc0[c & 1][t] = mfma4(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
                         else acc0[c & 1][t] = mfma16(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
                     }
-            // the next tile's rows (the next group's first tile behind the last): x's registers are free from here on
-            fetch(tg + 1 < Gr ? grp * Gr + tg + 1 : (grp + gridDim.x) * Gr, xn);
+            // x's registers are free from here on
+            if constexpr (G == 1) fetch((grp + gridDim.x) * Gr, xn);
+            else if (tg + 2 < G) { if (tg & 1) fetch(grp * Gr + tg + 2, xm); else fetch(grp * Gr + tg + 2, xn); }
+            else if (tg + 2 == G) fetch((grp + gridDim.x) * Gr, xn);
             f32x4* ex = reinterpret_cast<f32x4*>(lds + C::EX_OFF) + (tg * TALL_WAVES + wave) * (MT0 * 64);
 #pragma unroll
             for (int t = 0; t < MT0; ++t) {
@@ -350,7 +359,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         };
         ldT(0, Bq[0]);
         if (Gr * 4 > 1) ldT(1, Bq[1]);
+        TALL_STAMP_G(21);
         __syncthreads();
+        TALL_STAMP_G(22);
 
         // ---- B: the narrow rest of the network for ONE tile per wave (tile = group's tile `wave`): the four partials summed in fixed
         // order, middle layers on MFMAs from the LDS image, last layer on the VALU, likelihood, delta chain, the narrow layers' dW
@@ -502,7 +513,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         }   // !FWD
         }   // slot < Gr
         }   // tb
+        TALL_STAMP_G(23);
         __syncthreads();
+        TALL_STAMP_G(24);
 
         // ---- C: dW_0 += delta_0^T [x, 1] over the group's tiles, this wave's column tiles; one k-step (rows 4 s .. 4 s + 3 of
         // tile tg) at a time, its rows requested two k-steps ahead

@@ -20,3 +20,5 @@ fn = lib.tbnn_tall_debug_stamps; fn.restype = ctypes.c_int; fn.argtypes = [ctype
 assert fn(buf) == 0
 v = list(buf)
 print("launch: prologue", v[17] - v[16], " group loop", v[18] - v[17], " dW_0 epilogue", v[19] - v[18], " rest of epilogue", v[20] - v[19], " total", v[20] - v[16])
+print("first group: phase A", v[21] - v[17], " wait at barrier 1", v[22] - v[21], " phase B", v[23] - v[22], " wait at barrier 2", v[24] - v[23],
+      " phase C (to the loop's end when the workgroup has one group)", v[18] - v[24])
