@@ -61,8 +61,8 @@ def test_logp_grad_tall_ragged_rows(native, n):
 
 @pytest.mark.parametrize("case,grid", [("mnist", 3), ("mnist", 64), ("tall_t1", 2), ("tall_t2", 5), ("tall_t3", 7)])
 def test_tall_several_tiles_per_workgroup(native, monkeypatch, case, grid):
-    """a small grid (TBNN_FAST_GRID): every workgroup walks several row tiles (accumulators carried over tiles, the exchange
-    buffers alternate) -- same value and gradient as the one-tile-per-workgroup launch, and as the fp64 oracle"""
+    """a small grid (TBNN_FAST_GRID): every workgroup walks several groups of row tiles (accumulators carried over the groups, the
+    exchange buffer and the delta_0 blocks re-used behind the barriers) -- same value and gradient as the full grid, and as the fp64 oracle"""
     spec, X, Y, theta, eta = problem(case)
     lp0, g0 = check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
     monkeypatch.setenv("TBNN_FAST_GRID", str(grid))
