@@ -57,7 +57,7 @@ __host__ __device__ static inline int tall_group_tiles(long ntiles, int gmax) {
 // accumulators in ArchVGPRs because the compiler halves a wave's budget as soon as one AccVGPR is asked for -- was built and
 // measured in round 4: 784 -> 20 -> 20 -> 1 at 12,000 rows 29.2 us against 28.4 us.  The two waves of a SIMD run the same program
 // in lockstep between the per-tile barriers, so one's serial stretch does not run under the other's MFMA blocks, and the
-// redundant narrow layers double.  Not kept.)
+// narrow layers -- which every wave then ran for the workgroup's one tile -- doubled.  Not kept.)
 template <class S, int NW_ = 4>
 struct TallCfg {
     static constexpr int NW = NW_;
@@ -565,7 +565,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
     constexpr bool WT = C::P() >= 2048;
     // ---- dW_0: every wave writes its own column tiles.  D layout: lane (n = i16, g) reg r = dW[out slot 16t+4g+r][column 16kt+n]:
     // a lane's four registers are four ROWS of the slab.  With 16-B aligned rows the tiles of one M tile are turned through the
-    // wave's own x blocks (dead by now; written [m][n], read back lane-linearly: lane l holds row l / 4, columns 4 (l % 4) .. +3)
+    // wave's own share of the staging area (the exchange buffer, dead by now; written [m][n], read back lane-linearly: lane l holds row
+    // l / 4, columns 4 (l % 4) .. +3)
     // and leave as 16-byte write-through stores -- a 4-byte sc1 store is one fabric write per lane
     {
         constexpr int out0 = C::out(0);
@@ -741,8 +742,8 @@ static inline int tall_forward_t(int gx, int nets, hipStream_t st, const float* 
                                  float* fouts, long out_stride) {
     NetDev nd{};
     constexpr int NW = TallPick<S>::NW;
-    // (forward only: no narrow-stretch redundancy worth sharing out at the price of fewer workgroups -- one tile per group)
-    hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, true, 1>), dim3(gx, nets), dim3(64 * NW), 0, st, nd, qimgs, img_stride, (const float*)nullptr, X,
+    // (forward only: groups of four -- the caller's grid is one workgroup per four row tiles, capped for ensembles: narrow_forward)
+    hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, true, 4>), dim3(gx, nets), dim3(64 * NW), 0, st, nd, qimgs, img_stride, (const float*)nullptr, X,
                        (const float*)nullptr, n, (float*)nullptr, 0, (double*)nullptr, fouts, out_stride, ChainStride{0, 0, 0});
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
