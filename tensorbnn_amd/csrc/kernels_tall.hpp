@@ -4,7 +4,7 @@
 // and the rows (3 KB each) are what the pass streams.  Until round 4 such shapes ran on the layered family (five launches,
 // the rows read twice per gradient).
 //
-// One WORKGROUP walks GROUPS of G row tiles (G = 1, 2 or 4 by the row count, tall_group_tiles); the fan-in is split over its four
+// One WORKGROUP walks GROUPS of G row tiles (G = 1 .. 4 by the row count, tall_group_tiles); the fan-in is split over its four
 // waves (wave w owns the column tiles [w CH, (w+1) CH) of the rows, of W_0 and of dW_0).  A group runs in three phases:
 //   A. layer 0 of the group's tiles: W_0's chunk lives in the wave's REGISTERS for the whole launch, as MFMA A operands (MT0 x CH x 4
 //      VGPRs), fetched once from the padded image k_update maintains; every wave multiplies its chunk of a tile's rows (16-B buffer
@@ -38,14 +38,14 @@
 #define TALL_STAMP_G(k) do {} while (0)
 #endif
 
-// Row tiles per group (1, 2 or 4 = TallCfg::GMAX: the instantiations of the kernel) at a given tile count.  A workgroup walks a group in three phases: layer 0 of its tiles (a per tile),
+// Row tiles per group (1 .. 4 = TallCfg::GMAX: the instantiations of the kernel) at a given tile count.  A workgroup walks a group in three phases: layer 0 of its tiles (a per tile),
 // the narrow stretch of ONE tile per wave (b per group, whatever the tile count), dW_0 of its tiles (part of a): with a ~ 2.3 us and
 // b ~ 5.8 us incl. the two barriers (784 -> 20 -> 20 -> 1) a launch over `ntiles` tiles costs rounds(g) x (g a + b), rounds(g) = ceil(ceil(ntiles / g) / 256
 // workgroups).  Big groups share the narrow stretch out best (3.65 us per tile at g = 4 against 5.0 at g = 1), small ones fill the
 // chip at few rows.  The same function sizes the grid and picks the instantiation.
 __host__ __device__ static inline int tall_group_tiles(long ntiles, int gmax) {
     int best = 1; long best_cost = 0;
-    for (int g = 1; g <= gmax; g *= 2) {
+    for (int g = 1; g <= gmax; g = g < 4 ? g + 1 : 2 * g) {
         const long groups = (ntiles + g - 1) / g, rounds = (groups + 255) / 256;
         const long cost = rounds * (23 * g + 58 + (g > 4 ? 24 * (g / 4 - 1) : 0));      // (g = 8: every wave runs the narrow stretch twice)
         if (g == 1 || cost < best_cost) { best = g; best_cost = cost; }
@@ -160,7 +160,7 @@ struct TallLast {              // per-lane partial sums of the VALU last layer's
 };
 
 // FWD: forward pass only (network.predict, network.py:141-171; predictor.py:132-155 with blockIdx.y = network)
-// G: row tiles per group (1, 2 or 4 -- tall_group_tiles -- a template parameter: with the group size a run-time value the tile loops
+// G: row tiles per group (1 .. 4 -- tall_group_tiles -- a template parameter: with the group size a run-time value the tile loops
 // of phases A and C end in branches, every tile becomes a scheduling region of its own, and the launch measured 9 % slower)
 template <class S, int NW, bool FWD = false, int G = 4>
 __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void k_fwd_bwd_tall(
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         // Two accumulator sets (even / odd column tiles) keep the MFMA chain four deep (a lone pair of accumulators is revisited
         // after 32 cycles, 8 short of the dependent latency)
         // The group's rows arrive two tiles ahead of their use: tile 0 was requested a group ago (xn), tile 1 is requested here (xm), tile
-        // t + 2 behind tile t's MFMAs into the set tile t vacated; behind tile G - 2 that is the NEXT group's tile 0, again in xn.  (One
+        // t + 2 behind tile t's MFMAs into the set tile t vacated; behind xn's last tile of the group that is the NEXT group's tile 0.  (One
         // tile ahead -- 2.2 k cycles of MFMAs -- is less than the rows' round trip: phase A took 4 k cycles per tile.)
         f32x4 xm[G > 1 ? CH : 1];
         if constexpr (G > 1) fetch(grp * Gr + 1, xm);
@@ -326,9 +326,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                         else acc0[c & 1][t] = mfma16(Wr[t][c][s], x[c][s], acc0[c & 1][t]);
                     }
             // x's registers are free from here on
-            if constexpr (G == 1) fetch((grp + gridDim.x) * Gr, xn);
-            else if (tg + 2 < G) { if (tg & 1) fetch(grp * Gr + tg + 2, xm); else fetch(grp * Gr + tg + 2, xn); }
-            else if (tg + 2 == G) fetch((grp + gridDim.x) * Gr, xn);
+            if (tg + 2 < G) {
+                if constexpr (G > 2) { if (tg & 1) fetch(grp * Gr + tg + 2, xm); else fetch(grp * Gr + tg + 2, xn); }
+            } else if ((tg & 1) == 0) fetch((grp + gridDim.x) * Gr, xn);      // xn's last tile of this group: the next group's tile 0
             f32x4* ex = reinterpret_cast<f32x4*>(lds + C::EX_OFF) + (tg * TALL_WAVES + wave) * (MT0 * 64);
 #pragma unroll
             for (int t = 0; t < MT0; ++t) {
@@ -730,6 +730,7 @@ static inline int tall_launch_t(int grid, hipStream_t st, const NetDev& nd, cons
     switch (tall_group_tiles((n + 15) / 16, GMAX)) {
         case 1: TALL_LAUNCH(1); break;
         case 2: TALL_LAUNCH(2); break;
+        case 3: TALL_LAUNCH(3); break;
         case 4: TALL_LAUNCH(4); break;
         default: if constexpr (GMAX >= 8) TALL_LAUNCH(8); break;
     }

@@ -44,10 +44,10 @@ def test_logp_grad_tall(native, case):
     assert np.abs(g - g_g).max() <= 5e-5 * np.abs(g_g).max()
 
 
-@pytest.mark.parametrize("n", [1, 17, 5000 + 3, 12000 + 7, 20000 + 1])
+@pytest.mark.parametrize("n", [1, 17, 5000 + 3, 12000 + 7, 20000 + 1, 50000 + 3])
 def test_logp_grad_tall_group_sizes_aligned_rows(native, n):
-    """the 16-byte-aligned row path (784 columns) at row counts that take groups of 1, 2 and 4 row tiles (tall_group_tiles), each with a
-    ragged last tile and -- for 2 and 4 -- a last group that is not full"""
+    """the 16-byte-aligned row path (784 columns) at row counts that take groups of 1 (<= 17 rows), 2 (5,003), 3 (12,007; 20,001) and 4
+    (50,003) row tiles (tall_group_tiles), each with a ragged last tile and a last group that is not full"""
     spec, X, Y, theta, eta = o.synth_problem([784, 20, 20, 1], n, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI)
     X = (np.abs(X) / 28.0).astype(np.float32)
     check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
