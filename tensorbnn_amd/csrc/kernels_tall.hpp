@@ -43,7 +43,8 @@
 // b ~ 5.8 us incl. the two barriers (784 -> 20 -> 20 -> 1) a launch over `ntiles` tiles costs rounds(g) x (g a + b), rounds(g) = ceil(ceil(ntiles / g) / 256
 // workgroups).  Big groups share the narrow stretch out best (3.65 us per tile at g = 4 against 5.0 at g = 1), small ones fill the
 // chip at few rows.  The same function sizes the grid and picks the instantiation.
-__host__ __device__ static inline int tall_group_tiles(long ntiles, int gmax) {
+static inline int tall_group_tiles(long ntiles, int gmax) {
+    if (const char* e = getenv("TBNN_TALL_G")) { const int g = atoi(e); if (g >= 1 && g <= gmax) return g; }       // A/B runs
     int best = 1; long best_cost = 0;
     for (int g = 1; g <= gmax; g = g < 4 ? g + 1 : 2 * g) {
         const long groups = (ntiles + g - 1) / g, rounds = (groups + 255) / 256;
