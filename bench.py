@@ -36,9 +36,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = 157.3
 CONFIG_KEY = {"c1": "configs[0]", "c2": "configs[1]", "c4": "configs[3]", "c5": "configs[4]",
-              "c5g": "configs[4] with GaussianDenseLayer priors"}
+              "c5g": "configs[4] with GaussianDenseLayer priors", "mn": "docs example 784-20-20-1"}
 # CPU sample per workload: (max epochs, leapfrog steps per epoch, wall cap in s) for the all-threads run
-CPU_SAMPLE = {"c1": (20, 100, 10.0), "c2": (20, 50, 30.0), "c4": (1, 3, 30.0), "c5": (1, 20, 30.0)}
+CPU_SAMPLE = {"c1": (20, 100, 10.0), "c2": (20, 50, 30.0), "c4": (1, 3, 30.0), "c5": (1, 20, 30.0), "mn": (4, 50, 15.0)}
 
 
 def algorithmic_flops(dims, n):
@@ -57,6 +57,20 @@ def host_cpus():
     except OSError:
         cores = set(aff)
     return len(aff), len(cores)
+
+
+def cgroup_throttled_ms():
+    """milliseconds this container's cgroup has spent throttled by its CPU quota so far (cgroup v2 cpu.stat), or None.  A math
+    library that starts a thread per LOGICAL CPU (256 on the test boxes) under a 16-CPU quota burns the 100-ms period's quota in a
+    few ms of spinning; the kernel then freezes every thread of the container -- the launch thread too -- for the rest of the period:
+    measured as single 77-80 ms stalls inside timed regions that follow a NumPy matmul (NOTES.md, round 4)."""
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            if ln.startswith("throttled_usec"):
+                return int(ln.split()[1]) / 1000.0
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def cgroup_cpu_max():
@@ -186,7 +200,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
 
     wl = WORKLOADS[name]
     DIMS, N_ROWS, L = wl["dims"], wl["n"], wl["L"]
-    layers, lik, X, Y, theta0, eta0 = synth_problem(DIMS, N_ROWS, prior=wl["prior"], likelihood=wl["lik"])
+    layers, lik, X, Y, theta0, eta0 = synth_problem(DIMS, N_ROWS, prior=wl["prior"], likelihood=wl["lik"], x_scale=wl.get("x_scale"))
     burned = None if args.from_initial else burned_state(name, os.path.join(ROOT, "tests", "golden"))
     hyper = wl["hyper"]                   # configs[4]: hyper-HMC on the priors enabled (network.py:414-471)
     da = None
@@ -195,7 +209,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
         eps_warm = eps = float(burned["eps"])
         state = f"burned-in ({int(burned['epochs'])} epochs, tests/golden/{name}_burned.npz)"
     else:
-        eps_warm, eps = bench_eps(name) if name != "c1" else (1e-4, 1e-4)
+        eps_warm, eps = bench_eps(name) if name not in ("c1", "mn") else ((1e-4, 1e-4) if name == "c1" else (1e-3, 1e-3))
         state = "initial state (no burned-in fixture): warm-up at eps_warmup"
     if args.eps is not None:
         eps_warm = eps = args.eps
@@ -288,6 +302,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
     # 1.2 % off the measured rate of configs[1] (19.75 k against 19.98 k leapfrog steps/s)
     ch.set_profiling(int(os.environ.get("TBNN_BENCH_PROFILE_STRIDE", "47")))
     fence()
+    thr0 = cgroup_throttled_ms()
     t0 = time.perf_counter()
     outs = run(steps, eps)
     dt_own = time.perf_counter() - t0          # this rank's own clock: its last epoch's record has been read back (hmc_run / gather return)
@@ -296,6 +311,8 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
         os._exit(3)
     fence()
     dt = time.perf_counter() - t0
+    thr1 = cgroup_throttled_ms()
+    throttled = round(thr1 - thr0, 1) if (thr0 is not None and thr1 is not None) else None
     ranks = None
     if dist_on:
         cdev = ctx["cdev"]
@@ -365,7 +382,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
                    "rows": N_ROWS, "chains": world, "parallelism": f"{world} independent chains",
                    "kernel": kernel_name, "start_state": state, "sample_gather": gather_kind},
         "accept_ratio": round(acc_prob, 4), "accepted_fraction": round(acc_frac, 4),
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "cgroup_throttled_ms_in_timed_region": throttled,
     }
     if ranks is not None:
         line["ranks"] = ranks
@@ -385,7 +402,7 @@ def run_chain_group(name, n_chains, steps, warmup, dev):
     from tensorbnn_amd import _native as nat
     from tensorbnn_amd.workloads import WORKLOADS, burned_state, synth_problem
     wl = WORKLOADS[name]
-    layers, lik, X, Y, theta0, eta0 = synth_problem(wl["dims"], wl["n"], prior=wl["prior"], likelihood=wl["lik"])
+    layers, lik, X, Y, theta0, eta0 = synth_problem(wl["dims"], wl["n"], prior=wl["prior"], likelihood=wl["lik"], x_scale=wl.get("x_scale"))
     b = burned_state(name, os.path.join(ROOT, "tests", "golden"))
     theta0, eta0, eps = b["theta"].astype(np.float32), b["eta"].astype(np.float32), float(b["eps"])
     g = nat.ChainGroup(layers, n_chains, likelihood=lik, device=dev, seed=50, chain_id=0)
@@ -443,6 +460,8 @@ def compact_line(line):
     cfg.pop("parallelism", None)
     out["config"] = cfg
     out.pop("accepted_fraction", None)
+    if not out.get("cgroup_throttled_ms_in_timed_region"):
+        out.pop("cgroup_throttled_ms_in_timed_region", None)
     if "ranks" in out:                                   # per-rank diagnostics: min / max and what the collective library counted
         r = out["ranks"]
         out["ranks"] = {"steps_per_s_min": r["steps_per_s_min"], "steps_per_s_max": r["steps_per_s_max"],
@@ -456,20 +475,22 @@ def compact_line(line):
             if "chains_on_one_gpu" in r:
                 sec["configs[0]x64"] = {"value": r["value"], "chains": r["chains_on_one_gpu"], "per_chain": r["per_chain"], "accept": r["accept_ratio"]}
                 continue
-            e = {"value": r["value"], "ms_per_step": r["ms_per_step"], "accept": r["accept_ratio"], "L": r["config"]["leapfrog_per_step"]}
+            e = {"value": r["value"], "ms_per_step": round(r["ms_per_step"], 3), "accept": round(r["accept_ratio"], 3)}      # (L = value x ms_per_step / 1000)
             rf = r.get("roofline") or {}
             for k in ("frac", "frac_rocprof", "traffic"):
-                if rf.get(k) is not None:
+                if rf.get(k) is not None and not (k != "frac" and key.endswith("GaussianDenseLayer priors")):      # ([4]g: [4]'s kernel, [4]'s profile)
                     e[k] = rf[k]
             c = r.get("cpu_baseline")
             if c:
                 e["cpu"] = c["value"]
+            if r.get("cgroup_throttled_ms_in_timed_region"):
+                e["throttled_ms"] = r["cgroup_throttled_ms_in_timed_region"]
             if "hyper_accept_ratio" in r:
                 e["hyper_accept"] = r["hyper_accept_ratio"]
                 e["hyper_step"] = float("%.3g" % r["hyper_step_size"]["last"]) if r.get("hyper_step_size") else None
-            sec[key.replace(" with GaussianDenseLayer priors", "g")] = e
+            sec[key.replace(" with GaussianDenseLayer priors", "g").replace("docs example 784-20-20-1", "docs784")] = e
         out["secondary"] = sec
-        out["secondary_note"] = "[4]: Cauchy priors (improper hyper target, Q1); [4]g: Gaussian priors; [0]x64: 64 chains on ONE GPU; full: gpurun_out/bench_full.json"
+        out["secondary_note"] = "[4]: Cauchy priors (improper hyper target, Q1); [4]g: Gaussian priors; [0]x64: 64 chains, 1 GPU; docs784: reference tutorial shape; full: gpurun_out/bench_full.json"
     return out
 
 
@@ -532,7 +553,7 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c4", "c5", "c5g"],
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c4", "c5", "c5g", "mn"],
                     help="measure this workload alone (default: c2 = BASELINE configs[1], + the others as `secondary` at N = 1)")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
@@ -554,6 +575,10 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:      # ranks started by a launcher: same thread caps as spawn_ranks sets
         for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
             os.environ.setdefault(var, "2")
+    else:
+        # one process: NumPy's BLAS (the synthetic problems' teacher networks) must not start a thread per LOGICAL CPU under a CPU quota
+        # (see cgroup_throttled_ms); the CPU baseline sets its own thread counts through the C library / torch
+        os.environ.setdefault("OPENBLAS_NUM_THREADS", "8")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -606,7 +631,7 @@ def main():
     line = run_workload(main_wl, steps, warmup, args, rank, world, dev, ctx)
     if args.workload is None and world == 1 and not args.no_secondary:
         sec = {}
-        for name in ("c4", "c5", "c5g", "c1"):
+        for name in ("c4", "c5", "c5g", "c1", "mn"):
             w2 = WORKLOADS[name]
             try:
                 r = run_workload(name, w2["steps"], w2["warmup"], args, rank, world, dev, ctx)

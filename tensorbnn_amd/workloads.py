@@ -37,6 +37,11 @@ WORKLOADS = {
     "c4": dict(dims=[10, 200, 200, 200, 1], n=1_000_000, L=100, lik=nat.LIK_GAUSSIAN, hyper=False, steps=10, warmup=2,
                text="BASELINE configs[3]: 10->200->200->200->1 Relu BNN (Cauchy DenseLayer, GaussianLikelihood sd=0.1), "
                     "1M-row fp32 synthetic regression, L=100 leapfrog, 1 chain per GPU"),
+    # not a BASELINE config: the reference's own classification tutorial (docs/ClassificationExample.md:103-173: 784 -> 20 -> 20 -> 1 on
+    # MNIST pixels, two digits = 12k rows) with pixel-like synthetic rows |N(0,1)| / 28 -- the shape the tall-fan-in fused family is for
+    "mn": dict(dims=[784, 20, 20, 1], n=12_000, L=50, lik=nat.LIK_BERNOULLI, hyper=False, steps=40, warmup=5, x_scale=1.0 / 28.0,
+               text="docs/ClassificationExample.md shape: 784->20->20->1 Relu/Sigmoid BNN (Cauchy DenseLayer, BernoulliLikelihood), "
+                    "12k pixel-like fp32 synthetic rows, L=50 leapfrog, 1 chain per GPU"),
     "c5": dict(dims=[20, 100, 100, 2], n=500_000, L=50, lik=nat.LIK_BERNOULLI, hyper=True, steps=40, warmup=5,
                text="BASELINE configs[4]: 20->100->100->2 Relu/Sigmoid BNN (Cauchy DenseLayer, BernoulliLikelihood), "
                     "500k-row fp32 synthetic classification, L=50 leapfrog + hyper-HMC (L_h=100, dual averaging) per epoch, "
@@ -74,12 +79,15 @@ def _act(z, a):
     return z
 
 
-def synth_problem(dims, n, act=nat.ACT_RELU, prior=nat.PRIOR_CAUCHY, likelihood=nat.LIK_GAUSSIAN):
-    """returns (layers, likelihood, X[n,d_in], Y[n,d_out], theta0[P], eta0[H])"""
+def synth_problem(dims, n, act=nat.ACT_RELU, prior=nat.PRIOR_CAUCHY, likelihood=nat.LIK_GAUSSIAN, x_scale=None):
+    """returns (layers, likelihood, X[n,d_in], Y[n,d_out], theta0[P], eta0[H]); x_scale: rows |N(0,1)| * x_scale (pixel-like)
+    instead of N(0,1)"""
     nl = len(dims) - 1
     final_act = nat.ACT_SIGMOID if likelihood == nat.LIK_BERNOULLI else nat.ACT_NONE
     layers = [(dims[i], dims[i + 1], final_act if i == nl - 1 else act, prior) for i in range(nl)]
     X = np.random.Generator(np.random.PCG64(1234)).standard_normal((n, dims[0])).astype(np.float32)
+    if x_scale is not None:
+        X = (np.abs(X) * np.float32(x_scale)).astype(np.float32)
     tg = np.random.Generator(np.random.PCG64(4321))
     a = X.T.astype(np.float32)
     for (i, o, ac, _) in layers:

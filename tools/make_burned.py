@@ -34,6 +34,7 @@ PLAN = {   # blocks x epochs per block of burn-in, starting eps, scan candidates
     "c4": dict(blocks=24, per=5, eps0=1e-6),
     "c5": dict(blocks=40, per=10, eps0=5e-5, n_scan=120, scan=(0.25, 0.35, 0.5, 0.63, 0.8, 1.0, 1.25, 1.6)),   # erratic acceptance (stiff prior): long windows
     "c5g": dict(blocks=40, per=10, eps0=5e-5, n_scan=80),
+    "mn": dict(blocks=40, per=10, eps0=1e-3),
 }
 SCAN = (0.5, 0.63, 0.8, 1.0, 1.25, 1.6, 2.0)
 
@@ -46,7 +47,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     for cfg in args.cfgs:
         wl, plan = WORKLOADS[cfg], PLAN[cfg]
-        layers, lik, X, Y, theta0, eta0 = synth_problem(wl["dims"], wl["n"], prior=wl["prior"], likelihood=wl["lik"])
+        layers, lik, X, Y, theta0, eta0 = synth_problem(wl["dims"], wl["n"], prior=wl["prior"], likelihood=wl["lik"], x_scale=wl.get("x_scale"))
         ch = nat.Chain(layers, likelihood=lik, device=0, seed=50, chain_id=0)
         ch.set_data(X, Y); ch.set_state(theta0); ch.set_hypers(eta0)
         L, eps = wl["L"], plan["eps0"]
