@@ -10,7 +10,7 @@ from tensorbnn_amd.workloads import WORKLOADS, burned_state, synth_problem
 name = sys.argv[1] if len(sys.argv) > 1 else "c1"
 counts = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8, 16, 32, 64]
 wl = WORKLOADS[name]
-layers, lik, X, Y, theta0, eta0 = synth_problem(wl["dims"], wl["n"], prior=wl["prior"], likelihood=wl["lik"])
+layers, lik, X, Y, theta0, eta0 = synth_problem(wl["dims"], wl["n"], prior=wl["prior"], likelihood=wl["lik"], x_scale=wl.get("x_scale"))
 b = burned_state(name, os.path.join(ROOT, "tests", "golden"))
 theta0, eta0, eps = b["theta"].astype(np.float32), b["eta"].astype(np.float32), float(b["eps"])
 dX, dY = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
