@@ -34,7 +34,7 @@ PLAN = {   # blocks x epochs per block of burn-in, starting eps, scan candidates
     "c4": dict(blocks=24, per=5, eps0=1e-6),
     "c5": dict(blocks=40, per=10, eps0=5e-5, n_scan=120, scan=(0.25, 0.35, 0.5, 0.63, 0.8, 1.0, 1.25, 1.6)),   # erratic acceptance (stiff prior): long windows
     "c5g": dict(blocks=40, per=10, eps0=5e-5, n_scan=80),
-    "mn": dict(blocks=40, per=10, eps0=1e-3),
+    "mn": dict(blocks=400, per=10, eps0=1e-3, n_scan=100),     # 4,000 epochs: the acceptance at a fixed eps keeps falling for the first ~2,000
 }
 SCAN = (0.5, 0.63, 0.8, 1.0, 1.25, 1.6, 2.0)
 
