@@ -119,6 +119,43 @@ def _load():
 lib = _load()
 
 
+_QUOTA_WARNED = False
+
+
+def cpu_quota():
+    """CPUs this container may use per scheduling period (cgroup v2 cpu.max), or None when unlimited / unknown"""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, p = fh.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def _warn_cpu_quota_once():
+    """A chain is driven by ONE host thread that queues a few hundred launches per transition.  Under a CPU quota a math library with a
+    thread per logical CPU (NumPy's OpenBLAS on a 256-CPU box with a 16-CPU quota) exhausts the quota period in milliseconds and the kernel
+    freezes the whole container -- that thread too -- until the period ends: single 80-ms stalls (NOTES.md round 4).  Said
+    once per process when a BLAS / OpenMP pool larger than the quota is loaded."""
+    global _QUOTA_WARNED
+    if _QUOTA_WARNED:
+        return
+    _QUOTA_WARNED = True
+    quota = cpu_quota()
+    if quota is None or (os.cpu_count() or 1) <= quota:
+        return
+    try:
+        from threadpoolctl import threadpool_info
+        big = [f"{i.get('internal_api')}: {i.get('num_threads')} threads" for i in threadpool_info() if (i.get("num_threads") or 0) > quota]
+    except Exception:
+        return
+    if big:
+        import warnings
+        warnings.warn(f"tensorbnn_amd: this container may use {quota:g} CPUs per period but a math library runs {', '.join(big)}; its threads can "
+                      f"get the whole container throttled, the GPU launch thread included (single ~80 ms stalls).  Set OPENBLAS_NUM_THREADS / "
+                      f"OMP_NUM_THREADS / MKL_NUM_THREADS <= {int(quota)} before importing NumPy (INTEGRATION.md section 4a).", RuntimeWarning, stacklevel=3)
+
+
 def _check(rc: int):
     if rc < 0:
         raise TbnnError(f"libtbnn error {rc}: {lib.tbnn_last_error().decode()}")
@@ -158,6 +195,7 @@ class Chain:
             from . import jit as _jit
             if (jit if jit is not None else _jit.enabled()) and lib.tbnn_fused_kernel_available(C.byref(desc)) == 0:
                 _jit.ensure_registered(layers, likelihood)
+        _warn_cpu_quota_once()
         h = _H()
         _check(lib.tbnn_create(C.byref(desc), int(device), int(seed), int(chain_id), C.byref(h)))
         self._h = h
@@ -363,6 +401,7 @@ class ChainGroup:
             from . import jit as _jit
             if (jit if jit is not None else _jit.enabled()) and lib.tbnn_fused_kernel_available(C.byref(desc)) == 0:
                 _jit.ensure_registered(layers, likelihood)
+        _warn_cpu_quota_once()
         h = _H()
         _check(lib.tbnn_create_multi(C.byref(desc), int(device), int(seed), int(chain_id), int(n_chains), C.byref(h)))
         self._h = h

@@ -1,6 +1,10 @@
 import os
 import sys
 
+# (before NumPy is imported: the GPU boxes schedule 16 of 256 logical CPUs; a BLAS pool of 256 spinning threads gets the container
+# throttled, launch thread included -- tensorbnn_amd._native warns about it, NOTES.md round 4)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "8")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

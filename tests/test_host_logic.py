@@ -430,7 +430,7 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
 
     monkeypatch.setattr(subprocess, "call", fake_call)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):      # (conftest caps OpenBLAS for the test process itself)
         monkeypatch.delenv(k, raising=False)
     with pytest.raises(SystemExit) as e:
         bench.main()
@@ -474,3 +474,36 @@ def test_visible_gpus(monkeypatch, tmp_path):
     import builtins as _b
     monkeypatch.setattr(_b, "open", real_open); monkeypatch.setattr(os, "listdir", real_listdir)
     assert bench.visible_gpus() in (0, None)
+
+
+def test_cpu_quota_warning(monkeypatch, tmp_path):
+    """_native warns once per process when a math library's thread pool is larger than the container's CPU quota (the launch thread of
+    a chain was frozen for 80 ms at a time on a 256-CPU box with a 16-CPU quota: NOTES.md round 4)"""
+    import builtins, warnings, types
+    from tensorbnn_amd import _native as nat
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            import io
+            return io.StringIO("400000 100000\n")
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert nat.cpu_quota() == 4.0
+    fake = types.ModuleType("threadpoolctl")
+    fake.threadpool_info = lambda: [{"internal_api": "openblas", "num_threads": 64}, {"internal_api": "openmp", "num_threads": 2}]
+    monkeypatch.setitem(sys.modules, "threadpoolctl", fake)
+    monkeypatch.setattr(nat.os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(nat, "_QUOTA_WARNED", False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        nat._warn_cpu_quota_once()
+        nat._warn_cpu_quota_once()                      # once per process
+    assert len(w) == 1 and "openblas: 64 threads" in str(w[0].message) and "OPENBLAS_NUM_THREADS" in str(w[0].message)
+    # a pool within the quota: silent
+    fake.threadpool_info = lambda: [{"internal_api": "openblas", "num_threads": 4}]
+    monkeypatch.setattr(nat, "_QUOTA_WARNED", False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        nat._warn_cpu_quota_once()
+    assert not w
