@@ -432,9 +432,7 @@ def _short_cpu(c):
            "sample": c["sample"].split(" (+1")[0] + ", oracle/c OpenMP"}
     if "one_thread" in c:
         out["one_thread"] = c["one_thread"]["value"]
-    if isinstance(c.get("torch_cpu"), dict) and "value" in c["torch_cpu"]:
-        out["torch_cpu"] = c["torch_cpu"]["value"]
-    return out
+    return out                                 # (the PyTorch-CPU cross-check is in the full record)
 
 
 def _short_roof(r):
@@ -443,6 +441,8 @@ def _short_roof(r):
     keep = ("bound", "achieved", "peak", "unit", "frac", "frac_rocprof", "rocprof_source", "profile_build_match", "traffic",
             "kernel_us", "end_to_end_frac")          # ("kernel" is config.kernel: not repeated on the short line)
     out = {k: r[k] for k in keep if k in r}
+    if out.get("rocprof_source"):
+        out["rocprof_source"] = out["rocprof_source"].replace("profiles/", "")
     if "launch latency" in str(out.get("bound", "")):
         out["bound"] = "launch latency"
     return out
@@ -490,7 +490,7 @@ def compact_line(line):
                 e["hyper_step"] = float("%.3g" % r["hyper_step_size"]["last"]) if r.get("hyper_step_size") else None
             sec[key.replace(" with GaussianDenseLayer priors", "g").replace("docs example 784-20-20-1", "docs784")] = e
         out["secondary"] = sec
-        out["secondary_note"] = "[4]: Cauchy priors (improper hyper target, Q1); [4]g: Gaussian priors; [0]x64: 64 chains, 1 GPU; docs784: reference tutorial shape; full: gpurun_out/bench_full.json"
+        out["secondary_note"] = "[4]: Cauchy priors (improper hyper target, Q1); [4]g: Gaussian priors; [0]x64: 64 chains, 1 GPU; docs784: reference tutorial shape; all: gpurun_out/bench_full.json"
     return out
 
 

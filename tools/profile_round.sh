@@ -13,7 +13,8 @@ declare -A CMD
 CMD[c2]="python3 bench.py --workload c2 --steps 40 --warmup 10 --no-cpu-baseline"
 CMD[c4]="python3 bench.py --workload c4 --no-cpu-baseline"
 CMD[c5]="python3 bench.py --workload c5 --no-cpu-baseline"
-for W in ${PROFILE_WORKLOADS:-c2 c4 c5}; do
+CMD[mn]="python3 bench.py --workload mn --no-cpu-baseline"
+for W in ${PROFILE_WORKLOADS:-c2 c4 c5 mn}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- ${CMD[$W]} > $OUT/trace_$W.log 2>&1 || echo "trace $W failed"
   f=$(find $OUT/trace_$W -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${W}_kernel_stats.csv
   i=0

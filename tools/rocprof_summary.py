@@ -6,12 +6,13 @@ import collections, csv, glob, json, os, sys
 out = sys.argv[1]
 tag = os.path.basename(os.path.normpath(out))
 # kernels of one fused forward+backward pass, per workload
-PASS = {"c2": ["k_fwd_bwd_fast3"], "c4": ["k_chain_wide", "k_dw_wide", "k_reduce_wide"], "c5": ["k_fwd_bwd_mid", "k_chain_wide", "k_dw_wide", "k_reduce_wide"]}
-PASS = {w: PASS[w] for w in os.environ.get("PROFILE_WORKLOADS", "c2 c4 c5").split() if w in PASS}
+PASS = {"c2": ["k_fwd_bwd_fast3"], "c4": ["k_chain_wide", "k_dw_wide", "k_reduce_wide"], "c5": ["k_fwd_bwd_mid", "k_chain_wide", "k_dw_wide", "k_reduce_wide"],
+        "mn": ["k_fwd_bwd_tall"]}
+PASS = {w: PASS[w] for w in os.environ.get("PROFILE_WORKLOADS", "c2 c4 c5 mn").split() if w in PASS}
 
 
 def kname(full):
-    for k in ("k_fwd_bwd_fast3", "k_fwd_bwd_fast", "k_fwd_bwd_mid", "k_chain_wide", "k_dw_wide", "k_reduce_wide", "k_update", "k_hyper", "k_energy"):
+    for k in ("k_fwd_bwd_fast3", "k_fwd_bwd_fast", "k_fwd_bwd_mid", "k_fwd_bwd_tall", "k_chain_wide", "k_dw_wide", "k_reduce_wide", "k_update", "k_hyper", "k_energy"):
         if k in full:
             return k
     return None
