@@ -123,6 +123,9 @@ struct TallCfg {
         for (int m = 1; m <= NM; ++m) wave += (TA(m) + TR(m + 1)) * 256;
         return SMALL_FLOATS + (ex > stg ? ex : stg) + gmax * MT0 * 256 + NW * wave;
     }
+#ifndef TALL_C_REVERSE
+#define TALL_C_REVERSE 1
+#endif
 #ifndef TALL_GMAX
 #define TALL_GMAX 4
 #endif
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         }
         // dW_0's first operands (tile 0, k-step 0): requested here, used behind the narrow stretch
         float Bq[3][FWD ? 1 : CH];
-        __amdgpu_buffer_rsrc_t rsT = rsrc_rows(grp * Gr);
+        __amdgpu_buffer_rsrc_t rsT = rsrc_rows(grp * Gr + (TALL_C_REVERSE ? Gr - 1 : 0));
         auto ldT = [&](int s, float (&B)[FWD ? 1 : CH]) __attribute__((always_inline)) {
             if constexpr (!FWD) {
 #pragma unroll
@@ -523,9 +526,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         if constexpr (!FWD) {
 #pragma unroll
             for (int q = 0; q < 4 * G; ++q) {
-                const int tg = q >> 2, s = q & 3;
+                // (TALL_C_REVERSE: the group's LAST tile first -- its rows were read most recently in phase A and are the likeliest
+                // to be in L2 still: 32 workgroups' groups of three are 4.8 MB against an XCD's 4 MB)
+                const int tg = TALL_C_REVERSE ? Gr - 1 - (q >> 2) : (q >> 2), s = q & 3;
                 if (q + 2 < 4 * Gr) {                                // two k-steps (52 MFMAs) ahead, three operand sets
-                    if (((q + 2) & 3) == 0) rsT = rsrc_rows(grp * Gr + ((q + 2) >> 2));
+                    if (((q + 2) & 3) == 0) rsT = rsrc_rows(grp * Gr + (TALL_C_REVERSE ? Gr - 1 - ((q + 2) >> 2) : ((q + 2) >> 2)));
                     ldT((q + 2) & 3, Bq[(q + 2) % 3]);
                 }
                 float (&Bop)[CH] = Bq[q % 3];
