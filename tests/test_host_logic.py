@@ -411,7 +411,7 @@ def test_bench_line_fits_driver_tail():
         assert k in line
     assert line["roofline"]["frac_rocprof"] == 0.4291 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
     # the round-4 record (one more secondary entry: 64 chains on one GPU): the WHOLE line inside the 2-KB tail, so that it parses
-    full4 = json.load(open(os.path.join(ROOT, "profiles", "r04h_bench_full.json")))
+    full4 = json.load(open(os.path.join(ROOT, "profiles", "r04i_bench_full.json")))
     text4 = json.dumps(bench.compact_line(full4))
     assert len(text4) <= 2048 and '"configs[0]x64": {"value"' in text4 and json.loads(text4)["roofline"]["profile_build_match"] is True
 
