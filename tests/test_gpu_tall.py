@@ -53,6 +53,22 @@ def test_logp_grad_tall_group_sizes_aligned_rows(native, n):
     check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST)
 
 
+@pytest.mark.parametrize("case", ["mnist", "tall_t1", "tall_t3"])
+def test_tall_every_group_size_on_the_same_rows(native, monkeypatch, case):
+    """TBNN_TALL_G forces the instantiation: groups of 1, 2, 3 and 4 row tiles on the SAME rows (a tile count no group size divides) give the
+    same value and gradient up to fp32 summation order, and each matches the fp64 oracle"""
+    spec, X, Y, theta, eta = problem(case)
+    res = []
+    for g in (1, 2, 3, 4):
+        monkeypatch.setenv("TBNN_TALL_G", str(g))
+        res.append(check_logp_grad(native, spec, X, Y, theta, eta, kernel=native.KERNEL_FAST))
+    monkeypatch.delenv("TBNN_TALL_G")
+    lp0, g0 = res[0]
+    for lp, g in res[1:]:
+        assert abs(lp - lp0) <= 1e-6 * abs(lp0) + 1e-5
+        assert np.abs(g - g0).max() <= 2e-5 * np.abs(g0).max()
+
+
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 129, 4200 + 3])
 def test_logp_grad_tall_ragged_rows(native, n):
     spec, X, Y, theta, eta = o.synth_problem([70, 24, 40, 1], n, o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN)
