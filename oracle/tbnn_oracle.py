@@ -828,12 +828,14 @@ def synth_problem(dims, n, act=ACT_RELU, prior=PRIOR_CAUCHY, likelihood=LIK_GAUS
         sd = (2.0 / l.out_dim) ** 0.5
         tparts.append(((tg.standard_normal((l.out_dim, l.in_dim)) * sd).astype(np.float32),
                        (tg.standard_normal((l.out_dim, 1)) * sd).astype(np.float32)))
-    f = forward(spec, flatten(tparts), X, np.float32)
+    # teacher outputs and targets in fp64, rounded to fp32 ONCE: an fp32 matmul's last bits follow the BLAS thread count, and
+    # inputs that do must not decide a tolerance (fp64 sums differ by 1e-16 relative at most: invisible after the rounding)
+    f = forward(spec, flatten(tparts).astype(np.float64), X.astype(np.float64), np.float64)
     ng = np.random.Generator(np.random.PCG64(5678))
     if likelihood == LIK_BERNOULLI:
         Y = (ng.random(f.T.shape) < f.T).astype(np.float32)
     else:
-        Y = f.T + 0.1 * ng.standard_normal(f.T.shape).astype(np.float32)
+        Y = f.T + 0.1 * ng.standard_normal(f.T.shape).astype(np.float32).astype(np.float64)
         sd_y = Y.std(0)
         Y = ((Y - Y.mean(0)) / np.where(sd_y > 0, sd_y, 1.0)).astype(np.float32)
     parts = []

@@ -53,6 +53,13 @@ WORKLOADS = {
                 text="BASELINE configs[4] with GaussianDenseLayer priors: 20->100->100->2 Relu/Sigmoid BNN, BernoulliLikelihood, "
                      "500k-row fp32 synthetic classification, L=50 leapfrog + hyper-HMC (L_h=100, dual averaging) per epoch, "
                      "1 chain per GPU"),
+    # not BASELINE configs: two architectures outside the shape-specialised families' first reach, profiled every round
+    # (tools/profile_round.sh) -- wide hidden layers, and the 10-class net of network.add's "any stack" (network.py:173-191)
+    "w300": dict(dims=[8, 300, 300, 1], n=50_000, L=20, lik=nat.LIK_GAUSSIAN, hyper=False, steps=10, warmup=2,
+                 text="8->300->300->1 Relu BNN (Cauchy DenseLayer, GaussianLikelihood), 50k-row fp32 synthetic regression, L=20 leapfrog, 1 chain per GPU"),
+    "mc10": dict(dims=[784, 100, 100, 10], n=12_000, L=20, lik=nat.LIK_BERNOULLI, hyper=False, steps=10, warmup=2, x_scale=1.0 / 28.0,
+                 text="784->100->100->10 Relu/Sigmoid BNN (Cauchy DenseLayer, BernoulliLikelihood over 10 outputs), 12k pixel-like fp32 synthetic rows, "
+                      "L=20 leapfrog, 1 chain per GPU"),
 }
 for _w in WORKLOADS.values():
     _w.setdefault("prior", nat.PRIOR_CAUCHY)
@@ -89,18 +96,19 @@ def synth_problem(dims, n, act=nat.ACT_RELU, prior=nat.PRIOR_CAUCHY, likelihood=
     if x_scale is not None:
         X = (np.abs(X) * np.float32(x_scale)).astype(np.float32)
     tg = np.random.Generator(np.random.PCG64(4321))
-    a = X.T.astype(np.float32)
+    # (fp32 teacher weights, fp64 arithmetic, targets rounded to fp32 once: an fp32 matmul's last bits follow the BLAS thread count)
+    a = X.T.astype(np.float64)
     for (i, o, ac, _) in layers:
         sd = (2.0 / o) ** 0.5
-        W = (tg.standard_normal((o, i)) * sd).astype(np.float32)
-        b = (tg.standard_normal((o, 1)) * sd).astype(np.float32)
-        a = _act(W @ a + b, ac).astype(np.float32)
+        W = (tg.standard_normal((o, i)) * sd).astype(np.float32).astype(np.float64)
+        b = (tg.standard_normal((o, 1)) * sd).astype(np.float32).astype(np.float64)
+        a = _act(W @ a + b, ac)
     f = a
     ng = np.random.Generator(np.random.PCG64(5678))
     if likelihood == nat.LIK_BERNOULLI:
         Y = (ng.random(f.T.shape) < f.T).astype(np.float32)
     else:
-        Y = f.T + 0.1 * ng.standard_normal(f.T.shape).astype(np.float32)
+        Y = f.T + 0.1 * ng.standard_normal(f.T.shape).astype(np.float32).astype(np.float64)
         sd_y = Y.std(0)
         Y = ((Y - Y.mean(0)) / np.where(sd_y > 0, sd_y, 1.0)).astype(np.float32)
     parts = []

@@ -1,0 +1,163 @@
+"""GPU: the PRODUCTION random path end to end against the oracle.  The reference seeds once and lets the chain run
+(tensorBNN/network.py:562, :567-607); here that is `tbnn_hmc_run` / `tbnn_hmc_step` / `tbnn_hyper_step` with NO injected
+draws -- the momentum and the Metropolis uniform come from the device's Philox4x32-10 stream, key (seed, chain_id), counter
+(block, epoch, purpose) -- which is what bench.py times and the only mode a multi-chain handle has.  An oracle chain walks
+beside it on the same stream restated on the CPU (`o.philox_normals`, `o.philox_log_uniform`), carrying its OWN state
+forward:
+
+  * configs[1] at full size (n = 1e5) from the burned-in fixture: 60 epochs of L = 10 issued as ONE `tbnn_hmc_run` call
+    (no host round trip in between) against oracle/c;
+  * a `ChainGroup` (C = 4; chains 1 and 3 are checked) on the narrow, mid-width and tall-fan-in kernel families, with one
+    group `hyper_step` in between, against the fp64 NumPy oracle.
+
+Every Metropolis decision must equal the oracle's unless log u lies within 0.05 of the oracle's log accept ratio (a decision
+that hinges on the last bits of two fp32 sums: the oracle chain then follows the device's decision and says so); the log accept
+ratio within the stated fp32 tolerance 2e-2 + 1e-4 |lar| + 1e-6 |logp|; the accept ratio within 0.02; the states within 1e-4
+of their size at the end.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import c_oracle
+import tbnn_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MARGIN = 0.05
+SEED = 50
+
+
+def lar_tol(lar, logp):
+    return 2e-2 + 1e-4 * abs(lar) + 1e-6 * abs(logp)
+
+
+def layers_of(spec):
+    return [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+
+
+def draws(P, chain_id, epoch, hyper=False):
+    """the device's draws of one transition, restated: momentum (purpose 0 / 2) and log u (purpose 1 / 3)"""
+    pm, pu = (o.PURPOSE_HYPER_MOMENTUM, o.PURPOSE_HYPER_LOGU) if hyper else (o.PURPOSE_MOMENTUM, o.PURPOSE_LOGU)
+    return o.philox_normals(P, SEED, chain_id, epoch, pm), float(o.philox_log_uniform(SEED, chain_id, epoch, pu))
+
+
+class Tally:
+    def __init__(self):
+        self.n = self.agree = self.ambiguous = 0
+        self.dlar, self.acc_g, self.acc_o, self.lars = [], [], [], []
+
+    def add(self, rec, lar_o, lu, logp):
+        """one epoch: the device's record against the oracle's log accept ratio; returns the decision the oracle chain takes"""
+        self.n += 1
+        self.lars.append(lar_o)
+        self.dlar.append(abs(rec["log_accept_ratio"] - lar_o) / lar_tol(lar_o, logp))
+        self.acc_g.append(rec["accept_prob"]); self.acc_o.append(min(1.0, float(np.exp(min(lar_o, 0.0)))))
+        dec_o = lu < lar_o
+        if abs(lu - lar_o) < MARGIN:
+            self.ambiguous += 1
+            return bool(rec["accepted"])
+        self.agree += int(bool(rec["accepted"]) == dec_o)
+        return dec_o
+
+    def check(self, what):
+        mg, mo = float(np.mean(self.acc_g)), float(np.mean(self.acc_o))
+        print(f"{what}: {self.n} epochs on device draws, decisions equal {self.agree}/{self.n - self.ambiguous} ({self.ambiguous} within "
+              f"{MARGIN} of log u), accept ratio HIP {mg:.4f} oracle {mo:.4f}, max |dlar| / tol {max(self.dlar):.3f}, "
+              f"lar range [{min(self.lars):.2f}, {max(self.lars):.2f}]")
+        assert self.agree == self.n - self.ambiguous, (self.agree, self.n, self.ambiguous)
+        assert max(self.dlar) <= 1.0, max(self.dlar)
+        assert abs(mg - mo) <= 0.02, (mg, mo)
+
+
+def test_production_chain_on_device_draws_configs1_full_size(native):
+    """configs[1] (5->50->50->50->1, n = 1e5) on k_fwd_bwd_fast3: tbnn_hmc_run(60 epochs, L = 10), nothing injected"""
+    spec, X, Y, theta, eta = o.synth_problem([5, 50, 50, 50, 1], 100_000)
+    z = np.load(os.path.join(GOLDEN, "c2_burned.npz"))
+    theta, eta, eps = z["theta"].astype(np.float32), z["eta"].astype(np.float32), float(z["eps"])
+    EPOCHS, L, cid = 60, 10, 2
+    ch = native.Chain(layers_of(spec), likelihood=spec.likelihood, seed=SEED, chain_id=cid)
+    assert ch.kernel_name.startswith("fast3<")
+    ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+    recs = ch.hmc_run(eps, L, EPOCHS)                     # the path bench.py times: one call, the device draws
+    final = ch.get_state()
+    ch.close()
+    co = c_oracle.COracle(spec, X, Y)
+    th, t = theta.copy(), Tally()
+    for ep in range(EPOCHS):
+        p0, lu = draws(spec.n_params, cid, ep)
+        q, lar, lp0, _ = co.hmc_propose(th, eta, eps, L, p0)
+        if t.add(recs[ep], lar, lu, lp0):
+            th = q
+    t.check("configs[1] production chain")
+    assert 0.5 <= np.mean(t.acc_o) <= 0.98
+    assert min(r["accepted"] for r in recs) == 0 or min(t.lars) < -0.05       # a chain whose energy error matters
+    err = float(np.abs(final - th).max() / np.abs(th).max())
+    print(f"relative state distance after {EPOCHS} epochs {err:.1e}")
+    assert err <= 1e-4, err
+
+
+GROUPS = {
+    # family: dims, rows, activation, prior, likelihood, eps (mixed decisions after the burn-in below), kernel name
+    "narrow": ([5, 50, 50, 50, 1], 2000, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, 2e-4, "fast3<"),
+    "mid": ([4, 24, 40, 1], 517, o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN, 5e-4, "mid<"),
+    "tall": ([128, 16, 2], 333, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, 1e-3, "tall<"),
+}
+
+
+@pytest.mark.parametrize("family", list(GROUPS))
+def test_chain_group_on_device_draws_vs_oracle(native, family):
+    """tbnn_create_multi: 4 chains behind one handle, chain c on the key (seed, chain_id + c).  60 epochs of burn-in on the
+    device (not compared: they only move the chains to where the energy error matters), then 14 epochs + one group hyper
+    transition + 6 epochs, chains 1 and 3 against fp64 oracle chains started from the burned states"""
+    dims, n, act, prior, lik, eps, kname = GROUPS[family]
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, act, prior, lik)
+    C, c0, L, BURN, E1, E2, EPS_H, L_H = 4, 5, 5, 60, 14, 6, 2e-4, 10
+    rng = np.random.default_rng(12)
+    thetas = (theta[None, :] * (1.0 + 0.05 * rng.standard_normal((C, theta.size)))).astype(np.float32)
+    grp = native.ChainGroup(layers_of(spec), C, likelihood=spec.likelihood, seed=SEED, chain_id=c0, jit=False)
+    assert grp.kernel_name.startswith(kname), grp.kernel_name
+    grp.set_data(X, Y); grp.set_state(thetas); grp.set_hypers(eta)
+    grp.hmc_run(eps, L, BURN)
+    start, eta0 = grp.get_state(), grp.get_hypers()
+    r1 = grp.hmc_run(eps, L, E1)
+    mid_state = grp.get_state()
+    rh = grp.hyper_step(EPS_H, L_H)
+    eta1 = grp.get_hypers()
+    r2 = [grp.hmc_step(eps, L) for _ in range(E2)]                # the per-epoch entry point too: [epoch][chain]
+    final = grp.get_state()
+    grp.close()
+    t = Tally()
+    with np.errstate(all="ignore"):
+        for c in (1, 3):
+            th, et = start[c].astype(np.float64), eta0[c].astype(np.float64)
+            for k in range(E1):
+                ep = BURN + k
+                p0, lu = draws(spec.n_params, c0 + c, ep)
+                ref = o.weight_step(spec, th, et, X, Y, eps, L, p0, lu, np.float64)
+                if t.add(r1[c][k], ref.log_accept_ratio, lu, ref.logp_old):
+                    th = ref.theta_proposed.astype(np.float64)
+            err = float(np.abs(mid_state[c] - th).max() / np.abs(th).max())
+            assert err <= 1e-4, (c, err)
+            # the hyper transition draws on the epoch counter of the weight transition before it, purposes 2 / 3
+            p0h, luh = draws(spec.n_hypers, c0 + c, BURN + E1 - 1, hyper=True)
+            refh = o.hyper_step(spec, et, th, X, Y, EPS_H, L_H, p0h, luh, np.float64)
+            assert abs(rh[c]["log_accept_ratio"] - refh.log_accept_ratio) <= 2e-2 + 1e-3 * abs(refh.log_accept_ratio), (c, rh[c], refh.log_accept_ratio)
+            if abs(luh - refh.log_accept_ratio) >= MARGIN:
+                assert bool(rh[c]["accepted"]) == refh.accepted
+            if rh[c]["accepted"]:
+                et = refh.theta_proposed.astype(np.float64)
+            np.testing.assert_allclose(eta1[c], et, rtol=1e-4, atol=1e-5)
+            for k in range(E2):
+                ep = BURN + E1 + k
+                p0, lu = draws(spec.n_params, c0 + c, ep)
+                ref = o.weight_step(spec, th, et, X, Y, eps, L, p0, lu, np.float64)
+                if t.add(r2[k][c], ref.log_accept_ratio, lu, ref.logp_old):
+                    th = ref.theta_proposed.astype(np.float64)
+            err = float(np.abs(final[c] - th).max() / np.abs(th).max())
+            assert err <= 1e-4, (c, err)
+    t.check(f"chain group [{family}] chains 1, 3")
+    assert max(abs(x) for x in t.lars) > 0.05             # not a test of lar = 0
+    assert np.abs(final[1] - final[3]).max() > 0
