@@ -10,7 +10,9 @@ timed region.  The chain starts from the committed burned-in state tests/golden/
 with the step size recorded there, so the accept ratio is in [0.6, 0.9] whatever --steps / --warmup are.  One
 independent chain per GPU (chain_id = rank), no data-path collective; the RCCL all-gather of the sampled state
 (theta, eta) -- tbnn_gather_samples, the path's only exchange -- runs every --sampling-step epochs inside the timed
-region when N > 1.  value = leapfrog steps of all ranks / max-over-ranks wall time.
+region when N > 1.  value = leapfrog steps of all ranks / max-over-ranks wall time of one timed region of exactly --steps
+epochs; the region is measured --repeats times back to back (default 5, at most --max-region-seconds in all) and the median
+region is reported, every region's time under "timed_regions_ms".
 
 At N = 1 the same invocation also measures BASELINE configs[3], configs[4] (weight transition + hyper transition with
 the reference's dual averaging per epoch) and configs[0], each with its own roofline and cpu_baseline, under
@@ -34,11 +36,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = 157.3
+PEAK_TFLOPS = 157.3          # FP32 MFMA, dense (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0       # HBM3E spec; a float4 copy measures 6.29 TB/s (same guide) -- frac_hbm is quoted against the measured figure
+MEASURED_HBM_GBPS = 6290.0
 CONFIG_KEY = {"c1": "configs[0]", "c2": "configs[1]", "c4": "configs[3]", "c5": "configs[4]",
-              "c5g": "configs[4] with GaussianDenseLayer priors", "mn": "docs example 784-20-20-1"}
+              "c5g": "configs[4] with GaussianDenseLayer priors", "mn": "docs example 784-20-20-1",
+              "w300": "8-300-300-1", "mc10": "784-100-100-10"}
 # CPU sample per workload: (max epochs, leapfrog steps per epoch, wall cap in s) for the all-threads run
-CPU_SAMPLE = {"c1": (20, 100, 10.0), "c2": (20, 50, 30.0), "c4": (1, 3, 30.0), "c5": (1, 20, 30.0), "mn": (4, 50, 15.0)}
+CPU_SAMPLE = {"c1": (20, 100, 10.0), "c2": (20, 50, 30.0), "c4": (1, 3, 30.0), "c5": (1, 20, 30.0), "mn": (4, 50, 15.0),
+              "w300": (1, 5, 15.0), "mc10": (1, 5, 15.0)}
 
 
 def algorithmic_flops(dims, n):
@@ -188,7 +194,13 @@ def committed_profile(name, build_id, profiles_dir=None):
     return out
 
 
-def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
+def roofline_bound(flops, alg_bytes):
+    """which roof the algorithmic work of one pass sits under: MFMA floor flops / 157.3 TF/s against the HBM floor at the measured
+    6.29 TB/s (machine balance 25 FLOP/B)"""
+    return "hbm" if alg_bytes / (MEASURED_HBM_GBPS * 1e9) > flops / (PEAK_TFLOPS * 1e12) else "mfma"
+
+
+def run_workload(name, steps, warmup, args, rank, world, dev, ctx, repeats=1):
     """one workload on this rank's GPU; returns the result dict (rank 0) or None"""
     import numpy as np
     import torch
@@ -209,7 +221,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
         eps_warm = eps = float(burned["eps"])
         state = f"burned-in ({int(burned['epochs'])} epochs, tests/golden/{name}_burned.npz)"
     else:
-        eps_warm, eps = bench_eps(name) if name not in ("c1", "mn") else ((1e-4, 1e-4) if name == "c1" else (1e-3, 1e-3))
+        eps_warm, eps = bench_eps(name) if name in ("c2", "c4", "c5") else ((1e-4, 1e-4) if name == "c1" else (1e-3, 1e-3) if name == "mn" else (1e-6, 1e-6))
         state = "initial state (no burned-in fixture): warm-up at eps_warmup"
     if args.eps is not None:
         eps_warm = eps = args.eps
@@ -301,24 +313,46 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
     # all positions of a trajectory).  Every pair costs the stream a bubble: at every 10th pass (rounds 1-3) the pairs themselves took
     # 1.2 % off the measured rate of configs[1] (19.75 k against 19.98 k leapfrog steps/s)
     ch.set_profiling(int(os.environ.get("TBNN_BENCH_PROFILE_STRIDE", "47")))
-    fence()
-    thr0 = cgroup_throttled_ms()
-    t0 = time.perf_counter()
-    outs = run(steps, eps)
-    dt_own = time.perf_counter() - t0          # this rank's own clock: its last epoch's record has been read back (hmc_run / gather return)
-    if os.environ.get("TBNN_BENCH_FAIL_RANK") == str(rank):      # test hook: a rank that dies mid-run must take the job down, non-zero
-        print(f"[rank {rank}] TBNN_BENCH_FAIL_RANK: exiting with code 3", file=sys.stderr, flush=True)
-        os._exit(3)
-    fence()
-    dt = time.perf_counter() - t0
-    thr1 = cgroup_throttled_ms()
-    throttled = round(thr1 - thr0, 1) if (thr0 is not None and thr1 is not None) else None
+    # The timed region: EXACTLY `steps` epochs between two fences (barrier + device synchronisation), max over ranks.  A region of a
+    # few tens of ms (the driver's --steps 20 is 0.05 s at configs[1]) is at the mercy of one scheduling hiccup, so the region is
+    # measured `repeats` times back to back -- each again exactly `steps` epochs of the free-running chain -- and the MEDIAN region is
+    # the one reported (every region's time is in the full record); regions stop early once `--max-region-seconds` are spent.
+    regions, outs, dt_own = [], [], None
+    throttled = 0.0
+    t_all = time.perf_counter()
+    for rep in range(max(1, repeats)):
+        fence()
+        thr0 = cgroup_throttled_ms()
+        t0 = time.perf_counter()
+        o_r = run(steps, eps)
+        own = time.perf_counter() - t0         # this rank's own clock: its last epoch's record has been read back (hmc_run / gather return)
+        if os.environ.get("TBNN_BENCH_FAIL_RANK") == str(rank):      # test hook: a rank that dies mid-run must take the job down, non-zero
+            print(f"[rank {rank}] TBNN_BENCH_FAIL_RANK: exiting with code 3", file=sys.stderr, flush=True)
+            os._exit(3)
+        fence()
+        dt_r = time.perf_counter() - t0
+        thr1 = cgroup_throttled_ms()
+        if dist_on:
+            t = torch.tensor([dt_r], dtype=torch.float64, device=ctx["cdev"])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_r = float(t.item())
+        regions.append((dt_r, own, o_r, (thr1 - thr0) if (thr0 is not None and thr1 is not None) else None))
+        stop = time.perf_counter() - t_all > args.max_region_seconds
+        if dist_on:                                    # every rank takes the same decision
+            t = torch.tensor([1.0 if stop else 0.0], dtype=torch.float64, device=ctx["cdev"])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            stop = bool(t.item() > 0)
+        if stop:
+            break
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    med = order[(len(order) - 1) // 2]                  # the median region (the lower one of an even count: a region that was measured)
+    dt, dt_own, _, thr = regions[med]
+    outs = [o for r in regions for o in r[2]]           # accept ratio / kernel-time samples: every region's epochs
+    throttled = round(thr, 1) if thr is not None else None
+    region_ms = [round(r[0] * 1e3, 3) for r in regions]
     ranks = None
     if dist_on:
         cdev = ctx["cdev"]
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         # what every rank saw: its own rate (a starved launch thread shows here), the communicator size its collective library
         # reports (ncclCommCount), the gather route it took
         mine = torch.tensor([steps * L / dt_own, float(comm.count()) if comm is not None else -1.0,
@@ -357,16 +391,28 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
     traffic = prof_c["traffic"]
     roofline = None
     if k_us and name != "c1":
-        achieved = flops / (k_us * 1e-6) / 1e12
+        alg_bytes = 4.0 * N_ROWS * (DIMS[0] + DIMS[-1]) + 12.0 * P        # X, Y read once; q, p, g read / written
+        bound = roofline_bound(flops, alg_bytes)
+        tf = flops / (k_us * 1e-6) / 1e12
+        gbps = alg_bytes / (k_us * 1e-6) / 1e9
         rp_us, rp_src = prof_c["kernel_us"], prof_c["source"]
-        roofline = {"bound": "mfma", "kernel": kernel_name, "achieved": round(achieved, 3),
-                    "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS, 4),
-                    "frac_rocprof": round(flops / (rp_us * 1e-6) / 1e12 / PEAK_TFLOPS, 4) if rp_us else None,
+        if bound == "mfma":
+            head = {"bound": "mfma", "kernel": kernel_name, "achieved": round(tf, 3), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / PEAK_TFLOPS, 4),
+                    "frac_rocprof": round(flops / (rp_us * 1e-6) / 1e12 / PEAK_TFLOPS, 4) if rp_us else None}
+        else:                                  # at or under the ridge (docs784: 20.7 FLOP/B against 25): the HBM floor is the longer one
+            head = {"bound": "hbm", "kernel": kernel_name, "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                    "frac_rocprof": round(alg_bytes / (rp_us * 1e-6) / 1e9 / PEAK_HBM_GBPS, 4) if rp_us else None}
+        roofline = dict(head)
+        roofline.update({"frac_mfma": round(tf / PEAK_TFLOPS, 4), "frac_hbm": round(gbps / MEASURED_HBM_GBPS, 4),
+                    "frac_hbm_note": "algorithmic bytes / kernel time / 6.29 TB/s (measured copy rate); frac_mfma: algorithmic FLOP / kernel time / 157.3 TF/s",
                     "rocprof_kernel_us": rp_us, "rocprof_source": rp_src,
                     "profile_build_match": prof_c["match"], "build_id": nat.build_id(), "profiled_build": prof_c["profiled_build"],
-                    "traffic": traffic, "kernel_us": round(k_us, 2), "flop_per_launch": flops,
-                    "hbm_gbps_algorithmic": round((4.0 * N_ROWS * (DIMS[0] + DIMS[-1]) + 12.0 * P) / (k_us * 1e-6) / 1e9, 2),
-                    "end_to_end_frac": round(value / world * flops / 1e12 / PEAK_TFLOPS, 4)}
+                    "traffic": traffic, "kernel_us": round(k_us, 2), "flop_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+                    "hbm_gbps_algorithmic": round(gbps, 2),
+                    "end_to_end_frac": round(value / world * flops / 1e12 / PEAK_TFLOPS, 4) if bound == "mfma"
+                    else round(value / world * alg_bytes / 1e9 / PEAK_HBM_GBPS, 4)})
     elif name == "c1":
         roofline = {"bound": "launch latency (7e5 FLOP per step: SURVEY 8(d) reports steps/s only)", "kernel": kernel_name,
                     "kernel_us": round(k_us, 2) if k_us else None, "frac": None}
@@ -383,6 +429,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx):
                    "kernel": kernel_name, "start_state": state, "sample_gather": gather_kind},
         "accept_ratio": round(acc_prob, 4), "accepted_fraction": round(acc_frac, 4),
         "roofline": roofline, "cpu_baseline": cpu, "cgroup_throttled_ms_in_timed_region": throttled,
+        "timed_regions_ms": region_ms, "timed_region": f"median of {len(region_ms)} regions of exactly {steps} epochs each",
     }
     if ranks is not None:
         line["ranks"] = ranks
@@ -438,7 +485,7 @@ def _short_cpu(c):
 def _short_roof(r):
     if not r:
         return None
-    keep = ("bound", "achieved", "peak", "unit", "frac", "frac_rocprof", "rocprof_source", "profile_build_match", "traffic",
+    keep = ("bound", "achieved", "peak", "unit", "frac", "frac_rocprof", "frac_mfma", "frac_hbm", "rocprof_source", "profile_build_match", "traffic",
             "kernel_us", "end_to_end_frac")          # ("kernel" is config.kernel: not repeated on the short line)
     out = {k: r[k] for k in keep if k in r}
     if out.get("rocprof_source"):
@@ -477,6 +524,8 @@ def compact_line(line):
                 continue
             e = {"value": r["value"], "ms_per_step": round(r["ms_per_step"], 3), "accept": round(r["accept_ratio"], 3)}      # (L = value x ms_per_step / 1000)
             rf = r.get("roofline") or {}
+            if rf.get("bound") == "hbm":
+                e["bound"] = "hbm"
             for k in ("frac", "frac_rocprof", "traffic"):
                 if rf.get(k) is not None and not (k != "frac" and key.endswith("GaussianDenseLayer priors")):      # ([4]g: [4]'s kernel, [4]'s profile)
                     e[k] = rf[k]
@@ -553,12 +602,14 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c4", "c5", "c5g", "mn"],
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c4", "c5", "c5g", "mn", "w300", "mc10"],
                     help="measure this workload alone (default: c2 = BASELINE configs[1], + the others as `secondary` at N = 1)")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--eps", type=float, default=None, help="leapfrog step size (default: fixture value)")
     ap.add_argument("--sampling-step", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of exactly --steps epochs each for the headline workload; the median region is reported")
+    ap.add_argument("--max-region-seconds", type=float, default=20.0, help="no further timed region is started once this much time went into them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--from-initial", action="store_true", help="start from the initial state instead of the burned-in fixture")
@@ -628,7 +679,7 @@ def main():
     wl = WORKLOADS[main_wl]
     steps = args.steps if args.steps is not None else wl["steps"]
     warmup = args.warmup if args.warmup is not None else wl["warmup"]
-    line = run_workload(main_wl, steps, warmup, args, rank, world, dev, ctx)
+    line = run_workload(main_wl, steps, warmup, args, rank, world, dev, ctx, repeats=args.repeats)
     if args.workload is None and world == 1 and not args.no_secondary:
         sec = {}
         for name in ("c4", "c5", "c5g", "c1", "mn"):

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define TBNN_MAX_LAYERS 16
-#define TBNN_ABI_VERSION 1
+#define TBNN_ABI_VERSION 2   /* 2: multi-chain handles (tbnn_create_multi: buffers of set/get_state, hmc_step/run, hyper_step are [chains][...]), tbnn_build_id, tbnn_comm_count, tbnn_hyper_probs_many, tbnn_debug_momentum */
 
 /* activation layer that follows a dense layer
  * (tensorBNN/activationFunctions.py:27-63) */
@@ -150,6 +150,16 @@ int tbnn_hmc_step(tbnn_handle h, float eps, int32_t L, const float* p0, const fl
 /* n_epochs transitions back to back with fixed (eps, L) and no host
  * round-trip in between (adapter bypassed).  outs: n_epochs records. */
 int tbnn_hmc_run(tbnn_handle h, float eps, int32_t L, int32_t n_epochs, tbnn_step_out* outs);
+
+/* Multi-chain handles with EVERY chain at its own step size and leapfrog count -- the reference runs one paramAdapter per chain
+ * (network.py:221-235, :603-607), so C chains of it are C schedules.  eps, L: n_chains values.  The chains advance in lockstep for
+ * max_c L[c] steps; chain c takes its closing half kick at step L[c] and is skipped from then on (its blocks of the fused pass exit
+ * at once), so chain c is bit for bit tbnn_create(.., chain_id + c) driven with (eps[c], L[c]).  out[c].n_leapfrog = L[c].
+ * tbnn_hmc_run_each: n_epochs such transitions back to back, outs[chain][epoch].  (On a one-chain handle: arrays of one.) */
+int tbnn_hmc_step_each(tbnn_handle h, const float* eps, const int32_t* L, tbnn_step_out* out);
+int tbnn_hmc_run_each(tbnn_handle h, const float* eps, const int32_t* L, int32_t n_epochs, tbnn_step_out* outs);
+/* the hyper transition of every chain at its own step size eps_h[c] (one dual averaging per chain, network.py:457-469) */
+int tbnn_hyper_step_each(tbnn_handle h, const float* eps_h, int32_t L_h, tbnn_step_out* out);
 
 /* One hyper-parameter transition = the HMC part of InnerStepHyper
  * (network.py:414-456); dual averaging (:457-469) stays with the caller. */

@@ -22,6 +22,7 @@ PRIOR_CAUCHY, PRIOR_GAUSSIAN = 0, 1
 LIK_GAUSSIAN, LIK_FIXED_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST = 0, 1, 2
 MAX_LAYERS = 16
+ABI_VERSION = 2          # TBNN_ABI_VERSION of include/tbnn.h
 
 
 class TbnnError(RuntimeError):
@@ -73,6 +74,9 @@ SYMBOLS = [
     ("tbnn_forward", C.c_int, [_H, _fp, _fp, C.c_int64, _fp]),
     ("tbnn_hmc_step", C.c_int, [_H, C.c_float, C.c_int32, _fp, _fp, C.POINTER(StepOut), _dp]),
     ("tbnn_hmc_run", C.c_int, [_H, C.c_float, C.c_int32, C.c_int32, C.POINTER(StepOut)]),
+    ("tbnn_hmc_step_each", C.c_int, [_H, _fp, C.POINTER(C.c_int32), C.POINTER(StepOut)]),
+    ("tbnn_hmc_run_each", C.c_int, [_H, _fp, C.POINTER(C.c_int32), C.c_int32, C.POINTER(StepOut)]),
+    ("tbnn_hyper_step_each", C.c_int, [_H, _fp, C.c_int32, C.POINTER(StepOut)]),
     ("tbnn_hyper_step", C.c_int, [_H, C.c_float, C.c_int32, _fp, _fp, C.POINTER(StepOut)]),
     ("tbnn_hyper_logp_grad", C.c_int, [_H, _fp, _dp, _fp]),
     ("tbnn_export_sample_device", C.c_int, [_H, C.c_void_p]),
@@ -109,6 +113,15 @@ def _load():
             f"{LIB_PATH} not found: build it with `python -m tensorbnn_amd.build` "
             "(hipcc --offload-arch=gfx950).  tensorbnn_amd has no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    # the ABI version first: a stale library (built before the header grew) must say so, not die on a missing symbol
+    try:
+        lib.tbnn_abi_version.restype = C.c_int
+        have = lib.tbnn_abi_version()
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} implements C-ABI version {have}, this binding needs {ABI_VERSION} (include/tbnn.h): "
+                          "rebuild it with `python -m tensorbnn_amd.build --force`")
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
@@ -472,6 +485,32 @@ class ChainGroup:
 
     def set_epoch(self, epoch: int):
         _check(lib.tbnn_set_epoch(self._h, int(epoch)))
+
+    # ---- every chain at its own (eps, L) / its own hyper step size: one adapter and one dual averaging per chain, as C runs of
+    # the reference would have (network.py:221-235, :603-607, :457-469)
+    def _each(self, eps, L):
+        e = np.ascontiguousarray(np.broadcast_to(np.asarray(eps, dtype=np.float32), (self.C,)))
+        l = np.ascontiguousarray(np.broadcast_to(np.asarray(L, dtype=np.int32), (self.C,)))
+        return e, l
+
+    def hmc_step_each(self, eps, L):
+        """eps, L: one value per chain; chain c == the solo chain chain_id + c driven with (eps[c], L[c])"""
+        e, l = self._each(eps, L)
+        outs = (StepOut * self.C)()
+        _check(lib.tbnn_hmc_step_each(self._h, _p(e), l.ctypes.data_as(C.POINTER(C.c_int32)), outs))
+        return [o.as_dict() for o in outs]
+
+    def hmc_run_each(self, eps, L, n_epochs: int):
+        e, l = self._each(eps, L)
+        outs = (StepOut * (self.C * n_epochs))()
+        _check(lib.tbnn_hmc_run_each(self._h, _p(e), l.ctypes.data_as(C.POINTER(C.c_int32)), int(n_epochs), outs))
+        return [[outs[c * n_epochs + k].as_dict() for k in range(n_epochs)] for c in range(self.C)]
+
+    def hyper_step_each(self, eps_h, L_h: int):
+        e = np.ascontiguousarray(np.broadcast_to(np.asarray(eps_h, dtype=np.float32), (self.C,)))
+        outs = (StepOut * self.C)()
+        _check(lib.tbnn_hyper_step_each(self._h, _p(e), int(L_h), outs))
+        return [o.as_dict() for o in outs]
 
 
 COMM_ID_BYTES = 128

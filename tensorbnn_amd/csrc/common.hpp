@@ -59,7 +59,13 @@ __device__ __forceinline__ void store16(float* ptr, const tb_f32x4& v) {
 // Several chains in one launch (round 4): a handle created with tbnn_create_multi keeps its C chains' buffers as [C][...]
 // arrays and launches the per-chain kernels with gridDim.y = C; blockIdx.y picks the chain.  Strides the kernels cannot derive
 // from NetDev travel in this struct (all zero for one chain: blockIdx.y is 0 then anyway).
-struct ChainStride { long img, eta, slab; };
+// Per-chain step control of a multi-chain handle whose chains run at their own (eps, L) (tbnn_hmc_step_each; the reference runs one
+// adapter per chain, network.py:221-235, :603-607): the chains advance in lockstep for max_c L_c leapfrog steps; chain c takes its
+// closing half kick at step L_c and is skipped afterwards -- k_update returns for it and the blocks of the fused pass exit at once, so
+// its gradient slab and statistic stay those of ITS last step.
+struct StepCtl { float eps; int L; };
+__device__ __forceinline__ bool chain_done(const StepCtl* __restrict__ ctl, int t, int chain) { return ctl && t > ctl[chain].L; }
+struct ChainStride { long img, eta, slab; const StepCtl* ctl; int t; };
 
 // Per-chain scalar record kept on the device (doubles: energies are summed
 // and differenced in fp64 -- strictly more accurate than the reference's fp32).

@@ -6,7 +6,7 @@
 #include "common.hpp"
 #include "wide_api.hpp"
 
-#define TBNN_JIT_ABI 4
+#define TBNN_JIT_ABI 5      // 5: ChainStride carries the per-chain step control
 enum { TBNN_FAMILY_NARROW = 1, TBNN_FAMILY_WIDE = 2 };
 
 struct FusedOps {

@@ -719,6 +719,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 {
     using C = FastCfg<S>;
     // gridDim.y = chains of a multi-chain handle (tbnn_create_multi): this workgroup's chain
+    if (chain_done(cs.ctl, cs.t, blockIdx.y)) return;           // a chain past its own L (per-chain step control)
     qimg += (size_t)blockIdx.y * cs.img; eta += (size_t)blockIdx.y * cs.eta; slabs += (size_t)blockIdx.y * cs.slab; pstat += (size_t)blockIdx.y * PSTAT_CAP;
 #define TB_STAMP(i) do { if (stamps && threadIdx.x == 0 && blockIdx.x == 0) { stamps[i] = wall_clock64(); stamps[8 + i] = clock64(); } } while (0)
     TB_STAMP(0);
@@ -928,7 +929,7 @@ static inline int fast_grid(int, long n) {
 // qimg: the padded weight image of the position to evaluate
 static inline int fast_launch(int id, int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
                               const float* X, const float* Y, long n, float* slabs, int pitch, double* pstat,
-                              unsigned long long* stamps = nullptr, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0}) {
+                              unsigned long long* stamps = nullptr, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0, nullptr, 0}) {
     switch (id) {
         case 0: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC2>, dim3(grid, nchains), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps, cs); break;
         case 1: hipLaunchKernelGGL(k_fwd_bwd_fast<ShapeC1>, dim3(grid, nchains), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps, cs); break;

@@ -231,7 +231,8 @@ struct Fwd3 {
         sfor3<0, KG>([&](auto kt_) __attribute__((always_inline)) {
             constexpr int kt = decltype(kt_)::value;
             constexpr int ns = l == 0 ? C::KS0 : C::ksteps(K, kt);
-            f32x4 A4[MTd], F4 = (MT == 0 && l > 0) ? P0.F[kt] : Fn;
+            f32x4 A4[MTd], F4;
+            if constexpr (MT == 0 && l > 0) F4 = P0.F[kt]; else F4 = Fn;       // (constexpr: the other arm's subscript is out of range)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) A4[mt] = An[mt];
             // reads that ride in this group: the next group's operands (MT tiles + fringe weights), then the preload
@@ -251,7 +252,8 @@ struct Fwd3 {
                 constexpr int s = decltype(s_)::value;
                 sfor3<0, MT + (M4F ? 1 : 0)>([&](auto m_) __attribute__((always_inline)) {
                     constexpr int m = decltype(m_)::value, q = s * (MT + (M4F ? 1 : 0)) + m;
-                    const float bop = l == 0 ? T.x0[s] : T.a[C::aroff(l > 0 ? l - 1 : 0) + kt][s];
+                    float bop;
+                    if constexpr (l == 0) bop = T.x0[s]; else bop = T.a[C::aroff(l > 0 ? l - 1 : 0) + kt][s];
                     if constexpr (m < MT) acc[m] = mfma16(A4[m][s], bop, acc[m]);
                     else pa[kt % NA] = mfma4(F4[s], bop, pa[kt % NA]);
                     if constexpr (q < NLD) { issue(std::integral_constant<int, q>{}); __builtin_amdgcn_sched_barrier(0); }
@@ -1165,6 +1167,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 {
     using C = F3Cfg<S>;
     // gridDim.y = chains of a multi-chain handle (tbnn_create_multi): this workgroup's chain
+    if (chain_done(cs.ctl, cs.t, blockIdx.y)) return;           // a chain past its own L (per-chain step control)
     qimg += (size_t)blockIdx.y * cs.img; eta += (size_t)blockIdx.y * cs.eta; slabs += (size_t)blockIdx.y * cs.slab; pstat += (size_t)blockIdx.y * PSTAT_CAP;
     static_assert(C::VL && C::NF(C::NL - 1) == C::out(C::NL - 1) && C::MTF(C::NL - 1) == 0, "fast3: last layer must be all-fringe");
     using CO = Coop3<S>;
@@ -1475,7 +1478,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 static inline bool fast3_available(int id) { return id == 0 || id == 1 || id == 2; }
 static inline int fast3_launch(int id, int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta,
                                const float* X, const float* Y, long n, float* slabs, int pitch, double* pstat,
-                               unsigned long long* stamps = nullptr, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0}) {
+                               unsigned long long* stamps = nullptr, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0, nullptr, 0}) {
     switch (id) {
         case 0: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeC2>, dim3(grid, nchains), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps, cs); break;
         case 1: hipLaunchKernelGGL(k_fwd_bwd_fast3<ShapeC1>, dim3(grid, nchains), dim3(FAST_THREADS), 0, st, nd, qimg, eta, X, Y, n, slabs, pitch, pstat, stamps, cs); break;

@@ -16,8 +16,19 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     const float* __restrict__ slabs, int nslab, int pitch,
     const float* __restrict__ q_cur, const float* __restrict__ g_cur,
     float* __restrict__ q, float* __restrict__ p, float* __restrict__ g,
-    const int* __restrict__ imgmap, float* __restrict__ qimg, float* __restrict__ gd = nullptr, int img_floats = 0)
+    const int* __restrict__ imgmap, float* __restrict__ qimg, float* __restrict__ gd = nullptr, int img_floats = 0,
+    // per-chain step control (tbnn_hmc_step_each): chain blockIdx.y integrates with ITS eps for ITS L steps; t = 0: the opening half
+    // kick + drift, t = 1 .. max L: the step index.  (mode UPD_GRAD_ONLY -- the bootstrap evaluation -- is the same for every chain)
+    const StepCtl* __restrict__ ctl = nullptr, int t = 0)
 {
+    if (ctl && mode != UPD_GRAD_ONLY) {
+        const StepCtl me = ctl[blockIdx.y];
+        eps = me.eps;
+        if (t == 0) mode = UPD_FIRST;
+        else if (t < me.L) mode = UPD_MID;
+        else if (t == me.L) mode = UPD_LAST;
+        else return;                                   // this chain's trajectory is complete
+    }
     // gridDim.y = chains of a multi-chain handle: [C][P] state arrays, [C][H] hypers, [C][nslab][pitch] slabs, [C][img_floats] images
     if (blockIdx.y) {
         const size_t c = blockIdx.y, cp = c * (size_t)nd.P;
@@ -205,10 +216,13 @@ __global__ __launch_bounds__(1024) void k_energy(
     // EN_NEW with commit_out: the transition's end in this one launch -- the record for the host (k_commit_scal) and, when
     // accepted, cur <- proposal (k_commit: q, g, gd); two launches fewer per transition
     Scal* __restrict__ commit_out = nullptr, const float* __restrict__ g = nullptr, float* q_cur_w = nullptr,
-    float* __restrict__ g_cur = nullptr, const float* __restrict__ gd = nullptr, float* __restrict__ gd_cur = nullptr)
+    float* __restrict__ g_cur = nullptr, const float* __restrict__ gd = nullptr, float* __restrict__ gd_cur = nullptr,
+    // multi-chain EN_REFRESH after a hyper transition: chain blockIdx.y runs only when ITS hyper proposal was accepted
+    const Scal* __restrict__ only_if_accepted = nullptr)
 {
     __shared__ double red[16];
     __shared__ int s_acc;
+    if (only_if_accepted && !only_if_accepted[blockIdx.y].accepted) return;
     // gridDim.y = chains of a multi-chain handle (no trace there: trace_slot is null)
     if (blockIdx.y) {
         const size_t c = blockIdx.y, cp = c * (size_t)nd.P;
@@ -276,9 +290,10 @@ __global__ __launch_bounds__(256) void k_commit(
     int P, const Scal* __restrict__ sc, const float* __restrict__ q, const float* __restrict__ g,
     float* __restrict__ q_cur, float* __restrict__ g_cur, const float* __restrict__ gd, float* __restrict__ gd_cur)
 {
-    if (!sc->accepted) return;
+    const size_t c = blockIdx.y, cp = c * (size_t)P;               // gridDim.y = chains of a multi-chain handle
+    if (!sc[c].accepted) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < P) { q_cur[j] = q[j]; g_cur[j] = g[j]; gd_cur[j] = gd[j]; }
+    if (j < P) { q_cur[cp + j] = q[cp + j]; g_cur[cp + j] = g[cp + j]; gd_cur[cp + j] = gd[cp + j]; }
 }
 
 // After an ACCEPTED hyper transition (-> eta): the prediction does not depend on eta, so the data-term gradient at the
@@ -287,8 +302,15 @@ __global__ __launch_bounds__(256) void k_commit(
 // the sigma-free data term k_update stored: it is only READ here, so nothing compounds over repeated hyper steps.
 __global__ __launch_bounds__(256) void k_refresh_grad_after_hyper(
     NetDev nd, const float* __restrict__ eta, const float* __restrict__ q_cur,
-    const float* __restrict__ gd_cur, float* __restrict__ g_cur)
+    const float* __restrict__ gd_cur, float* __restrict__ g_cur, const Scal* __restrict__ hyper_rec = nullptr)
 {
+    // gridDim.y = chains of a multi-chain handle; hyper_rec: the chains' hyper-transition records -- a chain whose proposal was
+    // rejected keeps its cached gradient bit for bit
+    if (blockIdx.y) {
+        const size_t c = blockIdx.y, cp = c * (size_t)nd.P;
+        eta += c * nd.H; q_cur += cp; gd_cur += cp; g_cur += cp;
+    }
+    if (hyper_rec && !hyper_rec[blockIdx.y].accepted) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nd.P) return;
     const float sn = lik_sigma(nd, eta);
@@ -299,7 +321,8 @@ __global__ __launch_bounds__(256) void k_refresh_grad_after_hyper(
 }
 // copies the record for the host, then rolls cur <- new when accepted
 __global__ void k_commit_scal(Scal* __restrict__ sc, Scal* __restrict__ host_copy) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    sc += blockIdx.x; host_copy += blockIdx.x;                     // gridDim.x = chains
     *host_copy = *sc;
     if (sc->accepted) { sc->stat_cur = sc->stat_new; sc->prior_cur = sc->prior_new; sc->logp_cur = sc->logp_new; }
 }

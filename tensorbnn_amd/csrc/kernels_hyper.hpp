@@ -230,8 +230,10 @@ __device__ __forceinline__ void hyper_owned(const NetDev& nd, int t, int& j0, in
 __global__ __launch_bounds__(HYP_THREADS) void k_hyper(
     NetDev nd, int mode, float eps, int L, float* __restrict__ eta, const float* __restrict__ q, long n,
     const float* __restrict__ p0_inj, const float* __restrict__ logu_inj, uint32_t epoch, uint32_t key0, uint32_t key1,
-    const Scal* __restrict__ sc, float* __restrict__ ws, Scal* __restrict__ out, uint32_t seed_hi = 0)
+    const Scal* __restrict__ sc, float* __restrict__ ws, Scal* __restrict__ out, uint32_t seed_hi = 0,
+    const float* __restrict__ eps_each = nullptr)          // per-chain step sizes (tbnn_hyper_step_each: one dual averaging per chain)
 {
+    if (eps_each) eps = eps_each[blockIdx.x];
     // gridDim.x = chains of a multi-chain handle (one workgroup runs one chain's whole transition): chain c's [H] hypers, [P] weights,
     // record, work space, and its Philox key (seed, chain0 + c) -- key1 = chain_id ^ seed_hi
     if (blockIdx.x) {

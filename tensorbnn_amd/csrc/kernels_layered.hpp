@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
             if (kg < k1) mmk(A0, B0);
         };
         if (SK) {
-            // (underfilled, latency-bound: eight k-groups of loads in flight per wave rather than two)
-#pragma unroll 8
+            // (underfilled, latency-bound.  An `unroll 8` here -- eight k-groups of loads in flight -- is refused by the optimizer: the
+            // operand loads carry scheduling fences; the loop runs as written)
             for (int kg = k_lo; kg < k_hi; ++kg) { f32x4 A[LAY_TB], B[RB]; ldk(A, B, kg); mmk(A, B); }
             // partial tiles -> LDS; wave w finishes the (r, t) pairs with (r * LAY_TB + t) % 4 == w, summing the waves in fixed order
 #pragma unroll

@@ -170,7 +170,10 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
 {
     using C = MidCfg<S>;
     // gridDim.y: networks of an ensemble (FWD) or chains of a multi-chain handle (tbnn_create_multi; cs.img == img_stride then)
-    if constexpr (!FWD) { eta += (size_t)blockIdx.y * cs.eta; slabs += (size_t)blockIdx.y * cs.slab; pstat += (size_t)blockIdx.y * PSTAT_CAP; }
+    if constexpr (!FWD) {
+        if (chain_done(cs.ctl, cs.t, blockIdx.y)) return;       // a chain past its own L (per-chain step control)
+        eta += (size_t)blockIdx.y * cs.eta; slabs += (size_t)blockIdx.y * cs.slab; pstat += (size_t)blockIdx.y * PSTAT_CAP;
+    }
     // the opaque packed instructions (pkfma*: no hazard handling by the compiler) may read hidden activations only when those
     // come out of a plain VALU instruction: relu (v_max), tanh / elu (a select).  A raw MFMA result (no activation) or a
     // transcendental result (sigmoid: v_rcp, exp: v_exp) would need wait states nobody inserts
@@ -695,7 +698,7 @@ static inline int mid_grid(long n) {
 }
 template <class S>
 static inline int mid_launch_t(int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta, const float* X,
-                               const float* Y, long n, float* slabs, int pitch, double* pstat, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0}) {
+                               const float* Y, long n, float* slabs, int pitch, double* pstat, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0, nullptr, 0}) {
     hipLaunchKernelGGL((k_fwd_bwd_mid<S, false>), dim3(grid, nchains), dim3(MID_THREADS), 0, st, nd, qimg, cs.img, eta, X, Y, n, slabs, pitch, pstat,
                        (float*)nullptr, 0L, cs);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -706,6 +709,6 @@ static inline int mid_forward_t(int gx, int nets, hipStream_t st, const float* q
                                 float* fouts, long out_stride) {
     NetDev nd{};
     hipLaunchKernelGGL((k_fwd_bwd_mid<S, true>), dim3(gx, nets), dim3(MID_THREADS), 0, st, nd, qimgs, img_stride, (const float*)nullptr, X,
-                       (const float*)nullptr, n, (float*)nullptr, 0, (double*)nullptr, fouts, out_stride, ChainStride{0, 0, 0});
+                       (const float*)nullptr, n, (float*)nullptr, 0, (double*)nullptr, fouts, out_stride, ChainStride{0, 0, 0, nullptr, 0});
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -28,6 +28,7 @@
 // BNN_functions.py:23-32; reverse mode SURVEY A12; the path: network.py:394-408.
 #pragma once
 #include "kernels_mid.hpp"
+#include <atomic>
 
 // diagnostic build (-DTBNN_TILE_STAMPS, tools/experiments/tall_stamps.py): shader-clock stamps of workgroup 0 / wave 0 along the launch
 #ifdef TBNN_TILE_STAMPS
@@ -43,8 +44,14 @@
 // b ~ 5.8 us incl. the two barriers (784 -> 20 -> 20 -> 1) a launch over `ntiles` tiles costs rounds(g) x (g a + b), rounds(g) = ceil(ceil(ntiles / g) / 256
 // workgroups).  Big groups share the narrow stretch out best (3.65 us per tile at g = 4 against 5.0 at g = 1), small ones fill the
 // chip at few rows.  The same function sizes the grid and picks the instantiation.
+static inline std::atomic<int>& tall_forced_g() { static std::atomic<int> g{0}; return g; }
+static inline void tall_read_forced_g() { const char* e = getenv("TBNN_TALL_G"); tall_forced_g().store(e ? atoi(e) : 0, std::memory_order_relaxed); }
 static inline int tall_group_tiles(long ntiles, int gmax) {
-    if (const char* e = getenv("TBNN_TALL_G")) { const int g = atoi(e); if (g >= 1 && g <= gmax) return g; }       // A/B runs
+    // A/B runs: TBNN_TALL_G.  The environment is read where the grid is sized (tall_grid, at tbnn_set_data) and remembered; a launch
+    // -- once per leapfrog step on the host's hot path -- takes the remembered value, so it calls no getenv and agrees with the grid of
+    // the most recent set_data (a diagnostic knob: whatever the pairing, the group loop strides over the grid and stays correct)
+    const int forced = tall_forced_g().load(std::memory_order_relaxed);
+    if (forced >= 1 && forced <= gmax) return forced;
     int best = 1; long best_cost = 0;
     for (int g = 1; g <= gmax; g = g < 4 ? g + 1 : 2 * g) {
         const long groups = (ntiles + g - 1) / g, rounds = (groups + 255) / 256;
@@ -174,7 +181,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 {
     using C = TallCfg<S, NW>;
     // gridDim.y: networks of an ensemble (FWD) or chains of a multi-chain handle (tbnn_create_multi; cs.img == img_stride then)
-    if constexpr (!FWD) { eta += (size_t)blockIdx.y * cs.eta; slabs += (size_t)blockIdx.y * cs.slab; pstat += (size_t)blockIdx.y * PSTAT_CAP; }
+    if constexpr (!FWD) {
+        if (chain_done(cs.ctl, cs.t, blockIdx.y)) return;       // a chain past its own L (per-chain step control)
+        eta += (size_t)blockIdx.y * cs.eta; slabs += (size_t)blockIdx.y * cs.slab; pstat += (size_t)blockIdx.y * PSTAT_CAP;
+    }
     static_assert(C::LDS_OK, "LDS budget");
     constexpr int TALL_WAVES = NW, TALL_THREADS = 64 * NW;
     constexpr bool ACC_A = true;       // accumulators pinned to AccVGPRs by asm MFMAs (as in kernels_mid.hpp)
@@ -722,13 +732,14 @@ static void tall_image_map(int* map) {
 template <class S>
 static inline int tall_grid(long n) {
     const long ntiles = (n + 15) / 16;
+    tall_read_forced_g();
     const int g = tall_group_tiles(ntiles, TallCfg<S, TallPick<S>::NW>::GMAX);
     const long ngroups = (ntiles + g - 1) / g, rounds = (ngroups + 255) / 256;
     return (int)((ngroups + rounds - 1) / rounds);
 }
 template <class S>
 static inline int tall_launch_t(int grid, hipStream_t st, const NetDev& nd, const float* qimg, const float* eta, const float* X,
-                                const float* Y, long n, float* slabs, int pitch, double* pstat, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0}) {
+                                const float* Y, long n, float* slabs, int pitch, double* pstat, int nchains = 1, ChainStride cs = ChainStride{0, 0, 0, nullptr, 0}) {
     constexpr int NW = TallPick<S>::NW;
 #define TALL_LAUNCH(GG) hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, false, GG>), dim3(grid, nchains), dim3(64 * NW), 0, st, nd, qimg, cs.img, eta, X, Y, n, \
                                            slabs, pitch, pstat, (float*)nullptr, 0L, cs)
@@ -751,6 +762,6 @@ static inline int tall_forward_t(int gx, int nets, hipStream_t st, const float* 
     constexpr int NW = TallPick<S>::NW;
     // (forward only: groups of four -- the caller's grid is one workgroup per four row tiles, capped for ensembles: narrow_forward)
     hipLaunchKernelGGL((k_fwd_bwd_tall<S, NW, true, 4>), dim3(gx, nets), dim3(64 * NW), 0, st, nd, qimgs, img_stride, (const float*)nullptr, X,
-                       (const float*)nullptr, n, (float*)nullptr, 0, (double*)nullptr, fouts, out_stride, ChainStride{0, 0, 0});
+                       (const float*)nullptr, n, (float*)nullptr, 0, (double*)nullptr, fouts, out_stride, ChainStride{0, 0, 0, nullptr, 0});
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -95,6 +95,8 @@ struct tbnn_ctx {
     std::vector<hipEvent_t> pev; size_t pev_used = 0;   // pooled events: created once, re-used after every drain (no allocator in the timed loop)
     // hyper workspace
     float* hyp_ws = nullptr;
+    // per-chain step control (tbnn_hmc_step_each / tbnn_hyper_step_each): [C] on the device, staged through pinned memory
+    StepCtl* ctl = nullptr; StepCtl* ctl_host = nullptr; float* epsh = nullptr; float* epsh_host = nullptr;
     bool merge_ends = true;                // TBNN_MERGE_ENDS (read at tbnn_create): decision + record + commit in one k_energy launch
 };
 
@@ -224,6 +226,10 @@ extern "C" int tbnn_destroy(tbnn_handle h) {
     if (h->d_recs) hipFree(h->d_recs);
     if (h->h_recs) hipHostFree(h->h_recs);
     if (h->sc_host) hipHostFree(h->sc_host);
+    if (h->ctl) hipFree(h->ctl);
+    if (h->ctl_host) hipHostFree(h->ctl_host);
+    if (h->epsh) hipFree(h->epsh);
+    if (h->epsh_host) hipHostFree(h->epsh_host);
     if (h->pin) hipHostFree(h->pin);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -242,6 +248,12 @@ extern "C" int tbnn_create(const tbnn_net_desc* desc, int device, uint64_t seed,
 // tbnn_create(..., chain_id + c) would be, and the per-chain kernels of all of them run as ONE launch with gridDim.y = n_chains.
 extern "C" int tbnn_create_multi(const tbnn_net_desc* desc, int device, uint64_t seed, uint32_t chain_id, int32_t n_chains, tbnn_handle* out) {
     if (n_chains < 1 || n_chains > 1024) return fail(-1, "n_chains must be in [1, 1024]");
+    {   // element counts of the [chains][P] arrays are ints in the copy / commit kernels: refuse what would not fit
+        NetDev nd;
+        int rc = build_netdev(desc, nd);
+        if (rc) return rc;
+        if ((long long)n_chains * (long long)nd.P > 0x7FFFFFFFLL) return fail(-1, "n_chains x parameter count exceeds 2^31 - 1");
+    }
     return create_impl(desc, device, seed, chain_id, n_chains, out);
 }
 extern "C" int tbnn_chain_count(tbnn_handle h) { NEED(h); return h->C; }
@@ -289,6 +301,8 @@ static int create_impl(const tbnn_net_desc* desc, int device, uint64_t seed, uin
     HIPB(hipMemset(h->q_cur, 0, PB));
     HIPB(hipEventCreate(&h->ev0)); HIPB(hipEventCreate(&h->ev1));
     HIPB(hipMalloc(&h->hyp_ws, NC * hyper_ws_bytes(nd)));
+    HIPB(hipMalloc(&h->ctl, NC * sizeof(StepCtl))); HIPB(hipHostMalloc(&h->ctl_host, NC * sizeof(StepCtl)));
+    HIPB(hipMalloc(&h->epsh, NC * sizeof(float))); HIPB(hipHostMalloc(&h->epsh_host, NC * sizeof(float)));
     std::vector<float> eta1, eta; default_eta(nd, eta1);
     for (size_t c = 0; c < NC; ++c) eta.insert(eta.end(), eta1.begin(), eta1.end());
     HIPB(hipMemcpy(h->eta, eta.data(), eta.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -651,7 +665,7 @@ static inline int grad_nslab(const tbnn_ctx* h) { return h->shard ? 1 : h->nslab
 // ---- launch helpers (all on h->stream, no sync) ----
 // q == h->q: the leapfrog position, whose padded image h->qimg is maintained by k_update;
 // any other q gets its image built here (h->qimg_cur).
-static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
+static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta, const StepCtl* ctl = nullptr, int t = 0) {
     const float* img = nullptr;
     const int C = h->C;
     const long imgS = h->img_floats, slabS = (long)h->nslab * h->pitch;
@@ -674,14 +688,17 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
     // the one-slab-per-workgroup families take all chains of a multi-chain handle in ONE launch (gridDim.y = chain); the others
     // (two-kernel wide path, layered family, thread-per-row kernel: not what small problems run on) chain by chain through the
     // same activation store
-    const ChainStride cs = {imgS, (long)h->nd.H, slabS};
+    const ChainStride cs = {imgS, (long)h->nd.H, slabS, ctl, t};
+    // (the chain-by-chain families skip a chain past its own L on the host: ctl_host mirrors ctl)
+    auto done = [&](int c) { return ctl != nullptr && t > h->ctl_host[c].L; };
     if (h->lay) {
         for (int c = 0; c < C; ++c)
-            if (lay_launch(h->nd, h->lplan, h->stream, img + c * imgS, eta + (size_t)c * h->nd.H, h->dY, h->n, h->lstore, h->slabs + c * slabS, h->pitch,
+            if (!done(c) && lay_launch(h->nd, h->lplan, h->stream, img + c * imgS, eta + (size_t)c * h->nd.H, h->dY, h->n, h->lstore, h->slabs + c * slabS, h->pitch,
                            h->pstat + (size_t)c * PSTAT_CAP))
                 return fail(-2, "layered kernel launch failed");
     } else if (h->wide_id >= 0) {
         for (int c = 0; c < C; ++c) {
+            if (done(c)) continue;
             const float* ic = img + c * imgS; const float* ec = eta + (size_t)c * h->nd.H;
             double* pc = h->pstat + (size_t)c * PSTAT_CAP; float* sl = h->slabs + c * slabS;
             const int rc = h->jit ? h->jit->wlaunch(&h->wplan, h->stream, &h->nd, ic, ec, h->dX, h->dY, h->n, h->wstore, h->wslabA, h->wslabB, pc, sl)
@@ -700,7 +717,7 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
         if (rc) return fail(-2, "fast kernel launch failed");
     } else {
         for (int c = 0; c < C; ++c)
-            hipLaunchKernelGGL(k_fwd_bwd_generic, dim3(h->grid), dim3(GEN_RB), 0, h->stream, h->nd, q + (size_t)c * h->nd.P, eta + (size_t)c * h->nd.H, h->dX,
+            if (!done(c)) hipLaunchKernelGGL(k_fwd_bwd_generic, dim3(h->grid), dim3(GEN_RB), 0, h->stream, h->nd, q + (size_t)c * h->nd.P, eta + (size_t)c * h->nd.H, h->dX,
                                h->dY, h->n, h->scratch, h->scratchPerWG, h->slabs + c * slabS, h->pitch, h->pstat + (size_t)c * PSTAT_CAP);
     }
     if (h->shard) {
@@ -722,13 +739,13 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta) {
     HIPCHK(hipGetLastError());
     return 0;
 }
-static void launch_update(tbnn_ctx* h, int mode, float eps, const float* eta, float* q, float* g) {
+static void launch_update(tbnn_ctx* h, int mode, float eps, const float* eta, float* q, float* g, const StepCtl* ctl = nullptr, int t = 0) {
     const int gx = (h->pitch / 4 + UPD_COLS - 1) / UPD_COLS;
     const bool img = h->kernel == TBNN_KERNEL_FAST && q == h->q;
     // the data-term gradient goes with its state: the proposal's (h->gd) or, for the bootstrap evaluation, the current one's
     float* gd = g == h->g_cur ? h->gd_cur : (g == h->g ? h->gd : nullptr);
     hipLaunchKernelGGL(k_update, dim3(gx, h->C), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, h->nd, mode, eps, eta, grad_slabs(h), grad_nslab(h),
-                       h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg, gd, h->img_floats);
+                       h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg, gd, h->img_floats, ctl, t);
     if (img && (mode == UPD_FIRST || mode == UPD_MID)) h->q_img_valid = true;
 }
 static void launch_energy(tbnn_ctx* h, int which, const float* eta, const float* q, double* slot) {
@@ -1037,8 +1054,9 @@ extern "C" int tbnn_metrics(tbnn_handle h, int which, const float* theta, float 
 }
 
 // enqueue one transition (no sync).  trace: device array of L+1 doubles or null.
+// ctl (device, mirrored in h->ctl_host) != null: every chain at its own (eps, L) -- L is then max_c L_c and eps unused
 static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, const float* d_logu, double* d_trace,
-                              Scal* d_out) {
+                              Scal* d_out, const StepCtl* ctl = nullptr) {
     const NetDev& nd = h->nd;
     // logp0 of the trace: a fresh bootstrap evaluation writes it; a cached one (cur_valid) is copied from the chain's
     // scalar record -- h->pstat then holds the statistic of the LAST fused launch (a rejected proposal, a
@@ -1048,16 +1066,16 @@ static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, 
     if (rc) return rc;
     if (d_trace && cached) hipLaunchKernelGGL(k_trace_logp_cur, dim3(1), dim3(64), 0, h->stream, (const Scal*)h->sc, d_trace);
     hipLaunchKernelGGL(k_begin, dim3(1, h->C), dim3(1024), 0, h->stream, nd, d_p0, d_logu, h->epoch, h->key0, h->key1, h->p, h->sc, h->seed_hi);
-    launch_update(h, UPD_FIRST, eps, h->eta, h->q, h->g);
+    launch_update(h, UPD_FIRST, eps, h->eta, h->q, h->g, ctl, 0);
     for (int t = 1; t <= L; ++t) {
-        rc = launch_fwd_bwd(h, h->q, h->eta);
+        rc = launch_fwd_bwd(h, h->q, h->eta, ctl, t);
         if (rc) return rc;
         if (d_trace && t < L) {
             // logp at q_t needs the prior at q_t: evaluate before the drift
             launch_update(h, UPD_GRAD_ONLY, 0.f, h->eta, h->q, h->g);
             launch_energy(h, EN_TRACE, h->eta, h->q, d_trace + t);
         }
-        launch_update(h, t < L ? UPD_MID : UPD_LAST, eps, h->eta, h->q, h->g);
+        launch_update(h, t < L ? UPD_MID : UPD_LAST, eps, h->eta, h->q, h->g, ctl, t);
     }
     // the Metropolis decision, the host record and the commit in ONE single-workgroup launch for networks whose state that
     // workgroup copies in a few trips (TBNN_MERGE_ENDS=0: three launches, as before round 3)
@@ -1067,12 +1085,9 @@ static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, 
                            d_out, (const float*)h->g, h->q_cur, h->g_cur, (const float*)h->gd, h->gd_cur);
     } else {
         launch_energy(h, EN_NEW, h->eta, h->q, d_trace ? d_trace + L : nullptr);
-        for (int c = 0; c < h->C; ++c) {
-            const size_t cp = (size_t)c * nd.P;
-            hipLaunchKernelGGL(k_commit, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd.P, h->sc + c, h->q + cp, h->g + cp, h->q_cur + cp, h->g_cur + cp,
-                               (const float*)(h->gd + cp), h->gd_cur + cp);
-            hipLaunchKernelGGL(k_commit_scal, dim3(1), dim3(64), 0, h->stream, h->sc + c, d_out + c);
-        }
+        hipLaunchKernelGGL(k_commit, dim3((nd.P + 255) / 256, h->C), dim3(256), 0, h->stream, nd.P, (const Scal*)h->sc, (const float*)h->q, (const float*)h->g,
+                           h->q_cur, h->g_cur, (const float*)h->gd, h->gd_cur);
+        hipLaunchKernelGGL(k_commit_scal, dim3(h->C), dim3(64), 0, h->stream, h->sc, d_out);
     }
     HIPCHK(hipGetLastError());
     h->epoch += 1;
@@ -1128,6 +1143,7 @@ extern "C" int tbnn_hmc_run(tbnn_handle h, float eps, int32_t L, int32_t n_epoch
     NEED(h);
     if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
     if (L < 1 || n_epochs < 1) return fail(-1, "L and n_epochs must be >= 1");
+    if ((long long)n_epochs * (long long)h->C > (1LL << 24)) return fail(-1, "n_epochs x chains exceeds 2^24 records per call: split the run");
     HIPCHK(hipSetDevice(h->device));
     // per-epoch records: a pooled device buffer and a pooled pinned host mirror (no allocator call -- hipFree synchronises
     // the device -- inside a caller's timed loop once the pool has grown to the largest n_epochs seen)
@@ -1157,6 +1173,58 @@ extern "C" int tbnn_hmc_run(tbnn_handle h, float eps, int32_t L, int32_t n_epoch
     return 0;
 }
 
+// every chain of the handle at its own (eps, L): stage the control block, run max L lockstep steps (enqueue_transition)
+static int stage_ctl(tbnn_ctx* h, const float* eps, const int32_t* L, int* Lmax) {
+    if (!eps || !L) return fail(-1, "null eps / L array");
+    int m = 0;
+    for (int c = 0; c < h->C; ++c) {
+        if (L[c] < 1) return fail(-1, "every L[c] must be >= 1");
+        h->ctl_host[c].eps = eps[c]; h->ctl_host[c].L = L[c];
+        m = std::max(m, (int)L[c]);
+    }
+    HIPCHK(hipMemcpyAsync(h->ctl, h->ctl_host, (size_t)h->C * sizeof(StepCtl), hipMemcpyHostToDevice, h->stream));
+    *Lmax = m;
+    return 0;
+}
+extern "C" int tbnn_hmc_run_each(tbnn_handle h, const float* eps, const int32_t* L, int32_t n_epochs, tbnn_step_out* outs) {
+    NEED(h);
+    if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
+    if (n_epochs < 1) return fail(-1, "n_epochs must be >= 1");
+    if ((long long)n_epochs * (long long)h->C > (1LL << 24)) return fail(-1, "n_epochs x chains exceeds 2^24 records per call: split the run");
+    HIPCHK(hipSetDevice(h->device));
+    const int C = h->C;
+    // (the stream is idle here -- every entry point returns after its work has completed -- so re-staging ctl_host is safe)
+    int Lmax = 0;
+    int rc = stage_ctl(h, eps, L, &Lmax);
+    if (rc) return rc;
+    if (h->recs_cap < n_epochs * C) {
+        if (h->d_recs) hipFree(h->d_recs);
+        if (h->h_recs) hipHostFree(h->h_recs);
+        h->d_recs = nullptr; h->h_recs = nullptr; h->recs_cap = 0;
+        const int cap = std::max(n_epochs * C, 64);
+        HIPCHK(hipMalloc(&h->d_recs, (size_t)cap * sizeof(Scal)));
+        HIPCHK(hipHostMalloc(&h->h_recs, (size_t)cap * sizeof(Scal)));
+        h->recs_cap = cap;
+    }
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int e = 0; e < n_epochs; ++e) {
+        rc = enqueue_transition(h, 0.f, Lmax, nullptr, nullptr, nullptr, h->d_recs + (size_t)e * C, h->ctl);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_recs, h->d_recs, (size_t)n_epochs * C * sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f; hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    const float fb = h->profile ? drain_profile(h) : 0.f;
+    if (outs)
+        for (int c = 0; c < C; ++c)
+            for (int e = 0; e < n_epochs; ++e) fill_out(h->h_recs[(size_t)e * C + c], L[c], ms * 1000.f / n_epochs, fb, outs + (size_t)c * n_epochs + e);
+    return 0;
+}
+extern "C" int tbnn_hmc_step_each(tbnn_handle h, const float* eps, const int32_t* L, tbnn_step_out* out) {
+    return tbnn_hmc_run_each(h, eps, L, 1, out);
+}
+
 extern "C" int tbnn_hyper_logp_grad(tbnn_handle h, const float* eta, double* logp, float* grad) {
     NEED(h);
     ONE_CHAIN(h, "tbnn_hyper_logp_grad");
@@ -1179,8 +1247,18 @@ extern "C" int tbnn_hyper_logp_grad(tbnn_handle h, const float* eta, double* log
     return 0;
 }
 
+static int hyper_step_impl(tbnn_handle h, float eps_h, const float* eps_each, int32_t L_h, const float* p0, const float* log_u, tbnn_step_out* out);
 extern "C" int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const float* p0, const float* log_u,
                                tbnn_step_out* out) {
+    return hyper_step_impl(h, eps_h, nullptr, L_h, p0, log_u, out);
+}
+extern "C" int tbnn_hyper_step_each(tbnn_handle h, const float* eps_h, int32_t L_h, tbnn_step_out* out) {
+    NEED(h);
+    if (!eps_h) return fail(-1, "null eps_h array");
+    return hyper_step_impl(h, 0.f, eps_h, L_h, nullptr, nullptr, out);
+}
+// eps_each (host, [chains]) != null: chain c's hyper transition at eps_each[c]
+static int hyper_step_impl(tbnn_handle h, float eps_h, const float* eps_each, int32_t L_h, const float* p0, const float* log_u, tbnn_step_out* out) {
     NEED(h);
     if (!h->dX) return fail(-1, "tbnn_set_data has not been called");
     if (L_h < 1) return fail(-1, "L_h must be >= 1");
@@ -1194,13 +1272,19 @@ extern "C" int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const fl
     if (p0) { HIPCHK(hipMemcpyAsync(h->p0_inj, p0, (size_t)nd.H * sizeof(float), hipMemcpyHostToDevice, h->stream)); d_p0 = h->p0_inj; }
     if (log_u) { HIPCHK(hipMemcpyAsync(h->logu_inj, log_u, sizeof(float), hipMemcpyHostToDevice, h->stream)); d_lu = h->logu_inj; }
     HIPCHK(hipMemcpyAsync(h->eta_prev, h->eta, (size_t)C * nd.H * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    const float* d_each = nullptr;
+    if (eps_each) {
+        memcpy(h->epsh_host, eps_each, (size_t)C * sizeof(float));
+        HIPCHK(hipMemcpyAsync(h->epsh, h->epsh_host, (size_t)C * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        d_each = h->epsh;
+    }
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     // the hyper transition uses the epoch counter of the weight transition that preceded it
     const uint32_t ep = h->epoch > 0 ? h->epoch - 1 : 0;
     // (one workgroup runs one chain's whole hyper transition: the chains of a multi-chain handle side by side, gridDim.x = chain)
     static_assert(sizeof(float) * 4 == 16, "hyper work space: 4 H floats per chain (hyper_ws_bytes)");
     hipLaunchKernelGGL(k_hyper, dim3(C), dim3(HYP_THREADS), 0, h->stream, nd, (int)HYP_STEP, eps_h, (int)L_h, h->eta, (const float*)h->q_cur, rows_total(h),
-                       d_p0, d_lu, ep, h->key0, h->key1, h->sc, h->hyp_ws, h->sc_out, h->seed_hi);
+                       d_p0, d_lu, ep, h->key0, h->key1, h->sc, h->hyp_ws, h->sc_out, h->seed_hi, d_each);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipMemcpyAsync(h->sc_host, h->sc_out, (size_t)C * sizeof(Scal), hipMemcpyDeviceToHost, h->stream));
@@ -1217,15 +1301,15 @@ extern "C" int tbnn_hyper_step(tbnn_handle h, float eps_h, int32_t L_h, const fl
         static const bool full = getenv("TBNN_HYPER_FULL_REFRESH") && atoi(getenv("TBNN_HYPER_FULL_REFRESH"));
         if (full || !h->cur_valid) h->cur_valid = false;
         else {
-            for (int c = 0; c < C; ++c) {
-                if (!h->sc_host[c].accepted) continue;           // (a rejected chain keeps its cached gradient bit for bit)
-                const size_t cp = (size_t)c * nd.P;
-                hipLaunchKernelGGL(k_refresh_grad_after_hyper, dim3((nd.P + 255) / 256), dim3(256), 0, h->stream, nd,
-                                   (const float*)(h->eta + (size_t)c * nd.H), (const float*)(h->q_cur + cp), (const float*)(h->gd_cur + cp), h->g_cur + cp);
-                hipLaunchKernelGGL(k_energy, dim3(1), dim3(1024), 0, h->stream, nd, (int)EN_REFRESH, (const float*)(h->eta + (size_t)c * nd.H),
-                                   (const float*)(h->q_cur + cp), (const float*)(h->p + cp), (const float*)(h->q_cur + cp),
-                                   stat_ptr(h) + (size_t)c * PSTAT_CAP, stat_entries(h), rows_total(h), h->sc + c, (double*)nullptr);
-            }
+            // one launch each for all chains (gridDim.y = chain); a chain whose hyper proposal was rejected returns at once, on the
+            // device, by its record in sc_out (it keeps its cached gradient bit for bit)
+            const Scal* gate = C > 1 ? (const Scal*)h->sc_out : (const Scal*)nullptr;
+            hipLaunchKernelGGL(k_refresh_grad_after_hyper, dim3((nd.P + 255) / 256, C), dim3(256), 0, h->stream, nd,
+                               (const float*)h->eta, (const float*)h->q_cur, (const float*)h->gd_cur, h->g_cur, gate);
+            hipLaunchKernelGGL(k_energy, dim3(1, C), dim3(1024), 0, h->stream, nd, (int)EN_REFRESH, (const float*)h->eta,
+                               (const float*)h->q_cur, (const float*)h->p, (const float*)h->q_cur,
+                               stat_ptr(h), stat_entries(h), rows_total(h), h->sc, (double*)nullptr,
+                               (Scal*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, (float*)nullptr, gate);
             HIPCHK(hipGetLastError());
         }
     }

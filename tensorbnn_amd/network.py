@@ -207,10 +207,12 @@ class network(object):
                   randomSteps=10, dualAveraging=False, adapt=True):
         """network.py:193-278 (argument names, including the misspelt ones, are the API).
         ``adapt=False`` (new) bypasses the (eps, L) adapter: fixed stepSizeStart / leapfrogStart."""
-        self.adapt = paramAdapter(stepSizeStart, leapfrogStart, stepSizeMin, stepSizeMax, stepSizeOptions, leapfogMin,
-                                  leapFrogMax, leapfrogIncrement, averagingSteps, burnin / averagingSteps, a=a,
-                                  delta=delta, cores=cores, strikes=strikes, randomSteps=randomSteps,
-                                  seed=self.seed + 7919 * self.chain_id)
+        # (kept: trainChains builds one adapter per chain from the same arguments)
+        self._adapt_args = (stepSizeStart, leapfrogStart, stepSizeMin, stepSizeMax, stepSizeOptions, leapfogMin, leapFrogMax,
+                            leapfrogIncrement, averagingSteps, burnin / averagingSteps)
+        self._adapt_kw = dict(a=a, delta=delta, cores=cores, strikes=strikes, randomSteps=randomSteps)
+        self._hyperStepSize0 = hyperStepSize
+        self.adapt = self._make_adapter(self.chain_id)
         self.adapt_enabled = adapt
         self.step_size = np.float32(stepSizeStart)
         self.leapfrog = np.int32(leapfrogStart)
@@ -219,6 +221,10 @@ class network(object):
         self._da = DualAveraging(hyperStepSize, burnin)   # :241-248
         self.dualAveraging = dualAveraging
         self.hyperLeapfrog = hyperLeapfrog
+
+    def _make_adapter(self, chain_id):
+        """the (eps, L) adapter of the chain with this id (network.py:221-235); its own random stream per chain"""
+        return paramAdapter(*self._adapt_args, seed=self.seed + 7919 * chain_id, **self._adapt_kw)
 
     # the reference keeps these scalars on the network object (network.py:241-248)
     hyper_step_size = property(lambda self: self._da.step_size)
@@ -306,14 +312,19 @@ class network(object):
         return records
 
     def trainChains(self, chains, epochs, samplingStep, likelihood, adjustHypers=True, folderName=None, networksPerFile=1000,
-                    verbose=False):
-        """NEW (no counterpart in the reference, which runs one chain): `chains` independent chains of this network on the one
-        GPU behind one native handle (tbnn_create_multi): chain c has the Philox stream of chain_id + c and is bit for bit what a
-        single-chain run with that chain_id would be at the same (eps, L) schedule.  All chains start from the network's
-        current state and advance in lockstep; the (eps, L) adapter and the hyper step's dual averaging are driven by chain 0
-        (one schedule for all).  Samples go to folderName/chain<c>/ in the reference's format (readable by `predictor`).
-        For problems that leave the GPU idle -- the reference's examples: tens to thousands of rows -- C chains cost about what
-        one costs.  Returns the per-epoch records (rec["main"]: one transition record per chain)."""
+                    verbose=False, initialStates=None):
+        """NEW (no counterpart in the reference, which runs one chain per process): `chains` independent chains of this network
+        on the one GPU behind one native handle (tbnn_create_multi).  Chain c IS the run `network(..., chain_id=chain_id + c)`
+        + `train(...)` would be: its own Philox stream, its OWN (eps, L) adapter (paramAdapter, network.py:221-235, :603-607)
+        and its OWN dual averaging of the hyper step size (network.py:457-469) -- bit for bit, states and records
+        (tests/test_gpu_multichain.py).  The chains advance in lockstep launches (gridDim.y = chain) for max_c L_c leapfrog
+        steps per epoch; a chain past its own L_c is skipped on the device (tbnn_hmc_step_each).
+        initialStates: None (every chain starts from the network's current state, as C runs of one script would) or an array
+        [chains][P] of flattened start states -- over-dispersed starts are what R-hat style diagnostics want.
+        Samples go to folderName/chain<c>/ in the reference's format (readable by `predictor`).  For problems that leave the
+        GPU idle -- the reference's examples: tens to thousands of rows -- C chains cost about what one costs.  Returns the
+        per-epoch records: rec["main"] / rec["hyper"]: one transition record per chain, rec["eps"] / rec["L"] /
+        rec["hyper_step_size"]: per-chain lists.  The network object mirrors chain 0 (states, step size, leapfrog)."""
         startSampling = self.burnin
         self.likelihood = likelihood
         if self._lik_hypers:
@@ -323,10 +334,18 @@ class network(object):
         self._lik_hypers = len(likelihood.hypers)
         grp = nat.ChainGroup(self._dense, int(chains), likelihood=likelihood.kind, fixed_sd=float(getattr(likelihood, "fixed_sd", 0.1)),
                              device=self.device, seed=self.seed, chain_id=self.chain_id, kernel=self.kernel)
+        C = grp.C
         if verbose:
-            print("tensorbnn_amd: fused kernel", grp.kernel_name, "x", grp.C, "chains")
+            print("tensorbnn_amd: fused kernel", grp.kernel_name, "x", C, "chains")
         grp.set_data(self.trainX, self.trainY.reshape(len(self.trainX), -1))
-        grp.set_state(self._theta())
+        if initialStates is None:
+            grp.set_state(self._theta())
+        else:
+            th0 = np.asarray(initialStates, dtype=np.float32)
+            if th0.shape != (C, grp.P):
+                grp.close()
+                raise ValueError(f"initialStates must be [{C}, {grp.P}]")
+            grp.set_state(th0)
         grp.set_hypers(np.concatenate(self.hyperStates) if self.hyperStates else np.zeros(0, np.float32))
         shapes = [s_.shape for s_ in self.states]
 
@@ -338,27 +357,41 @@ class network(object):
                 o += size
             return out
 
+        # one adapter and one dual averaging per chain; chain 0's are the network's own (what train() would use)
+        adapters = [self.adapt] + [self._make_adapter(self.chain_id + c) for c in range(1, C)]
+        das = [self._da] + [DualAveraging(self._hyperStepSize0, self.burnin) for _ in range(1, C)]
+        eps = np.full(C, self.step_size, dtype=np.float32)
+        leap = np.full(C, self.leapfrog, dtype=np.int32)
         writers = None
         if folderName is not None:
-            writers = [_SampleFiles(os.path.join(os.getcwd(), folderName, "chain%d" % c), self.states, self.layers) for c in range(grp.C)]
+            writers = [_SampleFiles(os.path.join(os.getcwd(), folderName, "chain%d" % c), self.states, self.layers) for c in range(C)]
         records, iter_ = [], 0
         try:
             while iter_ < epochs:
-                outs = grp.hmc_step(float(self.step_size), int(self.leapfrog))
-                rec = {"iter": iter_, "eps": float(self.step_size), "L": int(self.leapfrog), "main": outs}
+                outs = grp.hmc_step_each(eps, leap)
+                rec = {"iter": iter_, "eps": [float(e) for e in eps], "L": [int(l) for l in leap], "main": outs}
                 if adjustHypers and grp.H > 0:
-                    houts = grp.hyper_step(float(self.hyper_step_size), int(self.hyperLeapfrog))
-                    self.hyperAccept = self._dual_averaging(iter_, houts[0]["log_accept_ratio"])
+                    eps_h = np.array([float(d.step_size) for d in das], dtype=np.float32)
+                    houts = grp.hyper_step_each(eps_h, int(self.hyperLeapfrog))
+                    for c in range(C):
+                        acc = das[c].update(iter_, houts[c]["log_accept_ratio"])
+                        if c == 0:
+                            self.hyperAccept = acc
                     rec["hyper"] = houts
-                    rec["hyper_step_size"] = float(self.hyper_step_size)
+                    rec["hyper_step_size"] = [float(d.step_size) for d in das]
                 thetas, etas = grp.get_state(), grp.get_hypers()
                 self._set_states_from(thetas[0])                          # the network object mirrors chain 0
                 self.hyperStates = [etas[0][i:i + 1].copy() for i in range(etas.shape[1])]
-                self.mainAccept = np.float32(np.mean([o_["accept_prob"] for o_ in outs]))
+                self.mainAccept = np.float32(outs[0]["accept_prob"])
                 iter_ += 1
                 if self.adapt_enabled:
-                    step, leap = self.adapt.update(self.states)
-                    self.step_size, self.leapfrog = np.float32(step), np.int32(leap)
+                    sjd = []
+                    for c in range(C):
+                        e_c, l_c = adapters[c].update(thetas[c])
+                        eps[c], leap[c] = np.float32(e_c), np.int32(l_c)
+                        sjd.append(adapters[c].lastSJD)
+                    rec["sjd"] = sjd
+                    self.step_size, self.leapfrog = np.float32(eps[0]), np.int32(leap[0])
                 if writers is not None:
                     for c, w in enumerate(writers):
                         w.after_epoch(iter_, startSampling, samplingStep, networksPerFile, split(thetas[c]),

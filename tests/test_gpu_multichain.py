@@ -90,10 +90,49 @@ def test_group_guards(native):
     g5.close()
 
 
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_group_chains_at_their_own_step_size_and_leapfrog_count(native, shape):
+    """tbnn_hmc_run_each / tbnn_hmc_step_each / tbnn_hyper_step_each: every chain of a group at ITS OWN (eps, L) and hyper step size
+    -- the reference runs one adapter per chain (network.py:221-235, :603-607) -- is bit for bit the solo chain driven with those
+    values: the lockstep loop runs max L steps, a chain past its own L is skipped (k_update returns, the fused pass's blocks exit)"""
+    dims, n, act, prior, lik = SHAPES[shape]
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, act, prior, lik)
+    C, c0, seed = 4, 3, 50
+    rng = np.random.default_rng(5)
+    thetas = (theta[None, :] * (1.0 + 0.05 * rng.standard_normal((C, theta.size)))).astype(np.float32)
+    e0 = 2e-3 if lik == o.LIK_FIXED_GAUSSIAN else 2e-5
+    eps = np.array([e0, 0.5 * e0, 2.0 * e0, 0.3], dtype=np.float32)              # (the last one diverges: rejects)
+    Ls = np.array([3, 7, 1, 4], dtype=np.int32)
+    eps_h = np.array([1e-4, 3e-4, 5e-5, 2e-4], dtype=np.float32)
+    grp = native.ChainGroup(layers_of(spec), C, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, seed=seed, chain_id=c0, jit=False)
+    grp.set_data(X, Y); grp.set_state(thetas); grp.set_hypers(eta)
+    g1 = grp.hmc_run_each(eps, Ls, 3)
+    gh = grp.hyper_step_each(eps_h, 6) if spec.n_hypers else None
+    g2 = grp.hmc_step_each(eps[::-1].copy(), Ls[::-1].copy())
+    g3 = grp.hmc_step(e0, 2)                                                  # and back to one (eps, L) for all
+    g_state, g_hyp = grp.get_state(), grp.get_hypers()
+    grp.close()
+    for c in range(C):
+        ch = native.Chain(layers_of(spec), likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, seed=seed, chain_id=c0 + c, jit=False)
+        ch.set_data(X, Y); ch.set_state(thetas[c]); ch.set_hypers(eta)
+        s1 = ch.hmc_run(float(eps[c]), int(Ls[c]), 3)
+        sh = ch.hyper_step(float(eps_h[c]), 6) if spec.n_hypers else None
+        s2 = ch.hmc_step(float(eps[C - 1 - c]), int(Ls[C - 1 - c]))
+        s3 = ch.hmc_step(e0, 2)
+        for got, want in list(zip(g1[c], s1)) + [(g2[c], s2), (g3[c], s3)] + ([(gh[c], sh)] if sh else []):
+            np.testing.assert_array_equal(np.array([got[k] for k in REC], dtype=np.float64), np.array([want[k] for k in REC], dtype=np.float64))
+            assert got["n_leapfrog"] == want["n_leapfrog"]
+        np.testing.assert_array_equal(g_state[c], ch.get_state())
+        np.testing.assert_array_equal(g_hyp[c], ch.get_hypers())
+        ch.close()
+
+
 def test_train_chains_flow(tmp_path, monkeypatch, native):
-    """network.trainChains (new): the literal trainRegression problem (11 rows) as 5 chains on the one GPU through the drop-in
-    Python API -- one (eps, L) schedule from chain 0's adapter, per-chain sample folders in the reference's format that
-    `predictor` reads back; chain 0 of the group IS the single-chain `train` run of the same network (same records)."""
+    """network.trainChains: the literal trainRegression problem (11 rows) as 4 chains on the one GPU through the drop-in Python
+    API, every chain with its OWN (eps, L) adapter and its own dual averaging of the hyper step size -- as four runs of the
+    reference would have (network.py:221-235, :457-469, :603-607).  Chain c of the group IS the single-chain `train` run of
+    `network(..., chain_id=c)`: same (eps, L) schedule, same records, bit-identical states after 61 adapted epochs, same samples
+    on disk (per-chain folders in the reference's format that `predictor` reads back)."""
     import math
     from tensorbnn_amd.activationFunctions import Tanh
     from tensorbnn_amd.layer import GaussianDenseLayer
@@ -106,8 +145,8 @@ def test_train_chains_flow(tmp_path, monkeypatch, native):
     trainOut = np.sin(trainIn * math.pi * 2) * trainIn - np.cos(trainIn * math.pi)
     valOut = np.sin(valIn * math.pi * 2) * valIn - np.cos(valIn * math.pi)
 
-    def make():
-        net = network(np.float32, 1, trainIn, trainOut.T, valIn, valOut.T)
+    def make(chain_id=0):
+        net = network(np.float32, 1, trainIn, trainOut.T, valIn, valOut.T, chain_id=chain_id)
         seed = 1000
         net.add(GaussianDenseLayer(1, 10, seed=seed)); net.add(Tanh()); seed += 1000
         for _ in range(2):
@@ -115,22 +154,48 @@ def test_train_chains_flow(tmp_path, monkeypatch, native):
         net.add(GaussianDenseLayer(10, 1, seed=seed))
         net.setupMCMC(stepSizeStart=1e-3, stepSizeMin=1e-4, stepSizeMax=1e-2, stepSizeOptions=20, leapfrogStart=50,
                       leapfogMin=10, leapFrogMax=100, leapfrogIncrement=10, hyperStepSize=0.001, hyperLeapfrog=20,
-                      burnin=20, averagingSteps=5)
+                      burnin=20, averagingSteps=5, randomSteps=3)
         return net
 
-    C = 5
-    rec = make().trainChains(C, 41, 10, FixedGaussianLikelihood(sd=0.1), adjustHypers=True, folderName="multi", networksPerFile=2)
-    assert len(rec) == 41 and all(len(r["main"]) == C for r in rec)
-    solo = make().train(41, 10, FixedGaussianLikelihood(sd=0.1), adjustHypers=True, folderName="solo", networksPerFile=2, verbose=False)
-    for rg, rs in zip(rec, solo):                                     # chain 0 of the group == the single-chain run, epoch by epoch
-        assert rg["eps"] == rs["eps"] and rg["L"] == rs["L"]
-        assert rg["main"][0]["log_accept_ratio"] == rs["main"]["log_accept_ratio"] and rg["main"][0]["accepted"] == rs["main"]["accepted"]
-        assert rg["hyper"][0]["log_accept_ratio"] == rs["hyper"]["log_accept_ratio"]
-    ps = predictor(str(tmp_path / "solo") + "/")
-    finals = []
+    C, EPOCHS = 4, 61
+    rec = make().trainChains(C, EPOCHS, 10, FixedGaussianLikelihood(sd=0.1), adjustHypers=True, folderName="multi", networksPerFile=2)
+    assert len(rec) == EPOCHS and all(len(r["main"]) == C for r in rec)
+    schedules = set()
     for c in range(C):
+        net = make(chain_id=c)
+        solo = net.train(EPOCHS, 10, FixedGaussianLikelihood(sd=0.1), adjustHypers=True, folderName="solo%d" % c, networksPerFile=2, verbose=False)
+        for rg, rs in zip(rec, solo):                                 # chain c of the group == the single-chain run, epoch by epoch
+            assert rg["eps"][c] == rs["eps"] and rg["L"][c] == rs["L"], (c, rg["iter"])
+            assert rg["main"][c]["log_accept_ratio"] == rs["main"]["log_accept_ratio"] and rg["main"][c]["accepted"] == rs["main"]["accepted"]
+            assert rg["hyper"][c]["log_accept_ratio"] == rs["hyper"]["log_accept_ratio"]
+            assert rg["hyper_step_size"][c] == rs["hyper_step_size"]
+        schedules.add(tuple((r["eps"][c], r["L"][c]) for r in rec))
+        ps = predictor(str(tmp_path / ("solo%d" % c)) + "/")
         p = predictor(str(tmp_path / "multi" / ("chain%d" % c)) + "/")
-        assert p.numNetworks == ps.numNetworks == 2 and p.hypers[0].shape == (16,)
-        finals.append(p.vectors[-1])
-    np.testing.assert_array_equal(finals[0], ps.vectors[-1])          # same samples on disk
-    assert all(np.abs(finals[c] - finals[0]).max() > 0 for c in range(1, C))       # the other chains went their own way
+        assert p.numNetworks == ps.numNetworks == 4 and p.hypers[0].shape == (16,)
+        np.testing.assert_array_equal(p.vectors[-1], ps.vectors[-1])          # same samples on disk
+        for a, b in zip(p.hypers, ps.hypers):
+            np.testing.assert_array_equal(a, b)
+    assert len(schedules) == C                                        # the adapters went their own ways
+    assert len({r["L"][c] for r in rec for c in range(C)}) > 2         # and moved L
+
+
+def test_train_chains_initial_states(tmp_path, monkeypatch, native):
+    """trainChains(initialStates=[C][P]): over-dispersed starts; a wrong shape is refused"""
+    from tensorbnn_amd.activationFunctions import Relu
+    from tensorbnn_amd.layer import DenseLayer
+    from tensorbnn_amd.likelihood import GaussianLikelihood
+    from tensorbnn_amd.network import network
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((200, 1)).astype(np.float32); y = np.sin(x[:, 0]).astype(np.float32)
+    net = network(np.float32, 1, x, y, x[:20], y[:20])
+    net.add(DenseLayer(1, 10, seed=1)); net.add(Relu()); net.add(DenseLayer(10, 1, seed=2))
+    net.setupMCMC(stepSizeStart=1e-4, leapfrogStart=5, burnin=5, adapt=False)
+    P = sum(s.size for s in net.states)
+    th0 = (net._theta()[None, :] + 0.1 * rng.standard_normal((3, P))).astype(np.float32)
+    with pytest.raises(ValueError):
+        net.trainChains(3, 2, 1, GaussianLikelihood(sd=0.1), initialStates=th0[:2])
+    rec = net.trainChains(3, 4, 1, GaussianLikelihood(sd=0.1), initialStates=th0, adjustHypers=False)
+    lp = [rec[0]["main"][c]["logp_old"] for c in range(3)]
+    assert len(set(lp)) == 3                                          # three different start states

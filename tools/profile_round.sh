@@ -14,7 +14,10 @@ CMD[c2]="python3 bench.py --workload c2 --steps 40 --warmup 10 --no-cpu-baseline
 CMD[c4]="python3 bench.py --workload c4 --no-cpu-baseline"
 CMD[c5]="python3 bench.py --workload c5 --no-cpu-baseline"
 CMD[mn]="python3 bench.py --workload mn --no-cpu-baseline"
-for W in ${PROFILE_WORKLOADS:-c2 c4 c5 mn}; do
+# the layered family (any architecture; no burned-in fixture: a small fixed step from the initial state -- the kernels' durations do not depend on the state)
+CMD[w300]="python3 bench.py --workload w300 --eps 1e-6 --no-cpu-baseline"
+CMD[mc10]="python3 bench.py --workload mc10 --eps 1e-6 --no-cpu-baseline"
+for W in ${PROFILE_WORKLOADS:-c2 c4 c5 mn w300 mc10}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- ${CMD[$W]} > $OUT/trace_$W.log 2>&1 || echo "trace $W failed"
   f=$(find $OUT/trace_$W -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${W}_kernel_stats.csv
   i=0
@@ -23,7 +26,7 @@ for W in ${PROFILE_WORKLOADS:-c2 c4 c5 mn}; do
     timeout 300 rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc_${W}_$i -- ${CMD[$W]} > $OUT/pmc_${W}_$i.log 2>&1 || echo "pmc pass $i ($SET) of $W failed"
   done
 done
-python3 tools/rocprof_summary.py $OUT
+python3 tools/rocprof_summary.py $OUT          # (reads the per-dispatch traces: medians)
 # keep only the small summaries (the per-dispatch CSVs are large)
 find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 ls $OUT | head -40
