@@ -44,10 +44,21 @@ struct Shape {
 #ifndef TBNN_FAST_ACT
 #define TBNN_FAST_ACT 1
 #endif
+// DIAGNOSTIC builds only (TBNN_BUILD_TAG=skel.. TBNN_EXTRA_FLAGS=-DTBNN_SKEL=n, tools/experiments/skeleton.sh; wrong results, right
+// instruction streams -- never the product): what the one-wave-per-SIMD design of k_fwd_bwd_fast3 can reach.
+//   bit 0 (1): no row tiles at all -- prologue + epilogue only: the launch's fixed cost
+//   bit 1 (2): the tile body without the VALU work that is not an MFMA operand's address or value: activations and their
+//              derivatives pass their argument through, the fringe rows of dW (packed FMAs) are not accumulated
+//   bit 2 (4): the forward / delta chains' weight operands are not read from LDS (as if they lived in registers)
+//   bit 3 (8): the fourth N tile of dW_1 / dW_2 (3 useful columns of 16: units 48, 49 and the bias) is not computed
+#ifndef TBNN_SKEL
+#define TBNN_SKEL 0
+#endif
 template <int ACT>
 __device__ __forceinline__ float actc_fwd(float z) {
+    if constexpr ((TBNN_SKEL & 2) != 0) return z;
     // relu as ONE integer max on the bit pattern (negative floats are negative ints; no NaN canonicalisation op)
-    if constexpr (ACT == TBNN_ACT_RELU) return __int_as_float(max(__float_as_int(z), 0));
+    else if constexpr (ACT == TBNN_ACT_RELU) return __int_as_float(max(__float_as_int(z), 0));
 #if TBNN_FAST_ACT
     // hardware exp2 / reciprocal (about 2 ulp) instead of the library tanhf / expf + IEEE division: in the fused kernels
     // every VALU instruction costs MFMA time
@@ -105,7 +116,8 @@ __host__ __device__ constexpr int ones_slot(int U) { return 16 * (U / 16) + 4 * 
 // acc * act'(a) with act' expressed through the activation output a (relu: a select, no multiply)
 template <int ACT>
 __device__ __forceinline__ float actc_bwd_mul(float acc, float a) {
-    if constexpr (ACT == TBNN_ACT_RELU) return __float_as_int(a) > 0 ? acc : 0.f;
+    if constexpr ((TBNN_SKEL & 2) != 0) return acc;
+    else if constexpr (ACT == TBNN_ACT_RELU) return __float_as_int(a) > 0 ? acc : 0.f;
     else return acc * actc_bwd<ACT>(a);
 }
 
@@ -178,8 +190,10 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // v_accvgpr_read per result register; on gfx950 every VALU instruction costs ~9 cycles of tile time because the f32
 // MFMA and the VALU share the issue slot, tools/ubench/coexec.hip), and the dW tiles, which only MFMAs touch inside
 // the row loop, must then not compete for the 256 ArchVGPRs.  No software wait states are inserted around inline asm:
-// FAR says the same accumulator is revisited only after at least one other MFMA (>= 32 cycles, beyond the MFMA->MFMA
-// SrcC requirement); otherwise the builtin is used.  Operands come from LDS loads; the kernels drain the pipe
+// FAR says the same accumulator is revisited only after at least TWO other MFMAs; otherwise the builtin is used.  (Round 5: with
+// ONE other 16x16x4 MFMA in between -- two accumulator tiles taken in turn -- the asm form read a stale accumulator: 8.5e-2 relative
+// error in dW of a 7 -> 17 -> 33 -> 2 network on the narrow family's hand-threaded dW block; a 4x4x1 form accumulating into its predecessor's
+// result likewise.  The wide family's k_dw_wide keeps its two-tile turns, back to back at the full issue rate: parity-tested as they are.)  Operands come from LDS loads; the kernels drain the pipe
 // (mfma_drain) before the epilogue reads the accumulators.  TBNN_ACC_AGPR=0: builtin everywhere.
 #ifndef TBNN_ACC_AGPR
 #define TBNN_ACC_AGPR 1
@@ -254,6 +268,14 @@ __device__ __forceinline__ f32x2 relu_step2(f32x2 a, f32x2 big) {
     asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(big));
     return d;
 }
+#ifndef TBNN_F3_RELU_PKMUL
+#define TBNN_F3_RELU_PKMUL 1
+#endif
+__device__ __forceinline__ f32x2 pkmul2(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ float mul_legacy(float s, float x) {
     float d;
     asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(d) : "v"(s), "v"(x));
@@ -278,11 +300,20 @@ __device__ __forceinline__ void mfma_settle(f32x4 (&acc)[N]) {
 template <int ACT, bool SETTLED>
 __device__ __forceinline__ f32x4 actc_bwd_mul4(f32x4 acc, f32x4 a) {
     f32x4 r;
-    if constexpr (ACT == TBNN_ACT_RELU && TBNN_F3_RELU_PK && SETTLED) {
+    if constexpr ((TBNN_SKEL & 2) != 0) return acc;
+    else if constexpr (ACT == TBNN_ACT_RELU && TBNN_F3_RELU_PK && SETTLED) {
         const f32x2 big = {3.402823466e38f, 3.402823466e38f};
         const f32x2 s01 = relu_step2(f32x2{a[0], a[1]}, big), s23 = relu_step2(f32x2{a[2], a[3]}, big);
+#if TBNN_F3_RELU_PKMUL
+        // the mask applied by a PACKED multiply too: one instruction per register pair instead of one v_mul_legacy per register.
+        // (0 * inf = NaN here where the legacy multiply gives 0: a non-finite delta means a diverged trajectory, whose energy is
+        // non-finite either way -> rejected; the oracle's `delta * (a > 0)` makes the same NaN)
+        const f32x2 r01 = pkmul2(s01, f32x2{acc[0], acc[1]}), r23 = pkmul2(s23, f32x2{acc[2], acc[3]});
+        r[0] = r01[0]; r[1] = r01[1]; r[2] = r23[0]; r[3] = r23[1];
+#else
         r[0] = mul_legacy(s01[0], acc[0]); r[1] = mul_legacy(s01[1], acc[1]);
         r[2] = mul_legacy(s23[0], acc[2]); r[3] = mul_legacy(s23[1], acc[3]);
+#endif
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = actc_bwd_mul<ACT>(acc[i], a[i]);
@@ -325,6 +356,10 @@ __device__ __forceinline__ float gsum(float p) {
 // (ns is a constant after unrolling: the branches fold)
 __device__ __forceinline__ f32x4 load_ks(const float* p, int ns) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#if (TBNN_SKEL & 4)
+    asm volatile("" : "=v"(v));            // diagnostic: the chain's weight operands cost no LDS read (whatever the registers hold)
+    return v;
+#endif
     if (ns >= 3) v = *reinterpret_cast<const f32x4*>(p);
     else if (ns == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
     else v[0] = p[0];
@@ -465,7 +500,7 @@ struct BwdOps {
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    mfma16_acc<(MT * NT > 1)>(dW[C::dwoff(l) + mt * NT + nt], Aop[mt][s], Bop[nt][s]);
+                    mfma16_acc<(MT * NT > 2)>(dW[C::dwoff(l) + mt * NT + nt], Aop[mt][s], Bop[nt][s]);
     }
     // delta_{l-1} = (W_l^T dz) * act'(a_{l-1}); A operands from the transposed image, one k-group ahead
     static __device__ __forceinline__ void da(const TileRegs<S>& T, const float* __restrict__ lds, int i16, int g,

@@ -54,7 +54,24 @@ struct F3Cfg : FastCfg<S> {
     // number of layers whose dW has an MFMA part (a trailing all-fringe layer has none)
     static constexpr int NLM3 = MTF(B::NL - 1) == 0 ? B::NL - 1 : B::NL;
     static_assert(NLM3 == B::NLM, "fast3 expects the same MFMA/VALU split of the last layer as fast");
-    static constexpr int dwoff3(int l) { int o = 0; for (int m = 0; m < l && m < NLM3; ++m) o += MTF(m) * B::NT(m); return o; }
+    // N-side fringe of dW_l (round 5): 50 inputs + the bias column are 3 full N tiles + a 4th that holds 3 useful columns of 16 (units
+    // 48, 49 and the ones slot: image slots 48 + 4 j).  With at most 4 such columns the last N tile leaves the 16x16x4 path (MTF x 4
+    // MFMAs of 32 cycles per tile and layer) for the 16-block 4x4x1 form: block b = units 4b .. 4b+3, columns = slots 48 + 4j, one
+    // instruction (8 cycles) per data row -- 16 per tile and layer, ONE accumulator tile instead of MTF.  NTF: N tiles on the 16x16x4 path.
+#ifndef TBNN_F3_NFRINGE
+#define TBNN_F3_NFRINGE 1
+#endif
+    // (only where the epilogue stages all dW tiles in ONE pass -- at most 39 tiles before the change: the pair of N-fringe accumulators is summed there)
+    static constexpr int dw_tiles_plain() { int o = 0; for (int m = 0; m < NLM3; ++m) o += MTF(m) * B::NT(m); return o; }
+    static constexpr bool NCF(int l) {
+        return TBNN_F3_NFRINGE && TBNN_ACC_AGPR && TBNN_F3_THREAD && dw_tiles_plain() <= 39 && l < NLM3 && B::NT(l) >= 2 && MTF(l) >= 1 && MTF(l) <= 4 && B::in(l) + 1 - 16 * (B::NT(l) - 1) <= 4;
+    }
+    static constexpr int NTF(int l) { return NCF(l) ? B::NT(l) - 1 : B::NT(l); }
+    // (two N-fringe accumulators, even / odd data rows: a 4x4x1 MFMA that accumulates into the result of the one before it needs
+    // wait states the inline-asm form does not get -- back to back it read a stale accumulator; the pair is summed in the epilogue)
+    static constexpr int dwt3(int l) { return MTF(l) * NTF(l) + (NCF(l) ? 2 : 0); }        // accumulator tiles of layer l
+    static constexpr int dwoff3(int l) { int o = 0; for (int m = 0; m < l && m < NLM3; ++m) o += dwt3(m); return o; }
+    static constexpr int dwfr3(int l) { return dwoff3(l) + MTF(l) * NTF(l); }               // layer l's N-fringe tile
     static constexpr int DW3_TILES = dwoff3(B::NL);
     // per-lane k-slots of layer l's input: natural x for layer 0, else 4 registers of every tile of a_{l-1}
     static constexpr int KIN(int l) { return l == 0 ? B::KS0 : 4 * B::MT(l - 1); }
@@ -429,7 +446,7 @@ struct FringeDW {
     using C = F3Cfg<S>;
     static __device__ __forceinline__ void run(float (&FP)[C::FP_REGS > 0 ? C::FP_REGS : 1], const Tile3<S>& T,
                                                 const float (&dzf)[C::maxNF() > 0 ? C::maxNF() : 1], int g) {
-        constexpr int NF = C::FB(l) ? 0 : C::NF(l), KIN = C::KIN(l);
+        constexpr int NF = (C::FB(l) || (TBNN_SKEL & 2)) ? 0 : C::NF(l), KIN = C::KIN(l);
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             float* fp = FP + C::fpoff(l) + f * (KIN + 1);
@@ -463,6 +480,8 @@ struct Bwd3 {
     using C = F3Cfg<S>;
     static constexpr int MT = C::MTF(l), NT = C::NT(l), NF = C::NF(l);
     static constexpr int MTd = MT > 0 ? MT : 1, NFd = C::maxNF() > 0 ? C::maxNF() : 1;
+    static constexpr int NTM = C::NTF(l);                         // N tiles of dW_l on the 16x16x4 path (NT - 1 with the N-side fringe)
+    static constexpr bool NCF = C::NCF(l);
 
     // W(D_l) R(op_l): only when the layer has an MFMA dW part
     static __device__ __forceinline__ void issue(const f32x4 (&dz)[C::MT(l)], const float (&dzf)[NFd], float* wl, int i16, int g,
@@ -543,12 +562,51 @@ struct Bwd3 {
             }
         }
     }
-    static constexpr int NMF = MT > 0 ? 4 * MT * NT : 0;
+    static constexpr int NMF = MT > 0 ? 4 * MT * NTM : 0;
     static __device__ __forceinline__ void dw_step(int j, f32x4 (&dW)[C::DW3_TILES > 0 ? C::DW3_TILES : 1], const float (&Aop)[MTd][4],
                                                     const float (&Bop)[NT][4]) {
         if constexpr (MT > 0) {
-            const int s = j / (MT * NT), mt = (j / NT) % MT, nt = j % NT;
-            mfma16_acc<(MT * NT > 1)>(dW[C::dwoff3(l) + mt * NT + nt], Aop[mt][s], Bop[nt][s]);
+            const int s = j / (MT * NTM), mt = (j / NTM) % MT, nt = j % NTM;
+            if ((TBNN_SKEL & 8) && NT == 4 && nt == 3) return;
+            mfma16_acc<(MT * NTM > 2)>(dW[C::dwoff3(l) + mt * NTM + nt], Aop[mt][s], Bop[nt][s]);
+        }
+    }
+    // ---- N-side fringe of dW_l (F3Cfg::NCF): its operands go from LDS straight into AccVGPRs (an MFMA's A / B operands may be
+    // AccVGPRs on gfx950; the ~250 ArchVGPRs of this kernel have no room for 32 more):
+    //   A[q][s]: lane L = delta_l[unit L][row 4q + s]      -- the delta image row L (units 0 .. 16 MTF - 1; lanes above: unused blocks)
+    //   B[q][s]: lane L = a_{l-1}[slot 16 (NT-1) + 4 (L & 3)][row 4q + s]   -- units 48, 49, the ones slot, a zero slot
+    // nf_load runs once layer l's delta image is complete (issue / issue_step), nf_mfma a few dozen vector instructions later.
+    // Inline-asm LDS reads are invisible to the compiler's wait-count bookkeeping: nf_mfma waits for lgkmcnt(0) itself (extra
+    // outstanding reads only make the compiler's own counted waits stronger: LDS returns in order).
+    struct NFOps { f32x4 A[4], B[4]; };
+    static __device__ __forceinline__ void nf_load(NFOps& o, const float* wl, int lane) {
+        if constexpr (NCF) {
+            const float* da = wl + C::doff3 + lane * C::PR;
+            const float* ab = wl + C::aoff3(l) + (16 * (NT - 1) + 4 * (lane & 3)) * C::PR;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(o.A[q]) : "v"((unsigned)(size_t)da), "n"(16 * q) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(o.B[q]) : "v"((unsigned)(size_t)ab), "n"(16 * q) : "memory");
+            }
+        }
+    }
+    static __device__ __forceinline__ void nf_mfma(f32x4 (&dW)[C::DW3_TILES > 0 ? C::DW3_TILES : 1], NFOps& o) {
+        if constexpr (NCF) {
+            // two rows per statement, one per accumulator, and the wait states a dependent 4x4x1 needs written out: the next statement
+            // accumulates into acc0 three wait states after this one's first MFMA whatever the compiler puts between the statements
+            f32x4& acc0 = dW[C::dwfr3(l)];
+            f32x4& acc1 = dW[C::dwfr3(l) + 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int s = 0; s < 4; s += 2) {
+                    if (q == 0 && s == 0)
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mfma_f32_4x4x1_16b_f32 %0, %2, %3, %0\n\tv_mfma_f32_4x4x1_16b_f32 %1, %4, %5, %1\n\ts_nop 1"
+                                     : "+a"(acc0), "+a"(acc1) : "a"(o.A[q][s]), "a"(o.B[q][s]), "a"(o.A[q][s + 1]), "a"(o.B[q][s + 1]));
+                    else
+                        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, %0\n\tv_mfma_f32_4x4x1_16b_f32 %1, %4, %5, %1\n\ts_nop 1"
+                                     : "+a"(acc0), "+a"(acc1) : "a"(o.A[q][s]), "a"(o.B[q][s]), "a"(o.A[q][s + 1]), "a"(o.B[q][s + 1]));
+                }
         }
     }
     // fringe rows of dW_l in the B-operand layout: lane (i16, g) sums delta_f[row 4g+s] * a_{l-1}[slot 16nt+i16][row 4g+s]
@@ -556,7 +614,7 @@ struct Bwd3 {
     // NF == 1: pairs of rows.
     static __device__ __forceinline__ void fdw(float (&FP)[C::FP_REGS > 0 ? C::FP_REGS : 1], const float (&Fop)[8],
                                                 const float (&Bop)[NT][4]) {
-        if constexpr (C::FB(l)) {
+        if constexpr (C::FB(l) && !(TBNN_SKEL & 2)) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 f32x2 acc = {FP[C::fpoff(l) + 2 * nt], FP[C::fpoff(l) + 2 * nt + 1]};
@@ -583,8 +641,9 @@ struct Bwd3 {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        mfma16_acc<(MT * NT > 1)>(dW[C::dwoff3(l) + mt * NT + nt], Aop[mt][s], Bop[nt][s]);
+                    for (int nt = 0; nt < NTM; ++nt)
+                        if (!((TBNN_SKEL & 8) && NT == 4 && nt == 3))
+                            mfma16_acc<(MT * NTM > 2)>(dW[C::dwoff3(l) + mt * NTM + nt], Aop[mt][s], Bop[nt][s]);
         }
     }
     // delta_{l-1} (full tiles + fringe) from delta_l
@@ -737,6 +796,8 @@ struct Pipe3 {
                                                 const float (&Aup)[Bwd3<S, l + 1>::MTd][4], const float (&Bup)[C::NT(l + 1)][4],
                                                 const float (&Fup)[8]) {
         float Aop[Bwd3<S, l>::MTd][4], Bop[C::NT(l)][4], Fop[8];
+        typename Bwd3<S, l>::NFOps NFop;
+        static_assert(!(C::NCF(l) || C::NCF(l + 1)) || (TBNN_ACC_AGPR && TBNN_F3_THREAD), "the N-side fringe rides in the hand-threaded pipeline");
 #if !(TBNN_ACC_AGPR && TBNN_F3_THREAD)
         Bwd3<S, l>::issue(dz, dzf, wl, i16, g, Aop, Bop, Fop);
 #endif
@@ -758,11 +819,18 @@ struct Pipe3 {
         {
             constexpr int NM = Bwd3<S, l + 1>::NMF, NL = Bwd3<S, l>::NLDS;
             static_assert(NM > 0, "the layer above has an MFMA dW part");
+            constexpr int NWRl = Bwd3<S, l>::NWR;
+            constexpr int JNF = NL > 0 ? ((NWRl * NM + NL - 1) / NL < NM ? (NWRl * NM + NL - 1) / NL : NM - 1) : NM - 1;   // first j whose steps include the last write
 #pragma unroll
             for (int j = 0; j < NM; ++j) {
                 Bwd3<S, l + 1>::dw_step(j, dW, Aup, Bup);
 #pragma unroll
                 for (int k = (j * NL) / NM; k < ((j + 1) * NL) / NM; ++k) Bwd3<S, l>::issue_step(k, dz, dzf, wl, i16, g, Aop, Bop, Fop);
+                // once this layer's delta image is complete (the image writes are the first NWR issue steps) its N-fringe operands
+                // leave for the AccVGPRs: they arrive under the rest of the dW MFMAs and are used behind the packed FMAs of the fringe
+                // rows below (held any longer -- over the delta step -- the register allocator starts moving dW tiles between the two
+                // register files)
+                if (j == JNF) Bwd3<S, l>::nf_load(NFop, wl, 16 * g + i16);
             }
         }
         SCHED_FENCE();
@@ -776,6 +844,7 @@ struct Pipe3 {
         TSTAMP(11 + 4 * l);
         Bwd3<S, l + 1>::fdw(FP, Fup, Bup);
         FringeDW<S, l>::run(FP, T, dzf, g);
+        Bwd3<S, l>::nf_mfma(dW, NFop);
         TSTAMP(12 + 4 * l);
         if constexpr (l > 0) {
             f32x4 dzp[C::MT(l - 1)];
@@ -797,7 +866,26 @@ template <class S, int l>
 struct SlabOut3 {
     using C = F3Cfg<S>;
     static __device__ __forceinline__ void run(const float* buf, float* __restrict__ slab, int wave, int lane, int t0, int cnt) {
-        constexpr int in = C::in(l), out = C::out(l), MT = C::MTF(l), NT = C::NT(l);
+        constexpr int in = C::in(l), out = C::out(l), MT = C::MTF(l), NT = C::NTF(l);
+        if constexpr (C::NCF(l)) {
+            // the N-fringe tile: lane (b, j) register i = dW[unit 4b + i][slot 16 (NT_all - 1) + 4j] (units of the full tiles: slot == unit)
+            const int t = C::dwfr3(l) - t0;
+            static_assert(C::EP3_TILES == C::DW3_TILES || !C::NCF(l), "the N-fringe pair is staged in one pass");
+            if (t >= 0 && t + 1 < cnt && (t & (FAST_WAVES - 1)) == wave) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(buf) + t * 64 + lane;
+                // (even-row and odd-row accumulators: tiles t and t + 1)
+                const f32x4 c0 = src[0] + src[64], c1 = src[C::EP3_TILES * 64] + src[C::EP3_TILES * 64 + 64],
+                            c2 = src[2 * C::EP3_TILES * 64] + src[2 * C::EP3_TILES * 64 + 64], c3 = src[3 * C::EP3_TILES * 64] + src[3 * C::EP3_TILES * 64 + 64];
+                const int b = lane >> 2, col = unit_of(in, 16 * (C::NT(l) - 1) + 4 * (lane & 3), true);
+                if (b < 4 * MT && col >= 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * b + r;
+                        slab_store<(C::P() >= 2048)>(slab + C::offW(l) + (col < in ? row * in + col : in * out + row), (c0[r] + c1[r]) + (c2[r] + c3[r]));
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1139,9 +1227,15 @@ struct Coop3 {
         if constexpr (C::MTF(l) > 0) {
             if (wave < C::MTF(l)) {
 #pragma unroll
-                for (int nt = 0; nt < C::NT(l); ++nt) {
-                    const int t = C::dwoff3(l) + wave * C::NT(l) + nt - t0;
+                for (int nt = 0; nt < C::NTF(l); ++nt) {
+                    const int t = C::dwoff3(l) + wave * C::NTF(l) + nt - t0;
                     if (t >= 0 && t < cnt) mine[t * 64 + lane] += dWc[cwoff(l) + nt];
+                }
+                if constexpr (C::NCF(l)) {
+                    // the cooperative rounds keep a whole 16x16x4 tile for the last N tile (D layout: lane (i16, g) register r = unit
+                    // 16 wave + 4g + r, slot 16 (NT - 1) + i16); its columns 4j go to lane 4 (4 wave + g) + j of the N-fringe tile
+                    const int t = C::dwfr3(l) - t0, i16 = lane & 15, g = lane >> 4;
+                    if (t >= 0 && t < cnt && (i16 & 3) == 0) mine[t * 64 + 16 * wave + 4 * g + (i16 >> 2)] += dWc[cwoff(l) + C::NTF(l)];
                 }
             }
         }
@@ -1207,6 +1301,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         const long G = gridDim.x, rem = ntiles % W;
         if (rem > 0 && rem <= 2 * G) { main_end = ntiles - rem; ncoop = rem <= G ? 1 : 2; }
     }
+    if constexpr ((TBNN_SKEL & 1) != 0) { main_end = 0; ncoop = 0; }       // diagnostic: the launch's fixed cost
     // the cooperative tiles' rows are fetched now: their latency hides under the whole tile loop
     float xc[2][C::KS0], yc[2][d_out];
 #pragma unroll
@@ -1328,9 +1423,12 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         {
             constexpr int LM = L - 1;
             float Aop[Bwd3<S, LM>::MTd][4], Bop[C::NT(LM)][4], Fop[8];
+            typename Bwd3<S, LM>::NFOps NFop;
             Bwd3<S, LM>::issue(dzp, dzpf, wl, i16, g, Aop, Bop, Fop);
+            Bwd3<S, LM>::nf_load(NFop, wl, lane);
             TSTAMP(32);
             FringeDW<S, LM>::run(FP, T, dzpf, g);
+            Bwd3<S, LM>::nf_mfma(dW, NFop);
             TSTAMP(33);
             if constexpr (LM > 0) {
                 f32x4 dzq[C::MT(LM - 1)];

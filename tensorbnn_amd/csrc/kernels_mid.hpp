@@ -554,7 +554,7 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                 };
                 sfor<0, NMF>(SFOR_LAMBDA(j) {
                     constexpr int j = SFOR_VAL(j), sj = j / (TZ * TAl), tj = (j / TAl) % TZ, uj = j % TAl;
-                    mfma16_acc<(TZ * TAl > 1)>(dW[C::dwoff(l) + tj * TAl + uj], Aop[tj][sj], Bop[uj][sj]);
+                    mfma16_acc<(TZ * TAl > 2)>(dW[C::dwoff(l) + tj * TAl + uj], Aop[tj][sj], Bop[uj][sj]);
                     sfor<mid_ops_before(j, N1, NE, NMF), mid_ops_before(j + 1, N1, NE, NMF)>(SFOR_LAMBDA(e) { under(std::integral_constant<int, SFOR_VAL(e)>{}); });
                     MID_FENCE();
                 });
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
             };
             sfor<0, NMF>(SFOR_LAMBDA(j) {
                 constexpr int j = SFOR_VAL(j), sj = j / (C::MT0 * C::NT0), tj = (j / C::NT0) % C::MT0, uj = j % C::NT0;
-                mfma16_acc<(C::MT0 * C::NT0 > 1)>(dW[C::dwoff(0) + tj * C::NT0 + uj], Aop[tj][sj], Bop[uj][sj]);
+                mfma16_acc<(C::MT0 * C::NT0 > 2)>(dW[C::dwoff(0) + tj * C::NT0 + uj], Aop[tj][sj], Bop[uj][sj]);
                 sfor<mid_ops_before(j, N1, NE, NMF), mid_ops_before(j + 1, N1, NE, NMF)>(SFOR_LAMBDA(e) { under(std::integral_constant<int, SFOR_VAL(e)>{}); });
                 MID_FENCE();
             });

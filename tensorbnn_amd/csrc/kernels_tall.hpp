@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                 for (int t = 0; t < TZ; ++t)
 #pragma unroll
-                    for (int u = 0; u < TAl; ++u) mfma16_acc<ACC_A>(dWm[C::dwoff(l) + t * TAl + u], Aop[t], Bop[u]);
+                    for (int u = 0; u < TAl; ++u) mfma16_acc<(ACC_A && TZ * TAl > 2)>(dWm[C::dwoff(l) + t * TAl + u], Aop[t], Bop[u]);
             }
             // delta_{l-1} = (W_l^T delta_l) * act'(a_l): W^T from the row-major image, strided 4-B reads
             f32x4 acc[MU];
@@ -565,8 +565,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 for (int t = 0; t < MT0; ++t)
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
-                        if (C::FR0 && t == C::MTF) mfma4_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
-                        else mfma16_acc<(ACC_A && MT0 * CH > 1)>(dW0[t * CH + c], Aop[t], Bop[c]);
+                        if (C::FR0 && t == C::MTF) mfma4_acc<(ACC_A && MT0 * CH > 2)>(dW0[t * CH + c], Aop[t], Bop[c]);
+                        else mfma16_acc<(ACC_A && MT0 * CH > 2)>(dW0[t * CH + c], Aop[t], Bop[c]);
                     }
             }
         }
