@@ -116,7 +116,7 @@ struct Tile3 {
 #define TBNN_F3_M4 1
 #endif
 #ifndef TBNN_F3_M4ACC
-#define TBNN_F3_M4ACC 4
+#define TBNN_F3_M4ACC 2      // (4 until round 5; measured at configs[1]: 2 -> +0.5 %, 1 -> -0.2 %)
 #endif
 // prow: this lane's A-operand row (image row 16*MTF + 4*(i16&3), + 4g); tiles: the K dimension in D-layout registers
 template <class S, int K>
@@ -592,8 +592,9 @@ struct Bwd3 {
     }
     static __device__ __forceinline__ void nf_mfma(f32x4 (&dW)[C::DW3_TILES > 0 ? C::DW3_TILES : 1], NFOps& o) {
         if constexpr (NCF) {
-            // two rows per statement, one per accumulator, and the wait states a dependent 4x4x1 needs written out: the next statement
-            // accumulates into acc0 three wait states after this one's first MFMA whatever the compiler puts between the statements
+            // two rows per statement, one per accumulator, and the wait states a dependent 4x4x1 needs written out (two: what the
+            // compiler keeps between dependent 4x4x1 builtins): the next statement accumulates into acc0 behind this one's second MFMA
+            // and the s_nop, whatever the compiler puts between the statements
             f32x4& acc0 = dW[C::dwfr3(l)];
             f32x4& acc1 = dW[C::dwfr3(l) + 1];
 #pragma unroll
@@ -601,10 +602,10 @@ struct Bwd3 {
 #pragma unroll
                 for (int s = 0; s < 4; s += 2) {
                     if (q == 0 && s == 0)
-                        asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mfma_f32_4x4x1_16b_f32 %0, %2, %3, %0\n\tv_mfma_f32_4x4x1_16b_f32 %1, %4, %5, %1\n\ts_nop 1"
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mfma_f32_4x4x1_16b_f32 %0, %2, %3, %0\n\tv_mfma_f32_4x4x1_16b_f32 %1, %4, %5, %1\n\ts_nop 0"
                                      : "+a"(acc0), "+a"(acc1) : "a"(o.A[q][s]), "a"(o.B[q][s]), "a"(o.A[q][s + 1]), "a"(o.B[q][s + 1]));
                     else
-                        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, %0\n\tv_mfma_f32_4x4x1_16b_f32 %1, %4, %5, %1\n\ts_nop 1"
+                        asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %2, %3, %0\n\tv_mfma_f32_4x4x1_16b_f32 %1, %4, %5, %1\n\ts_nop 0"
                                      : "+a"(acc0), "+a"(acc1) : "a"(o.A[q][s]), "a"(o.B[q][s]), "a"(o.A[q][s + 1]), "a"(o.B[q][s + 1]));
                 }
         }
@@ -1413,7 +1414,8 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int o = 0; o < d_out; ++o) dzf[o] = rvalid ? lik_delta<S>(T.af[L][o], y[o], inv_var, g == 0, stat) : 0.f;
         TSTAMP(30);
-        FringeDW<S, L>::run(FP, T, dzf, g);
+        // (the last layer's fringe sums -- a dozen packed FMAs -- wait until the N-fringe operands of layer L-1 are on their way: NCF)
+        if constexpr (!C::NCF(L > 0 ? L - 1 : 0)) FringeDW<S, L>::run(FP, T, dzf, g);
         // delta of layer L-1, then the pipeline
         f32x4 dzL[C::MT(L)];
         f32x4 dzp[C::MT(L - 1)];
@@ -1426,14 +1428,19 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             typename Bwd3<S, LM>::NFOps NFop;
             Bwd3<S, LM>::issue(dzp, dzpf, wl, i16, g, Aop, Bop, Fop);
             Bwd3<S, LM>::nf_load(NFop, wl, lane);
+            if constexpr (C::NCF(LM)) FringeDW<S, L>::run(FP, T, dzf, g);
             TSTAMP(32);
             FringeDW<S, LM>::run(FP, T, dzpf, g);
-            Bwd3<S, LM>::nf_mfma(dW, NFop);
+#ifndef TBNN_F3_NF_LATE
+#define TBNN_F3_NF_LATE 0
+#endif
+            if constexpr (!(TBNN_F3_NF_LATE && LM > 0)) Bwd3<S, LM>::nf_mfma(dW, NFop);
             TSTAMP(33);
             if constexpr (LM > 0) {
                 f32x4 dzq[C::MT(LM - 1)];
                 float dzqf[NFd];
                 Bwd3<S, LM>::da(T, lds, i16, g, dzp, dzpf, dzq, dzqf);
+                if constexpr (TBNN_F3_NF_LATE != 0) Bwd3<S, LM>::nf_mfma(dW, NFop);
                 SCHED_FENCE();
                 TSTAMP(34);
                 Pipe3<S, LM - 1>::run(dW, FP, T, lds, wl, i16, g, dzq, dzqf, Aop, Bop, Fop);
