@@ -11,7 +11,8 @@
 #include "common.hpp"
 #include "update_ops.hpp"
 
-__global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
+template <int UC = UPD_COLS, int UG = UPD_GROUPS>
+__global__ __launch_bounds__(UC * UG) void k_update(
     NetDev nd, int mode, float eps, const float* __restrict__ eta,
     const float* __restrict__ slabs, int nslab, int pitch,
     const float* __restrict__ q_cur, const float* __restrict__ g_cur,
@@ -42,19 +43,19 @@ __global__ __launch_bounds__(UPD_COLS * UPD_GROUPS) void k_update(
     // the prior and the likelihood's sigma, can refresh the cached (log-prob, gradient) of the current state without
     // another pass over the rows (k_refresh_grad_after_hyper) -- and without compounding a rescaling factor over
     // consecutive accepted hyper steps
-    __shared__ float4 part[UPD_GROUPS][UPD_COLS];
+    __shared__ float4 part[UG][UC];
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const int c4 = blockIdx.x * UPD_COLS + tx;          // float4 column
+    const int c4 = blockIdx.x * UC + tx;                // float4 column
     const int jf = c4 * 4 + ty;                         // ty < 4 selects which of the column's 4 parameters this thread finishes
     const bool fin = ty < 4 && jf < nd.P;
     UpdPre u;
     if (fin) upd_prefetch(u, nd, mode, eta, jf, q_cur, g_cur, q, p, imgmap);
     float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (mode != UPD_FIRST) {
-        part[ty][tx] = upd_column_partial(slabs, nslab, pitch, c4, ty);
+        part[ty][tx] = upd_column_partial<UG>(slabs, nslab, pitch, c4, ty);
         __syncthreads();
 #pragma unroll
-        for (int h = UPD_GROUPS / 2; h > 0; h >>= 1) {
+        for (int h = UG / 2; h > 0; h >>= 1) {
             if (ty < h) {
                 const float4 a = part[ty][tx], b = part[ty + h][tx];
                 part[ty][tx] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_lay_pack_x(const float* __restrict__ X,
 template <int MODE, int RB, bool SK, int LAY_TB>
 __global__ __launch_bounds__(256) void k_lay_gemm(
     const float* __restrict__ img, int wpitch, const float* __restrict__ in, int KG, float* __restrict__ outb, int MT,
-    const float* __restrict__ aux, int auxT, long ntiles, int act, int n_units, int ones_slot)
+    const float* __restrict__ aux, int auxT, long ntiles, int act, int n_units, int ones_slot, int rev)
 {
     __shared__ f32x4 part[SK ? 4 * RB * LAY_TB * 64 : 1];
     const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -172,7 +172,10 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
     const long first = SK ? (long)blockIdx.x : (long)blockIdx.x * 4 + wave, stride = SK ? (long)gridDim.x : (long)gridDim.x * 4;
     const int KQ = SK ? (KG + 3) / 4 : KG;
     const int k_lo = SK ? wave * KQ : 0, k_hi = SK ? (k_lo + KQ < KG ? k_lo + KQ : KG) : KG;
-    for (long it = first; it < items; it += stride) {
+    for (long itf = first; itf < items; itf += stride) {
+        // rev: walk the row tiles from the far end -- consecutive GEMMs alternate, so a launch starts on the rows whose blocks the launch
+        // before it touched last (an XCD's L2 still holds that launch's last 4 MB)
+        const long it = rev ? items - 1 - itf : itf;
         const long rp = it / TG; const int t0 = (int)(it - rp * TG) * LAY_TB;
         const long rt0 = rp * RB;
         f32x4 acc[RB][LAY_TB];
@@ -302,29 +305,29 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
 // that leaves most of the 1024 SIMDs without a wave and the fan-in is long enough to pay for the LDS round
 template <int MODE, int LAY_TB>
 static inline void lay_gemm_launch_tb(hipStream_t st, const float* img, int wpitch, const float* in, int KG, float* outb, int MT,
-                                      const float* aux, int auxT, long ntiles, int act, int n_units, int ones_slot) {
+                                      const float* aux, int auxT, long ntiles, int act, int n_units, int ones_slot, int rev) {
     const int TG = (MT + LAY_TB - 1) / LAY_TB;
     const long items1 = ntiles * TG;
     if (items1 >= 4096) {
         const long items = ((ntiles + 1) / 2) * TG;
         hipLaunchKernelGGL((k_lay_gemm<MODE, 2, false, LAY_TB>), dim3((int)std::min<long>((items + 3) / 4, 8192)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
-                           ntiles, act, n_units, ones_slot);
+                           ntiles, act, n_units, ones_slot, rev);
     } else if (items1 < 1024 && KG >= 8) {
         hipLaunchKernelGGL((k_lay_gemm<MODE, 1, true, LAY_TB>), dim3((int)std::max<long>(1, items1)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
-                           ntiles, act, n_units, ones_slot);
+                           ntiles, act, n_units, ones_slot, rev);
     } else {
         hipLaunchKernelGGL((k_lay_gemm<MODE, 1, false, LAY_TB>), dim3((int)std::max<long>(1, (items1 + 3) / 4)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
-                           ntiles, act, n_units, ones_slot);
+                           ntiles, act, n_units, ones_slot, rev);
     }
 }
 
 // output tiles per item: 4, or all of them when the layer has only 1 or 2 (a 20-unit layer would otherwise issue its MFMAs twice)
 template <int MODE>
 static inline void lay_gemm_launch(hipStream_t st, const float* img, int wpitch, const float* in, int KG, float* outb, int MT,
-                                   const float* aux, int auxT, long ntiles, int act, int n_units, int ones_slot) {
-    if (MT == 1) lay_gemm_launch_tb<MODE, 1>(st, img, wpitch, in, KG, outb, MT, aux, auxT, ntiles, act, n_units, ones_slot);
-    else if (MT == 2) lay_gemm_launch_tb<MODE, 2>(st, img, wpitch, in, KG, outb, MT, aux, auxT, ntiles, act, n_units, ones_slot);
-    else lay_gemm_launch_tb<MODE, 4>(st, img, wpitch, in, KG, outb, MT, aux, auxT, ntiles, act, n_units, ones_slot);
+                                   const float* aux, int auxT, long ntiles, int act, int n_units, int ones_slot, int rev) {
+    if (MT == 1) lay_gemm_launch_tb<MODE, 1>(st, img, wpitch, in, KG, outb, MT, aux, auxT, ntiles, act, n_units, ones_slot, rev);
+    else if (MT == 2) lay_gemm_launch_tb<MODE, 2>(st, img, wpitch, in, KG, outb, MT, aux, auxT, ntiles, act, n_units, ones_slot, rev);
+    else lay_gemm_launch_tb<MODE, 4>(st, img, wpitch, in, KG, outb, MT, aux, auxT, ntiles, act, n_units, ones_slot, rev);
 }
 
 // likelihood (restated as in kernels_generic.hpp): statistic (Gaussian: sum of squared residuals; Bernoulli: log-prob) and
@@ -613,10 +616,12 @@ __global__ __launch_bounds__(256) void k_lay_unpack_f(const float* __restrict__ 
 }
 
 // the forward chain: a_0 (packed) -> ... -> f
+// consecutive GEMMs walk the row tiles in alternating directions (TBNN_LAY_ALT=0: all forwards, as before round 5)
+static inline int lay_alt() { static const int v = [] { const char* e = getenv("TBNN_LAY_ALT"); return e ? atoi(e) : 1; }(); return v; }
 static inline void lay_forward_chain(const NetDev& nd, const LayPlan& p, hipStream_t st, const float* img, float* store) {
     for (int l = 0; l < nd.nl; ++l)
         lay_gemm_launch<0>(st, img + p.wOff[l], 16 * p.TK[l], store + p.aOff[l], p.TK[l], store + p.aOff[l + 1], p.TO[l], nullptr, 0, p.ntiles,
-                           nd.act[l], nd.out[l], l + 1 == nd.nl ? -1 : nd.out[l]);
+                           nd.act[l], nd.out[l], l + 1 == nd.nl ? -1 : nd.out[l], lay_alt() ? (l & 1) : 0);
 }
 // one gradient: forward chain, likelihood, delta chain, dW slabs (p.NS slabs of `pitch` floats; pstat[p.NP])
 static inline int lay_launch(const NetDev& nd, const LayPlan& p, hipStream_t st, const float* img, const float* eta, const float* Y, long n,
@@ -626,7 +631,7 @@ static inline int lay_launch(const NetDev& nd, const LayPlan& p, hipStream_t st,
     if (p.tail) {
         for (int l = 0; l < p.l0; ++l)
             lay_gemm_launch<0>(st, img + p.wOff[l], 16 * p.TK[l], store + p.aOff[l], p.TK[l], store + p.aOff[l + 1], p.TO[l], nullptr, 0, p.ntiles,
-                               nd.act[l], nd.out[l], nd.out[l]);
+                               nd.act[l], nd.out[l], nd.out[l], lay_alt() ? (l & 1) : 0);
         if (p.TT == 2) hipLaunchKernelGGL(k_lay_tail<2>, dim3(p.GT), dim3(256), 0, st, nd, p, img, eta, Y, n, store, pstat);
         else hipLaunchKernelGGL(k_lay_tail<4>, dim3(p.GT), dim3(256), 0, st, nd, p, img, eta, Y, n, store, pstat);
         lb = (p.l0 > 1 ? p.l0 : 1) - 1;
@@ -635,9 +640,10 @@ static inline int lay_launch(const NetDev& nd, const LayPlan& p, hipStream_t st,
         hipLaunchKernelGGL(k_lay_lik, dim3(p.NLK), dim3(256), 0, st, nd, eta, (const float*)(store + p.aOff[nd.nl]), Y, n, p.TM[L], store + p.dOff[L], pstat);
         lb = L;
     }
+    // (the forward chain's last GEMM walked in direction (nl - 1) & 1; the likelihood kernel is a plain forward sweep)
     for (int l = lb; l >= 1; --l)
         lay_gemm_launch<1>(st, img + p.tOff[l], 16 * p.TM[l], store + p.dOff[l], p.TM[l], store + p.dOff[l - 1], p.TM[l - 1], store + p.aOff[l], p.TK[l],
-                           p.ntiles, nd.act[l - 1], nd.out[l - 1], -1);
+                           p.ntiles, nd.act[l - 1], nd.out[l - 1], -1, lay_alt() ? ((lb - l + 1) & 1) : 0);
     hipLaunchKernelGGL(k_lay_dw, dim3(p.NS, p.NY), dim3(256), 0, st, nd, p, (const float*)store, slabs, pitch);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -578,7 +578,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         if constexpr (C::DWM_TILES > 0) mfma_drain_acc(dWm);
     }
     float* slab = slabs + (size_t)blockIdx.x * pitch;
-    constexpr bool WT = C::P() >= 2048;
+#ifndef TALL_WT
+#define TALL_WT 1
+#endif
+    constexpr bool WT = TALL_WT && C::P() >= 2048;
     // ---- dW_0: every wave writes its own column tiles.  D layout: lane (n = i16, g) reg r = dW[out slot 16t+4g+r][column 16kt+n]:
     // a lane's four registers are four ROWS of the slab.  With 16-B aligned rows the tiles of one M tile are turned through the
     // wave's own share of the staging area (the exchange buffer, dead by now; written [m][n], read back lane-linearly: lane l holds row

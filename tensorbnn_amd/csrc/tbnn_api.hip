@@ -740,12 +740,18 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta, const S
     return 0;
 }
 static void launch_update(tbnn_ctx* h, int mode, float eps, const float* eta, float* q, float* g, const StepCtl* ctl = nullptr, int t = 0) {
-    const int gx = (h->pitch / 4 + UPD_COLS - 1) / UPD_COLS;
+    const bool big = h->nd.P >= UPD_BIG_P;             // block geometry by parameter count (update_ops.hpp)
+    const int ucols = big ? UPD_COLS_BIG : UPD_COLS;
+    const int gx = (h->pitch / 4 + ucols - 1) / ucols;
     const bool img = h->kernel == TBNN_KERNEL_FAST && q == h->q;
     // the data-term gradient goes with its state: the proposal's (h->gd) or, for the bootstrap evaluation, the current one's
     float* gd = g == h->g_cur ? h->gd_cur : (g == h->g ? h->gd : nullptr);
-    hipLaunchKernelGGL(k_update, dim3(gx, h->C), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, h->nd, mode, eps, eta, grad_slabs(h), grad_nslab(h),
-                       h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg, gd, h->img_floats, ctl, t);
+    if (big)
+        hipLaunchKernelGGL((k_update<UPD_COLS_BIG, UPD_GROUPS_BIG>), dim3(gx, h->C), dim3(UPD_COLS_BIG, UPD_GROUPS_BIG), 0, h->stream, h->nd, mode, eps, eta,
+                           grad_slabs(h), grad_nslab(h), h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg, gd, h->img_floats, ctl, t);
+    else
+        hipLaunchKernelGGL((k_update<UPD_COLS, UPD_GROUPS>), dim3(gx, h->C), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, h->nd, mode, eps, eta, grad_slabs(h),
+                           grad_nslab(h), h->pitch, h->q_cur, h->g_cur, q, h->p, g, img ? h->imgmap : nullptr, h->qimg, gd, h->img_floats, ctl, t);
     if (img && (mode == UPD_FIRST || mode == UPD_MID)) h->q_img_valid = true;
 }
 static void launch_energy(tbnn_ctx* h, int which, const float* eta, const float* q, double* slot) {
@@ -789,7 +795,7 @@ extern "C" int tbnn_logp_grad(tbnn_handle h, const float* theta, const float* et
     int rc = launch_fwd_bwd(h, dq, de);
     if (rc) return rc;
     const int gx = (h->pitch / 4 + UPD_COLS - 1) / UPD_COLS;
-    hipLaunchKernelGGL(k_update, dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, nd, (int)UPD_GRAD_ONLY, 0.f, de, grad_slabs(h), grad_nslab(h),
+    hipLaunchKernelGGL((k_update<UPD_COLS, UPD_GROUPS>), dim3(gx), dim3(UPD_COLS, UPD_GROUPS), 0, h->stream, nd, (int)UPD_GRAD_ONLY, 0.f, de, grad_slabs(h), grad_nslab(h),
                        h->pitch, h->q_cur, h->g_cur, const_cast<float*>(dq), h->p, h->tmp, (const int*)nullptr, (float*)nullptr, (float*)nullptr);
     // EN_TRACE leaves the chain's scalar record alone; stat comes from the slabs
     if (!h->trace || h->trace_cap < 2) {

@@ -45,6 +45,12 @@ __device__ __forceinline__ float prior_grad(int prior, float loc, float scale, f
 #ifndef UPD_GROUPS
 #define UPD_GROUPS 32  // slab groups per block
 #endif
+// networks with many parameters (P >= UPD_BIG_P: the tall-fan-in family's 784 -> 20 -> 20 -> 1 has 15.7 k, its k_update reads 16 MB of
+// slabs): 32 columns x 16 groups per block -- measured on that shape (round 5): 16 x 32: 33.35 k leapfrog steps/s, 32 x 16: 34.3 k,
+// 32 x 32: 34.0 k, 64 x 16: 33.3 k, 64 x 8: 32.4 k, 128 x 8: 30.5 k, 8 x 32: 32.6 k; configs[3] / [4] (12.4 k / 82.8 k): no difference
+#define UPD_BIG_P 8192
+#define UPD_COLS_BIG 32
+#define UPD_GROUPS_BIG 16
 
 // what a finishing thread (one parameter) needs besides the reduced gradient; fetched BEFORE the slab loads: one memory
 // round trip instead of two on the critical path of a leapfrog step
@@ -61,17 +67,19 @@ __device__ __forceinline__ void upd_prefetch(UpdPre& u, const NetDev& nd, int mo
     if (imgmap && (mode == UPD_FIRST || mode == UPD_MID)) { u.m0 = imgmap[jf]; u.m1 = imgmap[nd.P + jf]; }
 }
 // one thread's share of a float4 column: slabs ty, ty + 32, ... in a fixed order, 8 independent 16-B loads in flight
+template <int UPD_GROUPS_T = UPD_GROUPS>
 __device__ __forceinline__ float4 upd_column_partial(const float* slabs, int nslab, int pitch, int c4, int ty) {
+    constexpr int UG = UPD_GROUPS_T;
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 s0 = z, s1 = z, s2 = z, s3 = z;
     if (c4 * 4 < pitch) {
         const float4* base = reinterpret_cast<const float4*>(slabs) + c4;
         const int p4 = pitch >> 2;
         int w = ty;
-        for (; w + 7 * UPD_GROUPS < nslab; w += 8 * UPD_GROUPS) {
+        for (; w + 7 * UG < nslab; w += 8 * UG) {
             float4 v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(w + k * UPD_GROUPS) * p4];
+            for (int k = 0; k < 8; ++k) v[k] = base[(size_t)(w + k * UG) * p4];
 #pragma unroll
             for (int k = 0; k < 8; k += 4) {
                 s0.x += v[k].x; s0.y += v[k].y; s0.z += v[k].z; s0.w += v[k].w;
@@ -80,7 +88,7 @@ __device__ __forceinline__ float4 upd_column_partial(const float* slabs, int nsl
                 s3.x += v[k + 3].x; s3.y += v[k + 3].y; s3.z += v[k + 3].z; s3.w += v[k + 3].w;
             }
         }
-        for (; w < nslab; w += UPD_GROUPS) {
+        for (; w < nslab; w += UG) {
             const float4 a = base[(size_t)w * p4];
             s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
         }

@@ -132,8 +132,8 @@ def test_log_accept_ratio_band_against_fp64(native):
     """Which arm is off when a burned-in log accept ratio differs between the HIP path and oracle/c?  Ten free-running
     configs[1] epochs (n = 1e5, L = 10) from the burned-in state; every epoch's trajectory is also integrated by the fp64
     NumPy oracle from the HIP chain's own start state, and both fp32 arms are compared with it SEPARATELY against the stated
-    tolerance 2e-2 + 1e-4 |lar| + 1e-6 |logp| (lar is a difference of two fp32-evaluated log-probs of
-    magnitude 1e5); the HIP path (fp32 rows, every energy summed in fp64) is also held to twice the bare band."""
+    band 2e-2 + 1e-4 |lar| (BASELINE.md section 5 adds 1e-6 |logp| -- lar is a difference of two fp32-evaluated log-probs of
+    magnitude 1e5 -- which these epochs do not need)."""
     spec, X, Y, theta, eta = o.synth_problem([5, 50, 50, 50, 1], 100_000)
     z = np.load(os.path.join(GOLDEN, "c2_burned.npz"))
     theta, eta, eps = z["theta"].astype(np.float32), z["eta"].astype(np.float32), float(z["eps"])
@@ -156,12 +156,11 @@ def test_log_accept_ratio_band_against_fp64(native):
     print("lar (fp64)            :", np.array2string(rows[:, 0], precision=3))
     print("HIP - fp64            :", np.array2string(rows[:, 1], precision=4), "max / band", float(np.max(np.abs(rows[:, 1]) / band)))
     print("oracle/c - fp64       :", np.array2string(rows[:, 2], precision=4), "max / band", float(np.max(np.abs(rows[:, 2]) / band)))
-    # both fp32 arms against the stated tolerance, lar_tol() = band + 1e-6 |logp|.  (The HIP arm alone stays inside the bare band on
-    # most realisations of the synthetic data -- the data come out of an fp32 NumPy matmul and change in the last bit with the BLAS
-    # thread count -- but not on all: with 8 OpenBLAS threads one of the ten epochs reaches 1.36 x the bare band, 2.7e-7 of |logp|.)
-    tol = np.array([lar_tol(r[0], r[3]) for r in rows])
-    assert np.all(np.abs(rows[:, 1]) <= tol) and np.all(np.abs(rows[:, 1]) <= 2.0 * band), rows
-    assert np.all(np.abs(rows[:, 2]) <= tol), rows
+    # both fp32 arms inside the BARE band 2e-2 + 1e-4 |lar| (no |logp| term).  Until round 5 the synthetic targets came out of an fp32
+    # NumPy matmul whose last bits followed the BLAS thread count, and on one realisation an epoch of the HIP arm reached 1.36 x the band;
+    # with the targets synthesised in fp64 and rounded once (oracle.synth_problem) the worst of these ten epochs is 0.36 x the band.
+    assert np.all(np.abs(rows[:, 1]) <= band), rows
+    assert np.all(np.abs(rows[:, 2]) <= band), rows
     ch.close()
 
 
