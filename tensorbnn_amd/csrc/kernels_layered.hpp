@@ -99,7 +99,7 @@ static inline void lay_plan_rows(const NetDev& nd, long n, LayPlan& p) {
     for (int l = 0; l <= nd.nl; ++l) { p.aOff[l] = o; o += p.ntiles * 256 * (l < nd.nl ? p.TK[l] : p.TM[nd.nl - 1]); }
     for (int l = 0; l < nd.nl; ++l) { p.dOff[l] = o; o += p.ntiles * 256 * p.TM[l]; }
     p.store_floats = o;
-    p.NLK = (int)std::max<long>(1, std::min<long>(256, p.ntiles / 8));
+    p.NLK = (int)std::max<long>(1, std::min<long>(256, (p.ntiles * 16 * nd.d_out + 255) / 256));         // (row, output) elements per thread: ~1
     p.dw_items = 0;
     for (int l = 0; l < nd.nl; ++l) p.dw_items += lay_cdiv(p.TM[l], LAY_DBU) * lay_cdiv(p.TK[l], LAY_DBK);       // tile blocks (k_lay_dw)
     // k_lay_dw's grid: NY workgroups share out the tile blocks (one block per wave when that takes at most 16 of them), NS row
@@ -303,12 +303,24 @@ __global__ __launch_bounds__(256) void k_lay_gemm(
 }
 // launch one GEMM: two row tiles per item when there is plenty of work, one otherwise; split K over the workgroup when even
 // that leaves most of the 1024 SIMDs without a wave and the fan-in is long enough to pay for the LDS round
+// two row tiles per wave from this many (row tile, tile group) items on (TBNN_LAY_RB2: A/B runs).  Round 5: 4096 -> 1024.  784 -> 100 at
+// n = 12 k is 1,500 items: with one row tile per wave 52 us, with two 31 us -- a k-group's operand loads feed 32 MFMAs instead of 16 (the
+// whole 784 -> 100 -> 100 -> 10 gradient 125 -> 105 us); four row tiles per wave were slower at every size tried (8 -> 300 -> 300 -> 1: 357 -> 390 us),
+// and so was sharing a tile group's weights across the waves of a workgroup through LDS (one barrier per k-group: 105 -> 131 us)
+static inline long lay_rb2_items() { static const long v = [] { const char* e = getenv("TBNN_LAY_RB2"); return e ? atol(e) : 1024L; }(); return v; }
 template <int MODE, int LAY_TB>
 static inline void lay_gemm_launch_tb(hipStream_t st, const float* img, int wpitch, const float* in, int KG, float* outb, int MT,
                                       const float* aux, int auxT, long ntiles, int act, int n_units, int ones_slot, int rev) {
     const int TG = (MT + LAY_TB - 1) / LAY_TB;
     const long items1 = ntiles * TG;
-    if (items1 >= 4096) {
+    // (TBNN_LAY_SK2=0: off.  784 -> 100 at n = 12 k: 31 -> 27 us; the 784 -> 100 -> 100 -> 10 gradient 100.6 -> 96.8 us)
+    static const int sk2 = [] { const char* e = getenv("TBNN_LAY_SK2"); return e ? atoi(e) : 1; }();
+    if (sk2 && items1 >= lay_rb2_items() && items1 < 4096 && KG >= 16) {
+        // two row tiles per item AND the k-groups split over the workgroup's four waves: a long fan-in in front of few row tiles
+        const long items = ((ntiles + 1) / 2) * TG;
+        hipLaunchKernelGGL((k_lay_gemm<MODE, 2, true, LAY_TB>), dim3((int)std::max<long>(1, items)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
+                           ntiles, act, n_units, ones_slot, rev);
+    } else if (items1 >= lay_rb2_items()) {
         const long items = ((ntiles + 1) / 2) * TG;
         hipLaunchKernelGGL((k_lay_gemm<MODE, 2, false, LAY_TB>), dim3((int)std::min<long>((items + 3) / 4, 8192)), dim3(256), 0, st, img, wpitch, in, KG, outb, MT, aux, auxT,
                            ntiles, act, n_units, ones_slot, rev);
@@ -340,11 +352,15 @@ __global__ __launch_bounds__(256) void k_lay_lik(NetDev nd, const float* __restr
     const float inv_var = 1.f / (sigma * sigma);
     const int lact = nd.act[nd.nl - 1];
     double stat = 0.0;
-    for (long row = (long)blockIdx.x * 256 + threadIdx.x; row < n; row += (long)gridDim.x * 256) {
-        const size_t base = (size_t)(row >> 4) * TMl * 256 + (row & 15) * 16;
-        for (int o = 0; o < nd.d_out; ++o) {
-            const size_t e = base + (size_t)(o >> 4) * 256 + (o & 15);
-            const float fi = f[e], y = Y[row * nd.d_out + o];
+    // one thread per (row, output) element: with many outputs a thread per ROW ran the library logarithms of all of them one after the
+    // other (784 -> 100 -> 100 -> 10 at n = 12 k: 9.6 us for 120 k elements)
+    const long nel = n * nd.d_out;
+    for (long el = (long)blockIdx.x * 256 + threadIdx.x; el < nel; el += (long)gridDim.x * 256) {
+        const long row = el / nd.d_out;
+        {
+            const int o = (int)(el - row * nd.d_out);
+            const size_t e = (size_t)(row >> 4) * TMl * 256 + (row & 15) * 16 + (size_t)(o >> 4) * 256 + (o & 15);
+            const float fi = f[e], y = Y[el];
             float da;
             if (nd.lik == TBNN_LIK_BERNOULLI) {
                 const float p = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);     // likelihood.py:226-231

@@ -38,6 +38,9 @@ def scaled_problem(dims, n, acts, prior, lik, seed=0):
 
 CASES = {
     "mnist_like": ([784, 20, 20, 1], 1500, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_BERNOULLI),     # split-K GEMMs
+    # 784 -> 100 -> 100 -> 10 (network.add takes any stack, network.py:173-191): 10 outputs on the tile likelihood; at 6,000 rows the first
+    # layer's GEMM has 1,500 (row tile, tile group) items: two row tiles per item AND the k-groups split over the workgroup (round 5)
+    "ten_class": ([784, 100, 100, 10], 6000 + 3, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_BERNOULLI),
     "tabular100": ([100, 50, 50, 1], 3000 + 5, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
     "tabular100_big": ([100, 50, 50, 1], 70000 + 9, [o.ACT_RELU, o.ACT_RELU], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),   # two row tiles per wave
     "mixed_acts": ([4, 8, 8, 1], 777, [o.ACT_RELU, o.ACT_TANH], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),

@@ -61,10 +61,13 @@ for w, names in PASS.items():
         # launches of one pass: the kernels of the c2 / c4 / c5 / mn passes run once per pass; a layered gradient launches some
         # kernels several times (one GEMM per layer), so weight every kernel by launches / passes (passes = the rarest kernel's count)
         passes = min(s["launches"] for s in stats.values())
-        us = sum(s["median_us"] * s["launches"] / passes for s in stats.values())
-        kernel_us[w] = {"us": round(us, 3), "statistic": "sum over the pass's kernels of median launch duration x launches per pass",
+        # a kernel launched once per pass: its median; one launched several times per pass with different shapes (the layered GEMMs:
+        # a median over unlike launches means nothing): 1 %-trimmed mean x launches per pass
+        per_pass = lambda s: s["median_us"] if s["launches"] == passes else s["trimmed_mean_us"] * s["launches"] / passes
+        us = sum(per_pass(s) for s in stats.values())
+        kernel_us[w] = {"us": round(us, 3), "statistic": "sum over the pass's kernels of the median launch duration (kernels launched several times per pass: 1 %-trimmed mean x launches per pass)",
                         "mean_us": round(sum(s["mean_us"] * s["launches"] / passes for s in stats.values()), 3),
-                        "kernels": {k: s["median_us"] for k, s in stats.items()}, "detail": stats, "passes": passes,
+                        "kernels": {k: round(per_pass(s), 3) for k, s in stats.items()}, "detail": stats, "passes": passes,
                         "others": {k: robust(v) for k, v in dur.items() if k not in sel and len(v) > 5},
                         "source": f"profiles/{tag}_{w}_kernel_stats.csv + per-dispatch trace (medians: profiles/{tag}_rocprof_kernel_us.json)"}
     else:
@@ -88,10 +91,10 @@ for w, names in PASS.items():
     if acc:
         summ = {}
         for (k, c), (v, n) in sorted(acc.items()):
-            summ.setdefault(k, {})[c] = {"mean_per_launch": v / n, "launches": n}
+            if n > 5:                      # (one-off kernels -- the layered family packs the rows once per data set -- are not part of a pass)
+                summ.setdefault(k, {})[c] = {"mean_per_launch": v / n, "launches": n}
         json.dump(summ, open(os.path.join(out, f"{w}_pmc_summary.json"), "w"), indent=1)
         # per PASS: a kernel launched several times per pass (layered GEMMs) counts launches / passes times
-        passes = min(c["launches"] for k in summ for c in summ[k].values())
         rd = sum(2.0 * 1024 * summ[k]["FETCH_SIZE"]["mean_per_launch"] * summ[k]["FETCH_SIZE"]["launches"] for k in summ if "FETCH_SIZE" in summ[k])
         wr = sum(1024.0 * summ[k]["WRITE_SIZE"]["mean_per_launch"] * summ[k]["WRITE_SIZE"]["launches"] for k in summ if "WRITE_SIZE" in summ[k])
         prd = min([summ[k]["FETCH_SIZE"]["launches"] for k in summ if "FETCH_SIZE" in summ[k]] or [1])
