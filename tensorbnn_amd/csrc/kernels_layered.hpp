@@ -49,6 +49,10 @@ struct LayPlan {
     int GT;                           // its grid; NP = entries of the statistic buffer in use = max(NS, GT)
     int NP;
     int tail;                         // this data set runs the tail (set per data set: lay_plan_rows)
+    // round 5: a last layer of ONE output tile (<= 16 outputs) behind a layer too wide for the tail above (up to 8 tiles = 127 units + ones
+    // slot): its forward GEMM, the likelihood and the first backward GEMM as one launch (k_lay_last) -- three ~5-us launches otherwise
+    int last_ok;                      // the shape allows it (lay_plan_shape)
+    int last;                         // this data set runs it (lay_plan_rows)
 };
 
 // a result tile's 16 bytes per lane.  Every block this family stores is read by a LATER kernel, and between two kernels this part
@@ -85,6 +89,9 @@ static inline void lay_plan_shape(const NetDev& nd, LayPlan& p) {
     for (int l = p.l0; l < nd.nl; ++l) if (p.TK[l] > 2 || p.TO[l] > 2 || p.TM[l] > 2 || (l >= 1 && p.TM[l - 1] > 2)) p.TT = 4;
     if (const char* e = getenv("TBNN_LAY_TAIL")) if (atoi(e) == 0) p.l0 = nd.nl;       // A/B runs: one launch per layer and direction
     p.GT = 1; p.NP = 1; p.tail = 0;
+    p.last = 0;
+    p.last_ok = p.l0 == nd.nl && nd.nl >= 2 && p.TM[nd.nl - 1] == 1 && p.TK[nd.nl - 1] <= 8 && p.TM[nd.nl - 2] <= 8;
+    if (const char* e = getenv("TBNN_LAY_LAST")) if (atoi(e) == 0) p.last_ok = 0;       // A/B runs
 }
 // k_lay_dw's tile blocks: LAY_DBU output tiles x LAY_DBK input tiles per wave.  The kernel is bound by operand traffic (an operand
 // block feeds LAY_DBK resp. LAY_DBU MFMAs per k-step): 4 x 4 blocks load 0.5 blocks per MFMA.  8 x 4 blocks (0.375; -DLAY_DBU=8)
@@ -121,7 +128,8 @@ static inline void lay_plan_rows(const NetDev& nd, long n, LayPlan& p) {
     const long rounds = std::max<long>(1, (p.ntiles + cap - 1) / cap);
     p.GT = (int)std::min<long>(PSTAT_CAP, std::max<long>(1, (p.ntiles + 4 * rounds - 1) / (4 * rounds)));
     p.tail = p.l0 < nd.nl && p.ntiles < cap;       // it saves launches; over many rows the separate GEMMs are as fast (measured: r03_notes)
-    p.NP = p.tail ? std::max(p.NLK, p.GT) : p.NLK;
+    p.last = p.last_ok && !p.tail && p.ntiles < cap;
+    p.NP = (p.tail || p.last) ? std::max(p.NLK, p.GT) : p.NLK;
 }
 // theta index j -> image positions: map[j] (W_l, biases in the ones-slot column), map[P + j] (W_l^T; -1: none)
 static inline void lay_image_map(const NetDev& nd, const LayPlan& p, int* map) {
@@ -342,6 +350,19 @@ static inline void lay_gemm_launch(hipStream_t st, const float* img, int wpitch,
     else lay_gemm_launch_tb<MODE, 4>(st, img, wpitch, in, KG, outb, MT, aux, auxT, ntiles, act, n_units, ones_slot, rev);
 }
 
+// BernoulliLikelihood of one (row, output) element (likelihood.py:226-236: p clipped to [1e-8, 1 - 1e-7]; tfd.Bernoulli.log_prob =
+// xlogy(y, p) + xlog1py(1 - y, -p)): adds the log-probability to stat, returns d/df.  Hardware log2 / reciprocal (about 1 ulp), as in the
+// fused families' lik_delta (kernels_fast.hpp): the library logf / log1pf / IEEE divisions are some 300 instructions per element -- with ten
+// outputs per row they were half of the last layer's launch (784 -> 100 -> 100 -> 10: k_lay_last 12.7 us)
+__device__ __forceinline__ float lay_bernoulli(float fi, float y, double& stat) {
+    const float p = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f), q = 1.f - p;
+    const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
+    const float t1 = (y == 0.f) ? 0.f : y * __logf(p);
+    const float t2 = (1.f - y == 0.f) ? 0.f : (1.f - y) * __logf(q);
+    stat += (double)(t1 + t2);
+    return inside ? (y * __builtin_amdgcn_rcpf(p) - (1.f - y) * __builtin_amdgcn_rcpf(q)) : 0.f;
+}
+
 // likelihood (restated as in kernels_generic.hpp): statistic (Gaussian: sum of squared residuals; Bernoulli: log-prob) and
 // dz of the last layer = dL/df * act'(f).  f, dz: blocks [row tile][TMl][16][16]; one thread per data row.  Only the real
 // (row, output) entries of dz are written: the padding was zeroed when the store was allocated and nothing else writes it.
@@ -363,12 +384,7 @@ __global__ __launch_bounds__(256) void k_lay_lik(NetDev nd, const float* __restr
             const float fi = f[e], y = Y[el];
             float da;
             if (nd.lik == TBNN_LIK_BERNOULLI) {
-                const float p = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);     // likelihood.py:226-231
-                const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
-                const float t1 = (y == 0.f) ? 0.f : y * logf(p);          // tfd.Bernoulli.log_prob = xlogy(y,p) + xlog1py(1-y,-p)
-                const float t2 = (1.f - y == 0.f) ? 0.f : (1.f - y) * log1pf(-p);
-                stat += (double)(t1 + t2);
-                da = inside ? (y / p - (1.f - y) / (1.f - p)) : 0.f;
+                da = lay_bernoulli(fi, y, stat);
             } else {
                 const float res = y - fi;                                   // likelihood.py:88-94
                 stat += (double)res * (double)res;
@@ -557,12 +573,7 @@ __global__ __launch_bounds__(256) void k_lay_tail(NetDev nd, LayPlan p, const fl
                         const float fi = a[t][j], y = Y[row * nd.d_out + o];
                         float da;
                         if (nd.lik == TBNN_LIK_BERNOULLI) {
-                            const float pr = fminf(fmaxf(fi, 1e-8f), 1.f - 1e-7f);    // likelihood.py:226-231
-                            const bool inside = (fi > 1e-8f) && (fi < 1.f - 1e-7f);
-                            const float t1 = (y == 0.f) ? 0.f : y * logf(pr);
-                            const float t2 = (1.f - y == 0.f) ? 0.f : (1.f - y) * log1pf(-pr);
-                            stat += (double)(t1 + t2);
-                            da = inside ? (y / pr - (1.f - y) / (1.f - pr)) : 0.f;
+                            da = lay_bernoulli(fi, y, stat);
                         } else {
                             const float res = y - fi;                                  // likelihood.py:88-94
                             stat += (double)res * (double)res;
@@ -619,6 +630,92 @@ __global__ __launch_bounds__(256) void k_lay_tail(NetDev nd, LayPlan p, const fl
     if (threadIdx.x == 0) pstat[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The last layer alone (LayPlan::last): one wave takes a row tile through a_L -> f (one output tile, fan-in of up to 8 tiles), the
+// likelihood, dz_L and dz_{L-1} = (W_L^T dz_L) * act'_{L-1}(a_L) -- a_L stays in registers for act'.  Stores f, dz_L, dz_{L-1}.
+__global__ __launch_bounds__(256) void k_lay_last(NetDev nd, LayPlan p, const float* __restrict__ img, const float* __restrict__ eta,
+                                                  const float* __restrict__ Y, long n, float* __restrict__ store, double* __restrict__ pstat) {
+    constexpr int TK8 = 8;
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float sigma = lik_sigma(nd, eta);
+    const float inv_var = 1.f / (sigma * sigma);
+    const int L = p.nl - 1, lact = nd.act[L], lane_off = i16 * 16 + 4 * g;
+    const int KG = p.TK[L], wp = 16 * KG, MTp = p.TM[L - 1], outp = nd.out[L - 1], actp = nd.act[L - 1];
+    // the weights, once per wave: W_L rows (A operand of the forward tile) and W_L^T (A operand of the delta step; its k dimension is the
+    // one output tile: pitch 16)
+    f32x4 Af[TK8], Ab[TK8];
+    {
+        const float* w = img + p.wOff[L] + (size_t)i16 * wp + 4 * g;
+        const float* wt = img + p.tOff[L] + (size_t)i16 * 16 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < TK8; ++t) {
+            Af[t] = *reinterpret_cast<const f32x4*>(w + 16 * (t < KG ? t : KG - 1));
+            Ab[t] = *reinterpret_cast<const f32x4*>(wt + (size_t)(16 * (t < MTp ? t : MTp - 1)) * 16);
+        }
+    }
+    double stat = 0.0;
+    for (long rt = (long)blockIdx.x * 4 + wave; rt < p.ntiles; rt += (long)gridDim.x * 4) {
+        f32x4 a[TK8];
+        {
+            const float* ab = store + p.aOff[L] + (size_t)rt * KG * 256 + lane_off;
+#pragma unroll
+            for (int t = 0; t < TK8; ++t) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ab + (t < KG ? t : KG - 1) * 256);
+                a[t] = t < KG ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};          // two chains: even / odd k-groups
+#pragma unroll
+        for (int kg = 0; kg < TK8; kg += 2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = mfma16(Af[kg][j], a[kg][j], acc0);                       // a[kg] == 0 for kg >= KG
+                acc1 = mfma16(Af[kg + 1][j], a[kg + 1][j], acc1);
+            }
+        f32x4 f, dz;
+        const long row = rt * 16 + i16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = 4 * g + j;
+            f[j] = o < nd.d_out ? act_fwd(acc0[j] + acc1[j], lact) : 0.f;
+            float d = 0.f;
+            if (row < n && o < nd.d_out) {
+                const float fi = f[j], y = Y[row * nd.d_out + o];
+                float da;
+                if (nd.lik == TBNN_LIK_BERNOULLI) {
+                    da = lay_bernoulli(fi, y, stat);
+                } else {
+                    const float res = y - fi;                                  // likelihood.py:88-94
+                    stat += (double)res * (double)res;
+                    da = res * inv_var;
+                }
+                d = da * act_bwd(fi, lact);
+            }
+            dz[j] = d;
+        }
+        lay_block_store(store + p.aOff[L + 1] + (size_t)rt * 256 + lane_off, f);
+        lay_block_store(store + p.dOff[L] + (size_t)rt * 256 + lane_off, dz);
+        float* db = store + p.dOff[L - 1] + (size_t)rt * MTp * 256 + lane_off;
+#pragma unroll
+        for (int t = 0; t < TK8; ++t) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = mfma16(Ab[t][j], dz[j], acc);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int u = 16 * t + 4 * g + j;
+                v[j] = (t < MTp && u < outp) ? acc[j] * act_bwd(a[t][j], actp) : 0.f;
+            }
+            if (t < MTp) lay_block_store(db + t * 256, v);
+        }
+    }
+    const double wtot = wave_sum(stat);
+    if (lane == 0) red[wave] = wtot;
+    __syncthreads();
+    if (threadIdx.x == 0) pstat[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // network output f blocks -> fout[d_out][n] (network.predict, network.py:141-171)
 __global__ __launch_bounds__(256) void k_lay_unpack_f(const float* __restrict__ f, long n, long ntiles, int TMl, int d_out, float* __restrict__ fout) {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -651,6 +748,12 @@ static inline int lay_launch(const NetDev& nd, const LayPlan& p, hipStream_t st,
         if (p.TT == 2) hipLaunchKernelGGL(k_lay_tail<2>, dim3(p.GT), dim3(256), 0, st, nd, p, img, eta, Y, n, store, pstat);
         else hipLaunchKernelGGL(k_lay_tail<4>, dim3(p.GT), dim3(256), 0, st, nd, p, img, eta, Y, n, store, pstat);
         lb = (p.l0 > 1 ? p.l0 : 1) - 1;
+    } else if (p.last) {
+        for (int l = 0; l < L; ++l)
+            lay_gemm_launch<0>(st, img + p.wOff[l], 16 * p.TK[l], store + p.aOff[l], p.TK[l], store + p.aOff[l + 1], p.TO[l], nullptr, 0, p.ntiles,
+                               nd.act[l], nd.out[l], nd.out[l], lay_alt() ? (l & 1) : 0);
+        hipLaunchKernelGGL(k_lay_last, dim3(p.GT), dim3(256), 0, st, nd, p, img, eta, Y, n, store, pstat);
+        lb = L - 1;
     } else {
         lay_forward_chain(nd, p, st, img, store);
         hipLaunchKernelGGL(k_lay_lik, dim3(p.NLK), dim3(256), 0, st, nd, eta, (const float*)(store + p.aOff[nd.nl]), Y, n, p.TM[L], store + p.dOff[L], pstat);
