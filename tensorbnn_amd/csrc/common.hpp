@@ -125,6 +125,36 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
+// wave_sum's value in LANE 0 ONLY, bit for bit (the same tree: lane i += lane i + o for o = 32 .. 1), without the six dependent
+// LDS-crossbar round trips of __shfl_down on a double (~650 cycles with one wave per SIMD): v_permlane32_swap / v_permlane16_swap
+// (gfx950) bring the upper half / the odd rows down, row_shl DPP moves do the steps inside a row.  tools/ubench/wsum.hip checks the
+// bits against wave_sum on the device.
+template <int CTRL>
+__device__ __forceinline__ double dpp_shl_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double wave_sum_lane0(double v) {
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);      // [1]: lanes 0..31 <- lanes 32..63
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v += __hiloint2double((int)b[1], (int)a[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // [1]: rows 0, 2 <- rows 1, 3
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v += __hiloint2double((int)b[1], (int)a[1]);
+    }
+    v = dpp_shl_add<0x108>(v);       // row_shl:8: lane i <- lane i + 8 of its row
+    v = dpp_shl_add<0x104>(v);
+    v = dpp_shl_add<0x102>(v);
+    v = dpp_shl_add<0x101>(v);
+    return v;
+}
 __device__ __forceinline__ float wave_sumf(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

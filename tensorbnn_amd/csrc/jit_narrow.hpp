@@ -40,3 +40,10 @@ struct JitNarrow {
         o->plan = nullptr; o->wlaunch = nullptr; o->wforward = nullptr;
     }
 };
+
+#ifdef TBNN_TILE_STAMPS
+// diagnostic build (TBNN_JIT_FLAGS=-DTBNN_TILE_STAMPS): this library's copy of the shader-clock stamps (tools/experiments/coopstamps.py)
+extern "C" int tbnn_jit_tile_stamps(unsigned long long* out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_tile_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -176,8 +176,14 @@ struct FastCfg {
 };
 
 // diagnostic build only (-DTBNN_TILE_STAMPS): shader-clock stamps at the phase boundaries of a tile step
+// (-DTBNN_TILE_STAMPS=2: only the kernel's outer phases, TSTAMPO -- the fine stamps serialise what they bracket)
 #ifdef TBNN_TILE_STAMPS
-#define TSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0) g_tile_stamps[k] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TSTAMPO(k) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && threadIdx.x == 0) g_tile_stamps[k] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TSTAMPO(k) do { } while (0)
+#endif
+#if defined(TBNN_TILE_STAMPS) && (TBNN_TILE_STAMPS + 0) != 2
+#define TSTAMP(k) TSTAMPO(k)
 #else
 #define TSTAMP(k) do { } while (0)
 #endif

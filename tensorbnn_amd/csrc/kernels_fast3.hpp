@@ -866,6 +866,8 @@ struct Pipe3 {
 template <class S, int l>
 struct SlabOut3 {
     using C = F3Cfg<S>;
+    // LD: slab is the workgroup's dense copy in LDS (plain stores; the kernel writes it out 16 bytes per lane)
+    template <bool LD = false>
     static __device__ __forceinline__ void run(const float* buf, float* __restrict__ slab, int wave, int lane, int t0, int cnt) {
         constexpr int in = C::in(l), out = C::out(l), MT = C::MTF(l), NT = C::NTF(l);
         if constexpr (C::NCF(l)) {
@@ -882,7 +884,7 @@ struct SlabOut3 {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 4 * b + r;
-                        slab_store<(C::P() >= 2048)>(slab + C::offW(l) + (col < in ? row * in + col : in * out + row), (c0[r] + c1[r]) + (c2[r] + c3[r]));
+                        slab_store<(!LD && C::P() >= 2048)>(slab + C::offW(l) + (col < in ? row * in + col : in * out + row), (c0[r] + c1[r]) + (c2[r] + c3[r]));
                     }
                 }
             }
@@ -902,12 +904,12 @@ struct SlabOut3 {
                         for (int r = 0; r < 4; ++r) {
                             const int row = unit_of(out, row0 + r, false);
                             if (row >= 0)
-                                slab_store<(C::P() >= 2048)>(slab + C::offW(l) + (col < in ? row * in + col : in * out + row), (c0[r] + c1[r]) + (c2[r] + c3[r]));
+                                slab_store<(!LD && C::P() >= 2048)>(slab + C::offW(l) + (col < in ? row * in + col : in * out + row), (c0[r] + c1[r]) + (c2[r] + c3[r]));
                         }
                     }
                 }
             }
-        if constexpr (l + 1 < C::NLM3) SlabOut3<S, l + 1>::run(buf, slab, wave, lane, t0, cnt);
+        if constexpr (l + 1 < C::NLM3) SlabOut3<S, l + 1>::template run<LD>(buf, slab, wave, lane, t0, cnt);
     }
 };
 
@@ -916,6 +918,7 @@ template <class S, int l>
 struct FringeOut {
     using C = F3Cfg<S>;
     // staging: lb[(wave * FP_REGS + reg) * 64 + lane]
+    template <bool LD = false>
     static __device__ __forceinline__ void run(const float* lb, float* __restrict__ slab, int tid) {
         constexpr int NF = C::NF(l), KIN = C::KIN(l), in = C::in(l), out = C::out(l);
         if constexpr (C::FB(l)) {
@@ -937,7 +940,7 @@ struct FringeOut {
                 }
                 const int cs = 16 * nt + i16, u = C::funit(l, f);
                 const int col = l == 0 ? (cs <= in ? cs : -1) : unit_of(in, cs, true);
-                if (col >= 0) slab_store<(C::P() >= 2048)>(slab + C::offW(l) + (col < in ? u * in + col : in * out + u), v);
+                if (col >= 0) slab_store<(!LD && C::P() >= 2048)>(slab + C::offW(l) + (col < in ? u * in + col : in * out + u), v);
             }
         } else
         // D layout: thread (item = (f, kslot, g), wave): item count per layer = NF * (KIN+1) * 4 lane groups
@@ -966,10 +969,10 @@ struct FringeOut {
                 }
                 v += __shfl_xor(v, 1, 64);
                 v += __shfl_xor(v, 2, 64);
-                if (dest >= 0 && w == 0) slab_store<(C::P() >= 2048)>(slab + dest, v);
+                if (dest >= 0 && w == 0) slab_store<(!LD && C::P() >= 2048)>(slab + dest, v);
             }
         }
-        if constexpr (l + 1 < C::NL) FringeOut<S, l + 1>::run(lb, slab, tid);
+        if constexpr (l + 1 < C::NL) FringeOut<S, l + 1>::template run<LD>(lb, slab, tid);
     }
 };
 
@@ -991,6 +994,7 @@ struct FringeOut {
 #ifndef TBNN_F3_COOP
 #define TBNN_F3_COOP 1
 #endif
+
 template <class S>
 struct Coop3 {
     using C = F3Cfg<S>;
@@ -1078,12 +1082,15 @@ struct Coop3 {
             *reinterpret_cast<f32x4*>(xb + MT * 256 + lane * 4) = mine;
         }
         own[l] = mine;
+        TSTAMP(41 + 3 * l);
         __syncthreads();
+        TSTAMP(42 + 3 * l);
 #pragma unroll
         for (int mt = 0; mt < C::MT(l); ++mt) T.a[C::aroff(l) + mt] = *reinterpret_cast<const f32x4*>(xb + mt * 256 + lane * 4);
 #pragma unroll
         for (int f = 0; f < NF; ++f) T.af[l][f] = xb[XAF + 16 * f + i16];
         image<l>(T, wl, i16, g);
+        TSTAMP(43 + 3 * l);
         if constexpr (l + 1 < L) fwd<l + 1>(T, own, lds, wl, xch, xsel, wave, lane, i16, g);
     }
 
@@ -1135,6 +1142,7 @@ struct Coop3 {
         if constexpr (NF > 0 && !C::FB(l)) {
             if (wave == MT) FringeDW<S, l>::run(FP, T, dzf, g);
         }
+        TSTAMP(50 + 2 * (L - 1 - l));
         if constexpr (l > 0) {
             constexpr int MTP = C::MTF(l - 1), NFP = C::NF(l - 1), K = C::out(l);
             constexpr bool XCHG = l - 1 > 0;                              // delta_0 feeds no further delta step
@@ -1179,6 +1187,7 @@ struct Coop3 {
 #pragma unroll
                 for (int f = 0; f < NFP; ++f) dzpf[f] = xb[XAF + 16 * f + i16];
             }
+            TSTAMP(51 + 2 * (L - 1 - l));
             bwd<l - 1>(dWc, FP, T, own, lds, wl, xch, xsel, wave, lane, i16, g, dzp, odz, dzpf);
         }
     }
@@ -1191,6 +1200,7 @@ struct Coop3 {
         Tile3<S> T;
         f32x4 own[HL];
         int xsel = 0;
+        TSTAMPO(40);
 #pragma unroll
         for (int t = 0; t < C::KS0; ++t) {
             T.x0[t] = x[t];
@@ -1202,6 +1212,7 @@ struct Coop3 {
             const f32x4 dA[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, dB[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
             Fwd3<S, L>::run(T, lds, wl, i16, g, dA, dB);
         }
+        TSTAMP(25);
         float dzf[NFd];
 #pragma unroll
         for (int o = 0; o < NFd; ++o) dzf[o] = 0.f;
@@ -1215,11 +1226,14 @@ struct Coop3 {
         float dzpf[NFd];
 #pragma unroll
         for (int f = 0; f < NFd; ++f) dzpf[f] = 0.f;
+        TSTAMP(26);
         Bwd3<S, L>::da(T, lds, i16, g, dzL, dzf, dzp, dzpf);             // delta_{L-1}: VALU, every tile on every wave
+        TSTAMP(27);
         f32x4 odz = dzp[0];
 #pragma unroll
         for (int mt = 1; mt < C::MTF(L - 1); ++mt) if (wave == mt) odz = dzp[mt];
         bwd<L - 1>(dWc, FP, T, own, lds, wl, xch, xsel, wave, lane, i16, g, dzp, odz, dzpf);
+        TSTAMPO(56);
     }
 
     // epilogue: add this wave's cooperative accumulators to its staged tiles [t0, t0 + cnt) (mine[t - t0][lane])
@@ -1241,6 +1255,281 @@ struct Coop3 {
             }
         }
         if constexpr (l + 1 < C::NLM3) merge<l + 1>(mine, dWc, wave, lane, t0, cnt);
+    }
+};
+
+// FringeOut's sums as (value, slab position) pairs in registers, nothing stored: every load of every layer is issued before the
+// first store (Epi3).  Threads without an item load item 0 (clamped) and get position -1.
+template <class S, int l>
+struct FringeVals {
+    using C = F3Cfg<S>;
+    static constexpr int NF = C::NF(l), KIN = C::KIN(l), in = C::in(l), out = C::out(l);
+    static constexpr int NI = C::FB(l) ? NF * C::NT(l) * 16 : NF * (KIN + 1) * 4;                     // items
+    static constexpr int TI = C::FB(l) ? NI : NI * FAST_WAVES;                                        // threads per pass over them
+    static constexpr int R = NF > 0 ? (TI + FAST_THREADS - 1) / FAST_THREADS : 0;
+    static constexpr int total() { if constexpr (l + 1 < C::NL) return R + FringeVals<S, l + 1>::total(); else return R > 0 ? R : 1; }
+    template <int AT, int NR>
+    static __device__ __forceinline__ void run(const float* lb, int tid, float (&fv)[NR], int (&fd)[NR]) {
+        if constexpr (NF > 0 && C::FB(l)) {
+            // B-operand layout: item = (f, nt, i16): sum over the 4 waves x 4 lane groups (x 2 row pairs when NF == 1)
+            constexpr int NT = C::NT(l);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int it0 = tid + r * FAST_THREADS, it = it0 < NI ? it0 : 0;
+                const int i16 = it & 15, nt = (it >> 4) % NT, f = it / (16 * NT);
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < FAST_WAVES; ++w) {
+                    float vw = 0.f;
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        if constexpr (NF == 2) vw += lb[(size_t)(w * C::FP_REGS + C::fpoff(l) + 2 * nt + f) * 64 + 16 * gg + i16];
+                        else vw += lb[(size_t)(w * C::FP_REGS + C::fpoff(l) + 2 * nt) * 64 + 16 * gg + i16] +
+                                   lb[(size_t)(w * C::FP_REGS + C::fpoff(l) + 2 * nt + 1) * 64 + 16 * gg + i16];
+                    }
+                    v += vw;
+                }
+                const int cs = 16 * nt + i16, u = C::funit(l, f);
+                const int col = l == 0 ? (cs <= in ? cs : -1) : unit_of(in, cs, true);
+                fv[AT + r] = v;
+                fd[AT + r] = (it0 < NI && col >= 0) ? C::offW(l) + (col < in ? u * in + col : in * out + u) : -1;
+            }
+        } else if constexpr (NF > 0) {
+            // D layout: thread (item = (f, kslot, g), wave)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int t = tid + r * FAST_THREADS;
+                const int it0 = t >> 2, w = t & 3, it = it0 < NI ? it0 : 0;
+                const int gg = it & 3, fk = it >> 2;
+                const int f = fk / (KIN + 1), k = fk - f * (KIN + 1);
+                const int reg = C::fpoff(l) + f * (KIN + 1) + k;
+                const f32x4* src = reinterpret_cast<const f32x4*>(lb + ((size_t)(w * C::FP_REGS + reg) * 4 + gg) * 16);
+                const f32x4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+                float v = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3])) +
+                          (((p2[0] + p2[1]) + (p2[2] + p2[3])) + ((p3[0] + p3[1]) + (p3[2] + p3[3])));
+                int dest = -1;
+                const int u = C::funit(l, f);
+                if (k == KIN) { if (gg == 0) dest = C::offW(l) + in * out + u; }
+                else {
+                    const int col = l == 0 ? (4 * k + gg < in ? 4 * k + gg : -1) : unit_of(in, 16 * (k >> 2) + 4 * gg + (k & 3), false);
+                    if (col >= 0) dest = C::offW(l) + u * in + col;
+                }
+                v += __shfl_xor(v, 1, 64);
+                v += __shfl_xor(v, 2, 64);
+                fv[AT + r] = v;
+                fd[AT + r] = (it0 < NI && w == 0) ? dest : -1;
+            }
+        }
+        if constexpr (l + 1 < C::NL) FringeVals<S, l + 1>::template run<AT + R>(lb, tid, fv, fd);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Epilogue of the one-pass shapes, written for ONE wave per SIMD (every instruction is paid at issue, nothing hides a latency):
+//  * specialised on the wave (a switch over four instantiations): which tiles a wave sums, where its copies go and which of its
+//    cooperative accumulators belong to which tile are then compile-time facts -- straight-line code, no per-tile predicate;
+//  * a wave keeps its own copy of the tiles it sums (t = wave mod 4) in registers: three staged copies per tile instead of four
+//    (the N-fringe accumulator pairs keep four: their cooperative share lands through a cross-lane LDS update);
+//  * the summed tiles and fringe rows go to a dense copy of the slab in LDS (it fits behind the three-copy staging area) and
+//    leave as 16-byte write-through stores, one contiguous KB per wave instruction, instead of one 4-byte fabric write per entry;
+//  * the log-likelihood statistic is reduced after the stores are issued.
+// The sum over the four waves keeps its fixed order (c0 + c1) + (c2 + c3).
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef TBNN_F3_EPI
+#define TBNN_F3_EPI 1
+#endif
+template <class S>
+struct Epi3 {
+    using C = F3Cfg<S>;
+    using CO = Coop3<S>;
+    static constexpr int T = C::DW3_TILES > 0 ? C::DW3_TILES : 1;
+    static constexpr int KMAX = (T + FAST_WAVES - 1) / FAST_WAVES;
+    static constexpr int P4 = (C::P() + 3) / 4 * 4;
+    static constexpr int FPd = C::FP_REGS > 0 ? C::FP_REGS : 1;
+    // tiles of an N-fringe accumulator pair: index among them, or -1
+    static constexpr int nf_index(int t) {
+        int k = 0;
+        for (int l = 0; l < C::NLM3; ++l)
+            if (C::NCF(l)) {
+                if (t == C::dwfr3(l)) return k;
+                if (t == C::dwfr3(l) + 1) return k + 1;
+                k += 2;
+            }
+        return -1;
+    }
+    static constexpr int nf_count() { int k = 0; for (int l = 0; l < C::NLM3; ++l) if (C::NCF(l)) k += 2; return k; }
+    static constexpr int NFT = nf_count();
+    // staging slot (KB) of source wave c's copy of tile t, or -1: the summing wave (t mod 4) keeps it in registers
+    static constexpr int slot(int t, int c) {
+        const int own = t & (FAST_WAVES - 1);
+        if (c == own) return nf_index(t) >= 0 ? 3 * T + nf_index(t) : -1;
+        return ((c - own + 3) & 3) * T + t;
+    }
+    static constexpr int ST_FLOATS = (3 * T + NFT) * 256;                         // staged tile copies
+    static constexpr int LB_FLOATS = FAST_WAVES * C::FP_REGS * 64;                // fringe partials
+    static constexpr int DENSE_OFF = ST_FLOATS + LB_FLOATS;
+    static constexpr bool ENABLED = TBNN_F3_EPI && C::DW3_TILES > 0 && C::EP3_TILES == C::DW3_TILES && C::P() >= 2048 &&
+                                    (size_t)DENSE_OFF + P4 <= (size_t)C::LDS3_FLOATS;
+
+    // wave W's cooperative accumulator for its copy of tile t (full tiles of its own M tile), or -1
+    template <int W>
+    static constexpr int coop_index(int t) {
+        if (!CO::ENABLED) return -1;
+        for (int l = 0; l < C::NLM3; ++l)
+            if (C::MTF(l) > 0 && W < C::MTF(l))
+                for (int nt = 0; nt < C::NTF(l); ++nt)
+                    if (t == C::dwoff3(l) + W * C::NTF(l) + nt) return CO::cwoff(l) + nt;
+        return -1;
+    }
+
+    // stage: every copy another wave sums -> LDS; own[k] = this wave's copy of tile 4 k + W
+    template <int W, int t = 0>
+    static __device__ __forceinline__ void stage(f32x4* st, f32x4 (&own)[KMAX], const f32x4 (&dW)[T], const f32x4 (&dWc)[CO::DWC], int lane) {
+        if constexpr (t < C::DW3_TILES) {
+            f32x4 v = dW[t];
+            constexpr int ci = coop_index<W>(t);
+            if constexpr (ci >= 0) v += dWc[ci];                                  // (zero when the workgroup ran no cooperative tile)
+            constexpr int sl = slot(t, W);
+            if constexpr (sl >= 0) st[sl * 64 + lane] = v;
+            else own[t / FAST_WAVES] = v;
+            stage<W, t + 1>(st, own, dW, dWc, lane);
+        }
+    }
+    // the cooperative rounds keep a whole 16x16x4 tile for the last N tile (D layout: lane (i16, g) register r = unit 16 W + 4 g + r,
+    // slot 16 (NT - 1) + i16); its columns 4 j go to lane 4 (4 W + g) + j of the wave's copy of the N-fringe tile (Coop3::merge)
+    template <int W, int l = 0>
+    static __device__ __forceinline__ void stage_nf_coop(f32x4* st, const f32x4 (&dWc)[CO::DWC], int lane) {
+        if constexpr (CO::ENABLED && l < C::NLM3) {
+            if constexpr (C::MTF(l) > 0 && W < C::MTF(l) && C::NCF(l)) {
+                const int i16 = lane & 15, g = lane >> 4;
+                if ((i16 & 3) == 0) st[slot(C::dwfr3(l), W) * 64 + 16 * W + 4 * g + (i16 >> 2)] += dWc[CO::cwoff(l) + C::NTF(l)];
+            }
+            stage_nf_coop<W, l + 1>(st, dWc, lane);
+        }
+    }
+    // source wave c's copy of tile t as wave W = t mod 4 sees it: staged, or its own registers
+    template <int W, int t, int c>
+    static __device__ __forceinline__ f32x4 cpy(const f32x4* st, const f32x4 (&own)[KMAX], int lane) {
+        constexpr int sl = slot(t, c);
+        if constexpr (sl >= 0) return st[sl * 64 + lane];
+        else return own[t / FAST_WAVES];
+    }
+    // The sums first, every store after them: the dense copy and the staging area are one LDS object, the compiler keeps a load
+    // behind any earlier store -- a tile summed and stored at a time pays a full LDS round trip per tile.
+    static constexpr int NLd = C::NLM3 > 0 ? C::NLM3 : 1;
+    template <int W, int k = 0>
+    static __device__ __forceinline__ void tiles_sum(const f32x4* st, const f32x4 (&own)[KMAX], int lane, f32x4 (&sum)[KMAX]) {
+        if constexpr (k < KMAX) {
+            constexpr int t = FAST_WAVES * k + W;
+            if constexpr (t < C::DW3_TILES && nf_index(t < C::DW3_TILES ? t : 0) < 0) {
+                const f32x4 c0 = cpy<W, t, 0>(st, own, lane), c1 = cpy<W, t, 1>(st, own, lane), c2 = cpy<W, t, 2>(st, own, lane), c3 = cpy<W, t, 3>(st, own, lane);
+                sum[k] = (c0 + c1) + (c2 + c3);
+            }
+            tiles_sum<W, k + 1>(st, own, lane, sum);
+        }
+    }
+    // the N-fringe accumulator pairs (even-row and odd-row accumulators: tiles t and t + 1)
+    template <int W, int l = 0>
+    static __device__ __forceinline__ void nf_sum(const f32x4* st, const f32x4 (&own)[KMAX], int lane, f32x4 (&nfs)[NLd]) {
+        if constexpr (l < C::NLM3) {
+            if constexpr (C::NCF(l) && (C::dwfr3(l) & (FAST_WAVES - 1)) == W) {
+                constexpr int t = C::dwfr3(l);
+                const f32x4 c0 = cpy<W, t, 0>(st, own, lane) + cpy<W, t + 1, 0>(st, own, lane), c1 = cpy<W, t, 1>(st, own, lane) + cpy<W, t + 1, 1>(st, own, lane),
+                            c2 = cpy<W, t, 2>(st, own, lane) + cpy<W, t + 1, 2>(st, own, lane), c3 = cpy<W, t, 3>(st, own, lane) + cpy<W, t + 1, 3>(st, own, lane);
+                nfs[l] = (c0 + c1) + (c2 + c3);
+            }
+            nf_sum<W, l + 1>(st, own, lane, nfs);
+        }
+    }
+    // layer l's tiles of wave W -> the dense slab copy in LDS (destinations as SlabOut3)
+    template <int W, int l = 0>
+    static __device__ __forceinline__ void tiles_out(float* dense, const f32x4 (&sum)[KMAX], const f32x4 (&nfs)[NLd], int lane) {
+        if constexpr (l < C::NLM3) {
+            constexpr int in = C::in(l), out = C::out(l), MT = C::MTF(l);
+            if constexpr (C::NCF(l) && (C::dwfr3(l) & (FAST_WAVES - 1)) == W) {
+                // the N-fringe tile: lane (b, j) register i = dW[unit 4b + i][slot 16 (NT_all - 1) + 4j]
+                const int b = lane >> 2, col = unit_of(in, 16 * (C::NT(l) - 1) + 4 * (lane & 3), true);
+                if (b < 4 * MT && col >= 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * b + r;
+                        dense[C::offW(l) + (col < in ? row * in + col : in * out + row)] = nfs[l][r];
+                    }
+                }
+            }
+            tiles_out_full<W, l, 0>(dense, sum, lane);
+            tiles_out<W, l + 1>(dense, sum, nfs, lane);
+        }
+    }
+    template <int W, int l, int k>
+    static __device__ __forceinline__ void tiles_out_full(float* dense, const f32x4 (&sum)[KMAX], int lane) {
+        constexpr int in = C::in(l), out = C::out(l), MT = C::MTF(l), NT = C::NTF(l);
+        if constexpr (k < MT * NT) {
+            constexpr int t = C::dwoff3(l) + k, mt = k / (NT > 0 ? NT : 1), nt = k % (NT > 0 ? NT : 1);
+            if constexpr ((t & (FAST_WAVES - 1)) == W) {
+                const int cs = 16 * nt + (lane & 15), row0 = 16 * mt + 4 * (lane >> 4);
+                const int col = l == 0 ? (cs <= in ? cs : -1) : unit_of(in, cs, true);
+                if (col >= 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = unit_of(out, row0 + r, false);
+                        if (row >= 0) dense[C::offW(l) + (col < in ? row * in + col : in * out + row)] = sum[t / FAST_WAVES][r];
+                    }
+                }
+            }
+            tiles_out_full<W, l, k + 1>(dense, sum, lane);
+        }
+    }
+
+    template <int W>
+    static __device__ __forceinline__ void run(float* __restrict__ lds, float* __restrict__ slab, const f32x4 (&dW)[T], const f32x4 (&dWc)[CO::DWC],
+                                               const float (&FP)[FPd], int tid, int lane) {
+        const int i16 = lane & 15, g = lane >> 4;
+        f32x4* st = reinterpret_cast<f32x4*>(lds);
+        float* lb = lds + ST_FLOATS;
+        float* dense = lds + DENSE_OFF;
+        f32x4 own[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) own[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                                          // images and exchange buffers are dead
+        stage<W>(st, own, dW, dWc, lane);
+        stage_nf_coop<W>(st, dWc, lane);
+        {   // (one base register + immediate offsets: the area lies above the 64 KB an LDS offset field reaches from 0)
+            int o = (W * C::FP_REGS * 4 + g) * 16 + i16;
+            asm volatile("" : "+v"(o));                                          // (an opaque index: the pointer itself would leave the LDS address space)
+#pragma unroll
+            for (int r = 0; r < C::FP_REGS; ++r) lb[o + r * 64] = FP[r];
+        }
+        if (tid < P4 - C::P()) dense[C::P() + tid] = 0.f;
+        __syncthreads();
+        TSTAMPO(63);
+        f32x4 sum[KMAX], nfs[NLd];
+        tiles_sum<W>(st, own, lane, sum);
+        nf_sum<W>(st, own, lane, nfs);
+        float fv[FringeVals<S, 0>::total()];
+        int fd[FringeVals<S, 0>::total()];
+        FringeVals<S, 0>::template run<0>(lb, tid, fv, fd);
+        TSTAMPO(35);
+        tiles_out<W>(dense, sum, nfs, lane);
+#pragma unroll
+        for (int i = 0; i < FringeVals<S, 0>::total(); ++i) if (fd[i] >= 0) dense[fd[i]] = fv[i];
+        TSTAMPO(36);
+        __syncthreads();
+        TSTAMPO(37);
+        {   // every read of the dense copy, then every store (a loop of read -> store pays an LDS round trip per 16 bytes)
+            constexpr int N4 = P4 / 4, NE = (N4 + FAST_THREADS - 1) / FAST_THREADS;
+            f32x4 d[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int e = tid + k * FAST_THREADS;
+                d[k] = *reinterpret_cast<const f32x4*>(dense + 4 * (e < N4 ? e : 0));
+            }
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int e = tid + k * FAST_THREADS;
+                if (e < N4) store16<true>(slab + 4 * e, d[k]);
+            }
+        }
     }
 };
 
@@ -1269,7 +1558,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     static_assert((C::LDS3_FLOATS + (CO::ENABLED ? 2 * CO::XB : 4)) * 4 + 64 <= 160 * 1024, "LDS budget");
     static_assert((size_t)FAST_WAVES * C::FP_REGS * 64 <= (size_t)C::LDS3_FLOATS, "fringe staging does not fit");
 #define TB_STAMP(i) do { if (stamps && threadIdx.x == 0 && blockIdx.x == 0) { stamps[i] = wall_clock64(); stamps[8 + i] = clock64(); } } while (0)
-    TB_STAMP(0);
+    TB_STAMP(0); TSTAMPO(57);
     __shared__ __attribute__((aligned(16))) float lds[C::LDS3_FLOATS];
     __shared__ __attribute__((aligned(16))) float xch[CO::ENABLED ? 2 * CO::XB : 4];     // cooperative tail: exchange buffers
     __shared__ double red[FAST_WAVES];
@@ -1351,7 +1640,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         for (int k = 0; k < IT; ++k) { const int e = tid + k * FAST_THREADS; if (e < N4) dst[e] = v[k]; }
     }
     __syncthreads();
-    TB_STAMP(1);
+    TB_STAMP(1); TSTAMPO(58);
 
     constexpr int NFd = C::maxNF() > 0 ? C::maxNF() : 1;
     f32x4 dW[C::DW3_TILES > 0 ? C::DW3_TILES : 1];
@@ -1449,9 +1738,9 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                 Bwd3<S, 0>::fdw(FP, Fop, Bop);
             }
         }
-        if (first) { TB_STAMP(2); first = false; }
+        if (first) { TB_STAMP(2); TSTAMPO(59); first = false; }
     }
-    TB_STAMP(3);
+    TB_STAMP(3); TSTAMPO(60);
     mfma_drain_acc(dW);
     f32x4 dWc[CO::DWC];
 #pragma unroll
@@ -1469,59 +1758,82 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xj, yj, ct * 16 + i16 < n);
         }
     }
-    TB_STAMP(5);
+    TB_STAMP(5); TSTAMPO(62);
 
     // ---- epilogue
-    const double wtot = wave_sum(stat);
-    if (lane == 0) red[wave] = wtot;
-    float* slab = slabs + (size_t)blockIdx.x * pitch;
-    // one staging pass for the dW tiles AND the fringe partials when both fit (configs[1]: 108 + 35 KB): two barriers
-    // instead of four
-    constexpr bool ONE_PASS = C::DW3_TILES > 0 && C::EP3_TILES == C::DW3_TILES &&
-                              (size_t)FAST_WAVES * (C::DW3_TILES * 256 + C::FP_REGS * 64) <= (size_t)C::LDS3_FLOATS;
-    if constexpr (ONE_PASS) {
-        float* lb = lds + FAST_WAVES * C::DW3_TILES * 256;
-        __syncthreads();
-        f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::DW3_TILES * 64);
-#pragma unroll
-        for (int t = 0; t < C::DW3_TILES; ++t) mine[t * 64 + lane] = dW[t];
-        if constexpr (CO::ENABLED) { if (ncoop > 0) CO::template merge<0>(mine, dWc, wave, lane, 0, C::DW3_TILES); }
-#pragma unroll
-        for (int r = 0; r < C::FP_REGS; ++r) lb[((size_t)(wave * C::FP_REGS + r) * 4 + g) * 16 + i16] = FP[r];
-        __syncthreads();
-        TB_STAMP(6);
-        SlabOut3<S, 0>::run(lds, slab, wave, lane, 0, C::DW3_TILES);
-        TB_STAMP(7);
-        FringeOut<S, 0>::run(lb, slab, tid);
-    } else {
-        if constexpr (C::DW3_TILES > 0) {
-#pragma unroll
-            for (int t0 = 0; t0 < C::DW3_TILES; t0 += C::EP3_TILES) {
-                __syncthreads();
-                f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::EP3_TILES * 64);
-#pragma unroll
-                for (int t = t0; t < t0 + C::EP3_TILES && t < C::DW3_TILES; ++t) mine[(t - t0) * 64 + lane] = dW[t];
-                const int cnt = (C::DW3_TILES - t0) < C::EP3_TILES ? (C::DW3_TILES - t0) : C::EP3_TILES;
-                if constexpr (CO::ENABLED) { if (ncoop > 0) CO::template merge<0>(mine, dWc, wave, lane, t0, cnt); }
-                __syncthreads();
-                SlabOut3<S, 0>::run(lds, slab, wave, lane, t0, cnt);
-            }
+    if constexpr (Epi3<S>::ENABLED) {
+        float* slab = slabs + (size_t)blockIdx.x * pitch;
+        switch (wave) {
+            case 0: Epi3<S>::template run<0>(lds, slab, dW, dWc, FP, tid, lane); break;
+            case 1: Epi3<S>::template run<1>(lds, slab, dW, dWc, FP, tid, lane); break;
+            case 2: Epi3<S>::template run<2>(lds, slab, dW, dWc, FP, tid, lane); break;
+            default: Epi3<S>::template run<3>(lds, slab, dW, dWc, FP, tid, lane); break;
         }
-        {   // fringe partials: [wave][reg][g][i16]
+        const double wtot = wave_sum_lane0(stat);                // (lane 0: the bits of wave_sum)
+        if (lane == 0) red[wave] = wtot;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < FAST_WAVES; ++w) t += red[w];
+            pstat[blockIdx.x] = t;
+        }
+    } else {
+        const double wtot = wave_sum(stat);
+        if (lane == 0) red[wave] = wtot;
+        float* slab = slabs + (size_t)blockIdx.x * pitch;
+        // one staging pass for the dW tiles AND the fringe partials when both fit (configs[1]: 108 + 35 KB): two barriers
+        // instead of four
+        constexpr bool ONE_PASS = C::DW3_TILES > 0 && C::EP3_TILES == C::DW3_TILES &&
+                                  (size_t)FAST_WAVES * (C::DW3_TILES * 256 + C::FP_REGS * 64) <= (size_t)C::LDS3_FLOATS;
+        if constexpr (ONE_PASS) {
+            float* lb = lds + FAST_WAVES * C::DW3_TILES * 256;
+            TSTAMP(20);
             __syncthreads();
-            float* lb = lds;
+            TSTAMP(21);
+            f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::DW3_TILES * 64);
+#pragma unroll
+            for (int t = 0; t < C::DW3_TILES; ++t) mine[t * 64 + lane] = dW[t];
+            TSTAMP(22);
+            if constexpr (CO::ENABLED) { if (ncoop > 0) CO::template merge<0>(mine, dWc, wave, lane, 0, C::DW3_TILES); }
+            TSTAMP(23);
 #pragma unroll
             for (int r = 0; r < C::FP_REGS; ++r) lb[((size_t)(wave * C::FP_REGS + r) * 4 + g) * 16 + i16] = FP[r];
+            TSTAMP(24);
             __syncthreads();
+            TB_STAMP(6); TSTAMPO(63);
+            SlabOut3<S, 0>::run(lds, slab, wave, lane, 0, C::DW3_TILES);
+            TB_STAMP(7);
             FringeOut<S, 0>::run(lb, slab, tid);
+        } else {
+            if constexpr (C::DW3_TILES > 0) {
+#pragma unroll
+                for (int t0 = 0; t0 < C::DW3_TILES; t0 += C::EP3_TILES) {
+                    __syncthreads();
+                    f32x4* mine = reinterpret_cast<f32x4*>(lds) + wave * (C::EP3_TILES * 64);
+#pragma unroll
+                    for (int t = t0; t < t0 + C::EP3_TILES && t < C::DW3_TILES; ++t) mine[(t - t0) * 64 + lane] = dW[t];
+                    const int cnt = (C::DW3_TILES - t0) < C::EP3_TILES ? (C::DW3_TILES - t0) : C::EP3_TILES;
+                    if constexpr (CO::ENABLED) { if (ncoop > 0) CO::template merge<0>(mine, dWc, wave, lane, t0, cnt); }
+                    __syncthreads();
+                    SlabOut3<S, 0>::run(lds, slab, wave, lane, t0, cnt);
+                }
+            }
+            {   // fringe partials: [wave][reg][g][i16]
+                __syncthreads();
+                float* lb = lds;
+#pragma unroll
+                for (int r = 0; r < C::FP_REGS; ++r) lb[((size_t)(wave * C::FP_REGS + r) * 4 + g) * 16 + i16] = FP[r];
+                __syncthreads();
+                FringeOut<S, 0>::run(lb, slab, tid);
+            }
+        }
+        if (tid == 0) {
+            double t = 0.0;
+            for (int w = 0; w < FAST_WAVES; ++w) t += red[w];
+            pstat[blockIdx.x] = t;
         }
     }
-    if (tid == 0) {
-        double t = 0.0;
-        for (int w = 0; w < FAST_WAVES; ++w) t += red[w];
-        pstat[blockIdx.x] = t;
-    }
-    TB_STAMP(4);
+    TB_STAMP(4); TSTAMPO(61);
 #undef TB_STAMP
 }
 
