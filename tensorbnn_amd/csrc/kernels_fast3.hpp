@@ -1338,6 +1338,9 @@ struct FringeVals {
 #ifndef TBNN_F3_EPI
 #define TBNN_F3_EPI 1
 #endif
+#ifndef TBNN_F3_COOP_PEEL
+#define TBNN_F3_COOP_PEEL 1          // two copies of the cooperative tile instead of a loop (0: the loop; configs[1]: +0.3 us of register shuffles around it)
+#endif
 template <class S>
 struct Epi3 {
     using C = F3Cfg<S>;
@@ -1746,6 +1749,14 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int t = 0; t < CO::DWC; ++t) dWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (CO::ENABLED) {
+#if TBNN_F3_COOP_PEEL
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                           // two copies of the body: no loop-carried register shuffle around a tile
+            const long ct = main_end + (long)j * gridDim.x + blockIdx.x;
+            if (j < ncoop && ct < ntiles)                       // workgroup-uniform: the barriers inside are met by all 4 waves
+                CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[j], yc[j], ct * 16 + i16 < n);
+        }
+#else
 #pragma unroll 1
         for (int j = 0; j < ncoop; ++j) {                       // one copy of the body: the second round's rows by select
             const long ct = main_end + (long)j * gridDim.x + blockIdx.x;
@@ -1757,6 +1768,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             for (int o = 0; o < d_out; ++o) yj[o] = j == 0 ? yc[0][o] : yc[1][o];
             CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xj, yj, ct * 16 + i16 < n);
         }
+#endif
     }
     TB_STAMP(5); TSTAMPO(62);
 
