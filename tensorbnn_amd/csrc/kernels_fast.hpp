@@ -868,7 +868,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 
     // ---- epilogue: every wave stages its dW tiles [wave][tile][lane] (16 B per lane), wave t%4 sums the
     // 4 copies of tile t in fixed order and writes the dense slab; EP_TILES per pass
-    const double wtot = wave_sum(stat);
+    const double wtot = wave_sum_lane0(stat);
     if (lane == 0) red[wave] = wtot;
     float* slab = slabs + (size_t)blockIdx.x * pitch;
 #pragma unroll

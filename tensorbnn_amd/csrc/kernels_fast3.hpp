@@ -883,8 +883,9 @@ struct SlabOut3 {
                 if (b < 4 * MT && col >= 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * b + r;
-                        slab_store<(!LD && C::P() >= 2048)>(slab + C::offW(l) + (col < in ? row * in + col : in * out + row), (c0[r] + c1[r]) + (c2[r] + c3[r]));
+                        const int row = unit_of(out, 4 * b + r, false);           // (a partly filled last M tile keeps its units in slot order)
+                        if (row >= 0)
+                            slab_store<(!LD && C::P() >= 2048)>(slab + C::offW(l) + (col < in ? row * in + col : in * out + row), (c0[r] + c1[r]) + (c2[r] + c3[r]));
                     }
                 }
             }
@@ -1455,8 +1456,8 @@ struct Epi3 {
                 if (b < 4 * MT && col >= 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * b + r;
-                        dense[C::offW(l) + (col < in ? row * in + col : in * out + row)] = nfs[l][r];
+                        const int row = unit_of(out, 4 * b + r, false);           // (a partly filled last M tile keeps its units in slot order)
+                        if (row >= 0) dense[C::offW(l) + (col < in ? row * in + col : in * out + row)] = nfs[l][r];
                     }
                 }
             }
@@ -1750,12 +1751,11 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     for (int t = 0; t < CO::DWC; ++t) dWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (CO::ENABLED) {
 #if TBNN_F3_COOP_PEEL
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {                           // two copies of the body: no loop-carried register shuffle around a tile
-            const long ct = main_end + (long)j * gridDim.x + blockIdx.x;
-            if (j < ncoop && ct < ntiles)                       // workgroup-uniform: the barriers inside are met by all 4 waves
-                CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[j], yc[j], ct * 16 + i16 < n);
-        }
+        // straight-line copies of the body, no loop: no loop-carried register shuffle around a tile (conditions are workgroup-uniform:
+        // the barriers inside are met by all 4 waves)
+        const long ct0 = main_end + blockIdx.x, ct1 = ct0 + gridDim.x;
+        if (ncoop > 0 && ct0 < ntiles) CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[0], yc[0], ct0 * 16 + i16 < n);
+        if (ncoop > 1 && ct1 < ntiles) CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[1], yc[1], ct1 * 16 + i16 < n);
 #else
 #pragma unroll 1
         for (int j = 0; j < ncoop; ++j) {                       // one copy of the body: the second round's rows by select
@@ -1790,7 +1790,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             pstat[blockIdx.x] = t;
         }
     } else {
-        const double wtot = wave_sum(stat);
+        const double wtot = wave_sum_lane0(stat);
         if (lane == 0) red[wave] = wtot;
         float* slab = slabs + (size_t)blockIdx.x * pitch;
         // one staging pass for the dW tiles AND the fringe partials when both fit (configs[1]: 108 + 35 KB): two barriers

@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void k_lay_tail(NetDev nd, LayPlan p, const fl
             for (int t = 0; t < TT; ++t) if (t < TMl) lay_block_store(db + t * 256, dz[t]);
         }
     }
-    const double wtot = wave_sum(stat);
+    const double wtot = wave_sum_lane0(stat);
     if (lane == 0) red[wave] = wtot;
     __syncthreads();
     if (threadIdx.x == 0) pstat[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void k_lay_last(NetDev nd, LayPlan p, const fl
             if (t < MTp) lay_block_store(db + t * 256, v);
         }
     }
-    const double wtot = wave_sum(stat);
+    const double wtot = wave_sum_lane0(stat);
     if (lane == 0) red[wave] = wtot;
     __syncthreads();
     if (threadIdx.x == 0) pstat[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);

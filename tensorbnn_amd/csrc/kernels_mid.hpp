@@ -595,7 +595,7 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
 
     // ---- epilogue: every wave stages its dW tiles [wave][tile][lane] (16 B per lane), wave t % 4 sums the 4 copies of
     // tile t in fixed order and writes the dense slab (theta order); EP_TILES per pass.  Deterministic.
-    const double wtot = wave_sum(stat);
+    const double wtot = wave_sum_lane0(stat);
     if (lane == 0) red[wave] = wtot;
     float* slab = slabs + (size_t)blockIdx.x * pitch;
     // (compile-time pass and tile indices throughout: a run-time index into dW would turn the accumulators into a

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         });
     }
     TALL_STAMP(19);
-    const double wtot = wave_sum(stat);
+    const double wtot = wave_sum_lane0(stat);
     if (lane == 0) red[wave] = wtot;
     // ---- middle layers: the four waves' k-step shares of every tile, summed in fixed order
     if constexpr (C::DWM_TILES > 0) {

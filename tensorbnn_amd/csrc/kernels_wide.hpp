@@ -752,7 +752,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     mfma_drain_acc(dW0);
 #endif
     // ---- epilogue: compact slab [layer 0][last layer] of this workgroup
-    const double wtot = wave_sum(stat);
+    const double wtot = wave_sum_lane0(stat);
     if (lane == 0) red[wave] = wtot;
     __syncthreads();                                   // ring is dead
     float* slab = slabA + (size_t)blockIdx.x * C::SA_FLOATS;

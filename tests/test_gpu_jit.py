@@ -77,6 +77,58 @@ def test_jit_kernel_cooperative_tail(native, monkeypatch, case, grid):
     ch.close()
 
 
+# shapes with >= 2048 parameters whose staging leaves room for the dense slab copy: the wave-specialised epilogue (Epi3: three staged
+# copies per tile, the own copy in registers, dense slab through LDS, 16-byte stores) in its variants -- two / one / no fringe unit
+# per hidden layer in the B-operand and the D layout, N-fringe accumulator pairs, a 2-output last layer -- each with no, one and two
+# cooperative tiles per workgroup (their accumulators are merged while staging)
+EPI_CASES = {
+    "fringe2": ([8, 50, 50, 1], o.ACT_RELU),
+    "fringe1_three_hidden": ([5, 49, 49, 49, 1], o.ACT_TANH),
+    "no_fringe_d_layout": ([6, 51, 51, 1], o.ACT_RELU),
+    "two_outputs": ([9, 35, 35, 35, 2], o.ACT_RELU),
+    "mixed_widths": ([12, 50, 40, 1], o.ACT_ELU),
+    "four_hidden": ([3, 33, 33, 33, 33, 1], o.ACT_RELU),
+    "wide_input": ([16, 49, 51, 1], o.ACT_SIGMOID),
+}
+
+
+@pytest.fixture(scope="module")
+def epi_kernels():
+    """the seven kernel libraries compiled side by side (one hipcc each, ~1 min) instead of one after the other"""
+    from concurrent.futures import ThreadPoolExecutor
+    def one(case):
+        dims, act = EPI_CASES[case]
+        spec = o.make_spec(dims, act, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, o.ACT_NONE)
+        return jit.build([(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers], spec.likelihood)
+    with ThreadPoolExecutor(max_workers=len(EPI_CASES)) as ex:
+        paths = list(ex.map(one, EPI_CASES))
+    assert all(paths), paths
+    return paths
+
+
+@pytest.mark.parametrize("case", list(EPI_CASES))
+@pytest.mark.parametrize("ncoop", [0, 1, 2])
+def test_jit_narrow_epilogue_variants(native, monkeypatch, epi_kernels, case, ncoop):
+    dims, act = EPI_CASES[case]
+    grid = 6
+    W = 4 * grid
+    n = 16 * (2 * W + (0, 3, grid + 2)[ncoop]) - 5                # two full rounds + 0 / 3 / grid + 2 left-over tiles, a ragged last tile
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, act, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    assert spec.n_params >= 2048
+    monkeypatch.setenv("TBNN_FAST_GRID", str(grid))
+    ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, kernel=native.KERNEL_FAST, jit=True)
+    assert ch.kernel_name.startswith("jit-fast3<"), ch.kernel_name
+    ch.set_data(X, Y)
+    lp, g, st = ch.logp_grad(theta, eta)
+    lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)
+    assert abs(lp - lp64) <= 4e-6 * abs(lp64) + 1e-3
+    for l, (ow, ob) in zip(spec.layers, spec.offsets()):
+        for a, b in ((ow, ob), (ob, ob + l.out_dim)):
+            assert np.abs(g[a:b] - g64[a:b]).max() <= 1e-4 * max(np.abs(g64[a:b]).max(), 1e-3), (case, ncoop, a, b)
+    ch.close()
+
+
 def test_jit_unsupported_shape_falls_back(native):
     """mixed hidden activations: no fused family -> AUTO runs on the layered MFMA kernels (TBNN_LAYERED=0: the thread-per-row
     kernel), FAST fails loudly"""
