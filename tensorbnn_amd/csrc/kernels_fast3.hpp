@@ -1750,25 +1750,26 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int t = 0; t < CO::DWC; ++t) dWc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (CO::ENABLED) {
-#if TBNN_F3_COOP_PEEL
-        // straight-line copies of the body, no loop: no loop-carried register shuffle around a tile (conditions are workgroup-uniform:
-        // the barriers inside are met by all 4 waves)
-        const long ct0 = main_end + blockIdx.x, ct1 = ct0 + gridDim.x;
-        if (ncoop > 0 && ct0 < ntiles) CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[0], yc[0], ct0 * 16 + i16 < n);
-        if (ncoop > 1 && ct1 < ntiles) CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[1], yc[1], ct1 * 16 + i16 < n);
-#else
+        if constexpr (TBNN_F3_COOP_PEEL && C::P() >= 1024) {
+            // straight-line copies of the body, no loop: no loop-carried register shuffle around a tile (conditions are workgroup-uniform:
+            // the barriers inside are met by all 4 waves).  Small networks keep the loop: their launch is fetch- and launch-bound, the second
+            // copy costs configs[0] 1 %
+            const long ct0 = main_end + blockIdx.x, ct1 = ct0 + gridDim.x;
+            if (ncoop > 0 && ct0 < ntiles) CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[0], yc[0], ct0 * 16 + i16 < n);
+            if (ncoop > 1 && ct1 < ntiles) CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[1], yc[1], ct1 * 16 + i16 < n);
+        } else {
 #pragma unroll 1
-        for (int j = 0; j < ncoop; ++j) {                       // one copy of the body: the second round's rows by select
-            const long ct = main_end + (long)j * gridDim.x + blockIdx.x;
-            if (ct >= ntiles) break;                            // workgroup-uniform: the barriers inside are met by all 4 waves
-            float xj[C::KS0], yj[d_out];
+            for (int j = 0; j < ncoop; ++j) {                       // one copy of the body: the second round's rows by select
+                const long ct = main_end + (long)j * gridDim.x + blockIdx.x;
+                if (ct >= ntiles) break;                            // workgroup-uniform: the barriers inside are met by all 4 waves
+                float xj[C::KS0], yj[d_out];
 #pragma unroll
-            for (int t = 0; t < C::KS0; ++t) xj[t] = j == 0 ? xc[0][t] : xc[1][t];
+                for (int t = 0; t < C::KS0; ++t) xj[t] = j == 0 ? xc[0][t] : xc[1][t];
 #pragma unroll
-            for (int o = 0; o < d_out; ++o) yj[o] = j == 0 ? yc[0][o] : yc[1][o];
-            CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xj, yj, ct * 16 + i16 < n);
+                for (int o = 0; o < d_out; ++o) yj[o] = j == 0 ? yc[0][o] : yc[1][o];
+                CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xj, yj, ct * 16 + i16 < n);
+            }
         }
-#endif
     }
     TB_STAMP(5); TSTAMPO(62);
 
