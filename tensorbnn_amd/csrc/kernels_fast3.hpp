@@ -1492,9 +1492,7 @@ struct Epi3 {
         f32x4* st = reinterpret_cast<f32x4*>(lds);
         float* lb = lds + ST_FLOATS;
         float* dense = lds + DENSE_OFF;
-        f32x4 own[KMAX];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) own[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 own[KMAX];                                                          // (entries of staged tiles stay unset and unread)
         __syncthreads();                                                          // images and exchange buffers are dead
         stage<W>(st, own, dW, dWc, lane);
         stage_nf_coop<W>(st, dWc, lane);
