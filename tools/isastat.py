@@ -7,7 +7,7 @@ import re, sys, collections
 path, key = sys.argv[1], sys.argv[2]
 lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(key) + r"\w*:", l))
-end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))      # (not the first s_endpgm: a kernel may return early)
 raw = lines[start:end]
 body = [l.strip() for l in raw if l.strip() and not l.strip().startswith((";", ".section", ".p2align", ".type", ".globl"))]
 if "--all" in sys.argv:
