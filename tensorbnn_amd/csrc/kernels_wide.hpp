@@ -148,6 +148,12 @@ struct WideCfg {
     static constexpr int PX = 16 * NT0 + 4;                     // x image pitch
     static constexpr int XIMG_FLOATS = 16 * PX;
     static constexpr int DZB = 4, PZ = 16 * DZB + 4;            // delta_0 transposed DZB tiles at a time
+    // dW_0's accumulators on the asm form (pinned to AccVGPRs, no software wait states): never where a group of delta_0 tiles -- DZB of them, or
+    // the MT0 % DZB left over -- takes exactly TWO accumulators in turn (one other MFMA between two visits: the distance at which the asm
+    // form read a stale accumulator; one accumulator back to back and three or more in turn are the tested cases)
+    static constexpr int dw0_turn(int tiles) { return NT0 * tiles; }
+    static constexpr bool DW0_FAR = dw0_turn(DZB < MT0 ? DZB : MT0) > 1 && dw0_turn(DZB < MT0 ? DZB : MT0) != 2 &&
+                                    (MT0 <= DZB || MT0 % DZB == 0 || dw0_turn(MT0 % DZB) != 2);
     static constexpr int SCR_FLOATS = 16 * PZ;
     // RESIDENT: the whole image (dense, unpadded chunks) fits in LDS next to the per-wave scratch -> no stream, no
     // ring, no barriers in the row loop (configs[4]: 100-wide layers); otherwise the 4-slot ring (configs[3])
@@ -199,7 +205,9 @@ struct WideCfg {
 #if !defined(WIDE_TBLOCK) || WIDE_TBLOCK
     // (transposed blocks, operands straight into registers: no LDS; two waves per SIMD when accumulators + operand sets fit)
     static constexpr int maxSmall() { int m = 0; for (int l = 1; l <= NM; ++l) { int v = TA(l) + 2 * QM(l) + 4 * QP(l); m = v > m ? v : m; } return m; }
-    static constexpr int DW_OCC = (WIDE_DW_OCC_MAX >= 2 && 4 * maxDWT() + 4 * maxSmall() + 40 <= 232) ? 2 : 1;
+    // (a layer with two M tiles per wave takes its a-blocks in pairs -- dw_wide_layer --: two operand blocks and their refills live at once)
+    static constexpr bool anyQM2() { for (int l = 1; l <= NM; ++l) if (QM(l) == 2) return true; return false; }
+    static constexpr int DW_OCC = (WIDE_DW_OCC_MAX >= 2 && 4 * maxDWT() + 4 * maxSmall() + 40 + (anyQM2() ? 36 : 0) <= 232) ? 2 : 1;
 #else
     static constexpr int DW_OCC = (WIDE_DW_OCC_MAX >= 2 && 2 * WIDE_RING * DW_SLOT_FLOATS * 4 <= 150 * 1024 &&
                                    4 * maxDWT() + 4 * DW_NGW * WIDE_DW_PD + 48 <= 232) ? 2 : 1;
@@ -737,7 +745,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                         for (int nt = 0; nt < C::NT0; ++nt)
 #if WIDE_DW0_AGPR
-                            mfma16_acc<(C::NT0 * (C::DZB < C::MT0 ? C::DZB : C::MT0) > 1)>(dW0[t * C::NT0 + nt], Aop[t - b0][s], Bop[nt][s]);
+                            mfma16_acc<C::DW0_FAR>(dW0[t * C::NT0 + nt], Aop[t - b0][s], Bop[nt][s]);
 #else
                             dW0[t * C::NT0 + nt] = mfma16(Aop[t - b0][s], Bop[nt][s], dW0[t * C::NT0 + nt]);
 #endif
@@ -899,12 +907,49 @@ __device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, l
         load_small(rn, An, Zn);
         const __amdgpu_buffer_rsrc_t ran = rsa(rn);
         WIDE_FENCE();
+        if constexpr (QM == 2) {
+            // TWO M tiles per wave: taken in turn per a-block, an accumulator would be revisited with ONE other MFMA in between -- the
+            // distance at which the asm form reads a stale accumulator (no software wait states around inline asm; found by
+            // tools/experiments/family_fuzz.py on 32 -> 116 -> 187 -> 114 -> 1: dW_2's tiles m < 4, u < 4 off by tens of percent and
+            // not even repeatable, while 8 -> 128 -> 128 -> 128 -> 1 passed).  The a-blocks are therefore taken in PAIRS: four accumulators
+            // in turn; an odd last block runs on the builtin form (the compiler keeps its wait states).
+            sfor<0, (TAl + 1) / 2>(SFOR_LAMBDA(h) {
+                constexpr int u = 2 * SFOR_VAL(h);
+                constexpr bool two = u + 1 < TAl;
+                constexpr int u1 = two ? u + 1 : u;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < QM; ++j) {
+                        mfma16_acc<two>(acc[j * TAl + u], A[j][s], B[u][s]);
+                        if constexpr (two) mfma16_acc<true>(acc[j * TAl + u1], A[j][s], B[u1][s]);
+                    }
+                sfor<0, RM>(SFOR_LAMBDA(k) {                          // left-over pairs on a-blocks u, u + 1
+                    constexpr int pp = u + SFOR_VAL(k) * TAl;
+                    if (wave == pp % 4) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) mfma16_acc<false>(acc[QM * TAl + pp / 4], Z[SFOR_VAL(k)][s], B[u][s]);
+                    }
+                    if constexpr (two) {
+                        constexpr int pq = u1 + SFOR_VAL(k) * TAl;
+                        if (wave == pq % 4) {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) mfma16_acc<false>(acc[QM * TAl + pq / 4], Z[SFOR_VAL(k)][s], B[u1][s]);
+                        }
+                    }
+                });
+                WIDE_FENCE();
+                B[u] = ld(ran, u);
+                if constexpr (two) B[u1] = ld(ran, u1);
+                WIDE_FENCE();
+            });
+        } else {
         sfor<0, TAl>(SFOR_LAMBDA(u) {
             constexpr int u = SFOR_VAL(u);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int j = 0; j < QM; ++j) mfma16_acc<(QM > 1)>(acc[j * TAl + u], A[j][s], B[u][s]);
+                for (int j = 0; j < QM; ++j) mfma16_acc<(QM > 2)>(acc[j * TAl + u], A[j][s], B[u][s]);
             sfor<0, RM>(SFOR_LAMBDA(k) {                              // left-over pairs on a-block u
                 constexpr int pp = u + SFOR_VAL(k) * TAl;
                 if (wave == pp % 4) {
@@ -916,6 +961,7 @@ __device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, l
             B[u] = ld(ran, u);
             WIDE_FENCE();
         });
+        }
     };
     for (long rt = rt0; rt < rt1; rt += 2) {
         body(rt, A0, Z0, A1, Z1);
