@@ -88,6 +88,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
             elif "ScratchSize [bytes/lane]:" in l and name and any(k in name for k in ("k_fwd_bwd_", "k_chain_wide", "k_dw_wide", "k_forward_fast3")):
                 if int(l.split("ScratchSize [bytes/lane]:")[1].split("[")[0]) > 0 and os.environ.get("TBNN_ALLOW_SPILL") != "1":   # (stamped diagnostic builds)
                     raise RuntimeError(f"{os.path.basename(cmd[-3])}: fused kernel {name} spills to scratch")
+    # every kernel object disassembled and checked for VALU-write -> asm-MFMA-read pairs without wait states (hazard_lint.py); a unit that shows
+    # one is rebuilt with the wait states inside the asm statements and must then be clean
+    from . import hazard_lint
+    for (cmd, _p, _e), obj in zip(procs, objs):
+        if not cmd[-3].endswith(".hip"):
+            continue
+        found = hazard_lint.check(obj)
+        if found:
+            print(f"{os.path.basename(obj)}: {len(found)} asm MFMAs behind a VALU write of their operand ({hazard_lint.describe(found, 2)}): "
+                  "rebuilding with -DTBNN_ASM_MFMA_NOP=1", file=sys.stderr, flush=True)
+            cmd2 = cmd[:1] + ["-DTBNN_ASM_MFMA_NOP=1"] + cmd[1:]
+            subprocess.run(cmd2, check=True, stderr=subprocess.DEVNULL)
+            found = hazard_lint.check(obj)
+            if found:
+                raise RuntimeError(f"{os.path.basename(obj)}: MFMA operand hazards remain: {hazard_lint.describe(found)}")
     # link next to the target and rename: a rank that waits for the file (bench.py) never maps a half-written library
     tmp = OUT + f".{os.getpid()}.tmp"
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs

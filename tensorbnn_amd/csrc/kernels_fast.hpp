@@ -204,10 +204,22 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #ifndef TBNN_ACC_AGPR
 #define TBNN_ACC_AGPR 1
 #endif
+// TBNN_ASM_MFMA_NOP=1: every asm MFMA carries two wait states of its own.  The hardware wants them between a VALU write of a VGPR and an MFMA
+// that reads it as SrcA / SrcB; the compiler keeps them for its own MFMAs and inserts nothing around inline asm.  An operand the register
+// allocator parked in an AccVGPR comes back through v_accvgpr_read (a VALU write), possibly right in front of the asm MFMA: build.py / jit.py
+// disassemble every unit (tensorbnn_amd/hazard_lint.py) and rebuild one that shows such a pair with this switch.
+#ifndef TBNN_ASM_MFMA_NOP
+#define TBNN_ASM_MFMA_NOP 0
+#endif
+#if TBNN_ASM_MFMA_NOP
+#define TBNN_MFMA_PRE "s_nop 1\n\t"
+#else
+#define TBNN_MFMA_PRE ""
+#endif
 template <bool FAR>
 __device__ __forceinline__ void mfma16_acc(f32x4& c, float a, float b) {
 #if TBNN_ACC_AGPR
-    if constexpr (FAR) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    if constexpr (FAR) asm volatile(TBNN_MFMA_PRE "v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     else c = mfma16(a, b, c);
 #else
     c = mfma16(a, b, c);
@@ -216,7 +228,7 @@ __device__ __forceinline__ void mfma16_acc(f32x4& c, float a, float b) {
 template <bool FAR>
 __device__ __forceinline__ void mfma4_acc(f32x4& c, float a, float b) {        // the 16-block 4x4x1 form, accumulator pinned like mfma16_acc
 #if TBNN_ACC_AGPR
-    if constexpr (FAR) asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    if constexpr (FAR) asm volatile(TBNN_MFMA_PRE "v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     else c = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 #else
     c = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);

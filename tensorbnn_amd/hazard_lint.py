@@ -1,0 +1,115 @@
+"""Build-time check of the compiled kernels: an MFMA must not read, as SrcA / SrcB, a VGPR that a VALU instruction wrote fewer than two wait
+states earlier (gfx90a / gfx940 / gfx950: the hardware does not interlock this pair; an MFMA issued right behind the write reads the OLD
+register).  The compiler keeps the distance for its own MFMAs; it inserts nothing around INLINE ASM, and the fused kernels' dW accumulation is
+inline asm (accumulators pinned to AccVGPRs, kernels_fast.hpp: mfma16_acc).  When register pressure makes the compiler park an operand in an
+AccVGPR, it comes back through `v_accvgpr_read` -- a VALU write -- possibly right in front of the asm MFMA: wrong and unrepeatable dW tiles
+(k_dw_wide at 15 -> 170 -> 114 -> 1 with two waves per SIMD, found by tools/experiments/transition_fuzz.py in round 5).
+
+build.py and jit.py disassemble every kernel object they produce and call `hazards()`; a unit with hazards is rebuilt with
+-DTBNN_ASM_MFMA_NOP=1 (every asm MFMA carries its own two wait states) and checked again.
+
+Wait states are counted as the compiler's hazard recognizer counts them: one per instruction between the write and the MFMA, N + 1 for `s_nop N`."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+NEED = 2
+LLVM_BIN = os.environ.get("TBNN_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+
+
+def _vregs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def hazards(listing: str, need: int = NEED, asm_only: bool = False):
+    """[(kernel, writer, mfma, wait states between)] in a disassembly (llvm-objdump -d) or a compiler listing (-S; asm_only: only the MFMAs
+    between ;;#ASMSTART / ;;#ASMEND)"""
+    out, kernel, window, in_asm = [], None, [], False
+    for ln in listing.split("\n"):
+        t = ln.strip()
+        m = re.match(r"^[0-9a-f]* ?<?(_Z\w+)>?:", ln)
+        if m:
+            kernel, window = m.group(1), []
+            continue
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith((";", ".", "//")):
+            continue
+        if t.endswith(":"):
+            window = []                       # a label: another path joins here
+            continue
+        t = t.split("//")[0].split(";")[0].strip()
+        if not t:
+            continue
+        op = t.split()[0]
+        args = [a.strip() for a in t[len(op):].split(",")]
+        if op.startswith("v_mfma") and (in_asm or not asm_only):
+            src = set()
+            for a in args[1:3]:
+                src |= _vregs(a)
+            dist = 0
+            for txt, wr, ws in reversed(window):
+                if wr & src:
+                    out.append((kernel, txt, t, dist))
+                    break
+                dist += ws
+                if dist >= need:
+                    break
+        wr = set()
+        if op.startswith("v_") and not op.startswith(("v_mfma", "v_cmp", "v_accvgpr_write", "v_smfmac")) and args:
+            wr = _vregs(args[0])
+        ws = (int(args[0]) + 1) if op == "s_nop" and args and args[0].isdigit() else 1
+        window.append((t, wr, ws))
+        window = window[-(need + 2):]
+    return out
+
+
+def disassemble(path: str) -> str:
+    """device code (gfx950) of a fat object / shared library as llvm-objdump text"""
+    d = tempfile.mkdtemp(prefix="tbnn_lint_")
+    try:
+        f = os.path.join(d, os.path.basename(path))
+        shutil.copy(path, f)
+        subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "--offloading", f], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        texts = []
+        for g in sorted(os.listdir(d)):
+            if "amdgcn" in g:
+                texts.append(subprocess.run([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", os.path.join(d, g)], check=True, capture_output=True,
+                                            text=True).stdout)
+        if not texts:
+            raise RuntimeError(f"no device code object found in {path}")
+        return "\n".join(texts)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def check(path: str, need: int = NEED):
+    """hazards of a compiled object / library (empty list: clean)"""
+    return hazards(disassemble(path), need)
+
+
+def describe(found, limit: int = 3) -> str:
+    per = {}
+    for k, w, m, dist in found:
+        per.setdefault(k, []).append((w, m, dist))
+    return "; ".join(f"{k[:90]}: {len(v)} (first: `{v[0][0]}` -> `{v[0][1]}`, {v[0][2]} wait states)" for k, v in list(per.items())[:limit])
+
+
+if __name__ == "__main__":
+    import sys
+    p = sys.argv[1]
+    need = int(sys.argv[2]) if len(sys.argv) > 2 else NEED
+    found = hazards(open(p).read(), need, asm_only=True) if p.endswith(".s") else check(p, need)
+    print(describe(found, 20) if found else "clean")
+    print(f"{p}: {len(found)} hazards")
+    sys.exit(1 if found else 0)

@@ -201,21 +201,39 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                 tmp = so + f".{os.getpid()}.tmp"
                 with open(src, "w") as f:
                     f.write(source(dims, hact, lact, bern, fam))
-                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
-                cmd += NARROW_FLAGS + extra      # as build.py compiles the kernels (VGPR-form chain MFMAs)
-                cmd += ["-Rpass-analysis=kernel-resource-usage", "-o", tmp, src]      # the remarks carry each kernel's ScratchSize
-                if verbose:
-                    print(" ".join(cmd), flush=True)
-                try:
-                    r = subprocess.run(cmd, capture_output=True, text=True)      # a child process: never an exec of this one
-                    rc, err = r.returncode, r.stderr
-                except OSError as e:
-                    rc, err = -1, str(e)
-                # a fused kernel that needs scratch memory has lost its register plan (accumulators demoted to a stack array
-                # are read back without the wait states an MFMA result needs): refuse it, the next family takes the shape
-                spills = [int(m) for m in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", err)]
-                if rc == 0 and any(v > 0 for v in spills):
-                    rc, err = 1, f"{src}:1:1: error: kernel family {fam} spills to scratch for this shape ({max(spills)} bytes per lane)\n"
+                # second attempt only when the first one's disassembly shows an asm MFMA right behind a VALU write of its operand
+                # (hazard_lint.py): the same sources with the wait states inside the asm statements
+                for nop in ([], ["-DTBNN_ASM_MFMA_NOP=1"]):
+                    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
+                    cmd += NARROW_FLAGS + extra + nop      # as build.py compiles the kernels (VGPR-form chain MFMAs)
+                    cmd += ["-Rpass-analysis=kernel-resource-usage", "-o", tmp, src]      # the remarks carry each kernel's ScratchSize
+                    if verbose:
+                        print(" ".join(cmd), flush=True)
+                    try:
+                        r = subprocess.run(cmd, capture_output=True, text=True)      # a child process: never an exec of this one
+                        rc, err = r.returncode, r.stderr
+                    except OSError as e:
+                        rc, err = -1, str(e)
+                    # a fused kernel that needs scratch memory has lost its register plan (accumulators demoted to a stack array
+                    # are read back without the wait states an MFMA result needs): refuse it, the next family takes the shape
+                    spills = [int(m) for m in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", err)]
+                    if rc == 0 and any(v > 0 for v in spills):
+                        rc, err = 1, f"{src}:1:1: error: kernel family {fam} spills to scratch for this shape ({max(spills)} bytes per lane)\n"
+                    if rc != 0:
+                        break
+                    try:
+                        from . import hazard_lint
+                        found = hazard_lint.check(tmp)
+                    except Exception as e:          # no disassembler on this machine: the library is used as built
+                        print(f"tensorbnn_amd: kernel library not checked for MFMA operand hazards ({e})", file=sys.stderr, flush=True)
+                        found = []
+                    if not found:
+                        break
+                    if nop:
+                        rc, err = 1, f"{src}:1:1: error: kernel family {fam}: MFMA operand hazards remain ({hazard_lint.describe(found)})\n"
+                    elif verbose:
+                        print(f"tensorbnn_amd: {len(found)} asm MFMAs behind a VALU write of their operand ({hazard_lint.describe(found, 1)}): "
+                              "rebuilding with their own wait states", file=sys.stderr, flush=True)
                 for f_ in (src,):
                     if os.path.exists(f_):
                         os.remove(f_)

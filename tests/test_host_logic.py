@@ -510,3 +510,42 @@ def test_cpu_quota_warning(monkeypatch, tmp_path):
         warnings.simplefilter("always")
         nat._warn_cpu_quota_once()
     assert not w
+
+
+# ---- build-time check of the compiled kernels (tensorbnn_amd/hazard_lint.py): no asm MFMA right behind a VALU write of its operand
+def test_hazard_lint_finds_the_pair_and_counts_wait_states():
+    from tensorbnn_amd import hazard_lint as hl
+    listing = """
+0000000000001000 <_Z9k_exampleILi1EEvPf>:
+	v_accvgpr_read_b32 v60, a94                                // 000000001000: D3D8403C 1800015E
+	s_waitcnt vmcnt(1)                                         // 000000001008: BF8C0F71
+	v_mfma_f32_16x16x4_f32 a[76:79], v6, v60, a[76:79]         // 00000000100C: D3C2804C 0D32790
+	v_accvgpr_read_b32 v61, a95                                // 000000001014: D3D8403D 1800015F
+	s_nop 1                                                    // 00000000101C: BF800001
+	v_mfma_f32_16x16x4_f32 a[76:79], v7, v61, a[76:79]         // 000000001020: D3C2804C 0D327B07
+	v_fma_f32 v8, v1, v2, v3                                   // 000000001028
+	v_mov_b32_e32 v9, v10                                      // 000000001030
+	v_mfma_f32_16x16x4_f32 a[0:3], v8, v62, a[0:3]             // 000000001034
+	v_mov_b32_e32 v11, v10                                     // 00000000103C
+	v_mov_b32_e32 v12, v10                                     // 000000001040
+	v_mov_b32_e32 v14, v10                                     // 000000001044
+	v_mfma_f32_16x16x4_f32 a[0:3], v13, v11, a[0:3]            // 000000001048
+"""
+    found = hl.hazards(listing)
+    # pair 1: one wait state (the s_waitcnt) between -> hazard; pair 2: s_nop 1 = two -> fine; pair 3: v_fma then one instruction -> hazard;
+    # pair 4: two instructions between the write and the MFMA -> fine
+    assert [(f[1].split()[0], f[3]) for f in found] == [("v_accvgpr_read_b32", 1), ("v_fma_f32", 1)], found
+    assert all(f[0] == "_Z9k_exampleILi1EEvPf" for f in found)
+    assert len(hl.hazards(listing, need=3)) == 4
+    assert "k_example" in hl.describe(found)
+
+
+def test_built_library_has_no_mfma_operand_hazard():
+    """the product library's device code, disassembled: what build.py checked object by object when it built it"""
+    import os
+    from tensorbnn_amd import hazard_lint as hl, _native as nat
+    if not os.path.exists(os.path.join(hl.LLVM_BIN, "llvm-objdump")):
+        pytest.skip("no llvm-objdump on this machine")
+    text = hl.disassemble(nat.LIB_PATH)
+    assert text.count("v_mfma_f32_16x16x4") > 1000           # the kernels are in there
+    assert hl.hazards(text) == []
