@@ -908,11 +908,13 @@ __device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, l
         const __amdgpu_buffer_rsrc_t ran = rsa(rn);
         WIDE_FENCE();
         if constexpr (QM == 2) {
-            // TWO M tiles per wave: taken in turn per a-block, an accumulator would be revisited with ONE other MFMA in between -- the
-            // distance at which the asm form reads a stale accumulator (no software wait states around inline asm; found by
-            // tools/experiments/family_fuzz.py on 32 -> 116 -> 187 -> 114 -> 1: dW_2's tiles m < 4, u < 4 off by tens of percent and
-            // not even repeatable, while 8 -> 128 -> 128 -> 128 -> 1 passed).  The a-blocks are therefore taken in PAIRS: four accumulators
-            // in turn; an odd last block runs on the builtin form (the compiler keeps its wait states).
+            // TWO M tiles per wave: the a-blocks are taken in PAIRS -- four accumulators in turn instead of two (an asm-form accumulator is
+            // revisited back to back or after at least two other MFMAs in every family); an odd last block runs on the builtin form.
+            // (Round 5: 32 -> 116 -> 187 -> 114 -> 1 and 15 -> 170 -> 114 -> 1 had wrong, unrepeatable dW tiles here.  The cause that was
+            // FOUND in the disassembly is the operand side: with two waves per SIMD the register allocator parks a-blocks in AccVGPRs, and
+            // the v_accvgpr_read that brings one back stood straight in front of the asm MFMA that reads it -- a VALU write and an MFMA read
+            // with no wait state between them.  build.py / jit.py now check every unit for that pair and rebuild it with the wait states
+            // inside the asm statement: tensorbnn_amd/hazard_lint.py.)
             sfor<0, (TAl + 1) / 2>(SFOR_LAMBDA(h) {
                 constexpr int u = 2 * SFOR_VAL(h);
                 constexpr bool two = u + 1 < TAl;
