@@ -27,10 +27,24 @@ def _vregs(tok):
     return {int(m.group(1))} if m else set()
 
 
+# The second pair: an MFMA writes ArchVGPRs (the chain MFMAs: -amdgpu-mfma-vgpr-form) and a VALU instruction reads them before the result has
+# landed -- passes + 2 wait states (what the compiler keeps: 2-pass 4x4x1 4, 8-pass 16x16x4 f32 10, 16-pass 18).  The compiler keeps that distance for
+# VALU code it generates; an INLINE-ASM reader (the packed relu mask / multiply of kernels_fast.hpp: relu_step2, pkmul2, mul_legacy) relies
+# on mfma_settle() standing in between, and a reader that slips in front of it reads the old register (k_fwd_bwd_mid at 80 -> 80 -> 51 -> 2,
+# round 5: delta of the last tile wrong by percent).
+def _mfma_read_need(op: str) -> int:
+    if "4x4x" in op:
+        return 4
+    if "32x32x" in op:
+        return 18
+    return 10
+
+
 def hazards(listing: str, need: int = NEED, asm_only: bool = False):
-    """[(kernel, writer, mfma, wait states between)] in a disassembly (llvm-objdump -d) or a compiler listing (-S; asm_only: only the MFMAs
-    between ;;#ASMSTART / ;;#ASMEND)"""
+    """[(kernel, writer, reader, wait states between)] in a disassembly (llvm-objdump -d) or a compiler listing (-S; asm_only: only the MFMAs
+    between ;;#ASMSTART / ;;#ASMEND are checked for the first pair)"""
     out, kernel, window, in_asm = [], None, [], False
+    mwrites = []          # MFMA results in ArchVGPRs not yet landed: [regs, text, wait states so far, needed]
     for ln in listing.split("\n"):
         t = ln.strip()
         m = re.match(r"^[0-9a-f]* ?<?(_Z\w+)>?:", ln)
@@ -46,13 +60,16 @@ def hazards(listing: str, need: int = NEED, asm_only: bool = False):
         if not t or t.startswith((";", ".", "//")):
             continue
         if t.endswith(":"):
-            window = []                       # a label: another path joins here
+            window, mwrites = [], []          # a label: another path joins here
             continue
         t = t.split("//")[0].split(";")[0].strip()
         if not t:
             continue
         op = t.split()[0]
         args = [a.strip() for a in t[len(op):].split(",")]
+        if op.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc", "s_swappc")):
+            window, mwrites = [], []          # a disassembly has no labels: what follows a branch may be reached from elsewhere
+            continue
         if op.startswith("v_mfma") and (in_asm or not asm_only):
             src = set()
             for a in args[1:3]:
@@ -69,6 +86,20 @@ def hazards(listing: str, need: int = NEED, asm_only: bool = False):
         if op.startswith("v_") and not op.startswith(("v_mfma", "v_cmp", "v_accvgpr_write", "v_smfmac")) and args:
             wr = _vregs(args[0])
         ws = (int(args[0]) + 1) if op == "s_nop" and args and args[0].isdigit() else 1
+        # second pair: a VALU (non-MFMA) instruction reading an MFMA result that has not landed
+        if op.startswith("v_") and not op.startswith(("v_mfma", "v_smfmac")) and mwrites:
+            srcs = set()
+            for a in (args if op.startswith(("v_cmp", "v_accvgpr_write")) else args[1:]):
+                srcs |= _vregs(a.split()[0] if a else a)
+            for regs, txt, age, needed in mwrites:
+                if regs & srcs and age < needed:
+                    out.append((kernel, txt, t, age))
+                    break
+        mwrites = [[r - wr, x, a + ws, nd] for r, x, a, nd in mwrites if a + ws < nd and (r - wr)]      # (a register written since is that writer's)
+        if op.startswith("v_mfma") and args:
+            dst = _vregs(args[0])
+            if dst:
+                mwrites.append([dst, t, 0, _mfma_read_need(op)])
         window.append((t, wr, ws))
         window = window[-(need + 2):]
     return out
