@@ -18,6 +18,7 @@
 #include "kernels_hyper.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_fast3.hpp"
+#include "kernels_traj.hpp"
 #include "kernels_layered.hpp"
 #include "wide_api.hpp"
 #include "mid_api.hpp"
@@ -98,6 +99,7 @@ struct tbnn_ctx {
     // per-chain step control (tbnn_hmc_step_each / tbnn_hyper_step_each): [C] on the device, staged through pinned memory
     StepCtl* ctl = nullptr; StepCtl* ctl_host = nullptr; float* epsh = nullptr; float* epsh_host = nullptr;
     bool merge_ends = true;                // TBNN_MERGE_ENDS (read at tbnn_create): decision + record + commit in one k_energy launch
+    bool traj = true;                      // TBNN_TRAJ (read at tbnn_create; 0: off): whole trajectories of small problems in one launch (kernels_traj.hpp)
 };
 
 extern "C" const char* tbnn_last_error(void) { return g_err.c_str(); }
@@ -394,6 +396,7 @@ static int create_impl(const tbnn_net_desc* desc, int device, uint64_t seed, uin
     }
     { const char* e1 = getenv("TBNN_FAST_SINGLE"); if (e1 && atoi(e1)) h->nd.reserved_flags |= 1; }
     { const char* e2 = getenv("TBNN_MERGE_ENDS"); h->merge_ends = !(e2 && atoi(e2) == 0); }
+    { const char* e3 = getenv("TBNN_TRAJ"); h->traj = !(e3 && atoi(e3) == 0); }
     const char* env = getenv("TBNN_PROFILE_FWDBWD");
     h->profile = env ? atoi(env) : 0;
 #undef HIPB
@@ -1073,7 +1076,17 @@ static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, 
     if (d_trace && cached) hipLaunchKernelGGL(k_trace_logp_cur, dim3(1), dim3(64), 0, h->stream, (const Scal*)h->sc, d_trace);
     hipLaunchKernelGGL(k_begin, dim3(1, h->C), dim3(1024), 0, h->stream, nd, d_p0, d_logu, h->epoch, h->key0, h->key1, h->p, h->sc, h->seed_hi);
     launch_update(h, UPD_FIRST, eps, h->eta, h->q, h->g, ctl, 0);
-    for (int t = 1; t <= L; ++t) {
+    // a small problem on an ahead-of-time narrow kernel: the L leapfrog steps in ONE launch, one workgroup per chain (kernels_traj.hpp).
+    // Not for a traced transition (per-step energies), a sharded gradient, a profiled run of the per-step kernels.
+    const bool traj = h->traj && !d_trace && L >= 1 && h->kernel == TBNN_KERNEL_FAST && h->fast_ver == 3 && !h->jit && h->wide_id < 0 && h->mid_id < 0 &&
+                      !h->lay && !h->shard && h->profile == 0 && h->n <= TBNN_TRAJ_MAX_ROWS && fast3_traj_available(h->fast_id);
+    if (traj) {
+        if (fast3_traj_launch(h->fast_id, h->C, h->stream, nd, h->qimg, (long)h->img_floats, h->eta, h->dX, h->dY, h->n, h->q, h->p, h->g, h->gd, h->imgmap,
+                              h->pstat, stat_entries(h), eps, L, ctl))
+            return fail(-2, "trajectory kernel launch failed");
+        h->q_img_valid = false;            // the images the kernel advanced lived in LDS
+    }
+    for (int t = 1; t <= L && !traj; ++t) {
         rc = launch_fwd_bwd(h, h->q, h->eta, ctl, t);
         if (rc) return rc;
         if (d_trace && t < L) {
