@@ -6,7 +6,7 @@
 #include "common.hpp"
 #include "wide_api.hpp"
 
-#define TBNN_JIT_ABI 5      // 5: ChainStride carries the per-chain step control
+#define TBNN_JIT_ABI 6      // 5: ChainStride carries the per-chain step control; 6: the trajectory kernel of small problems (kernels_traj.hpp)
 enum { TBNN_FAMILY_NARROW = 1, TBNN_FAMILY_WIDE = 2 };
 
 struct FusedOps {
@@ -25,6 +25,11 @@ struct FusedOps {
     // narrow family, optional: forward only for `nets` networks (images img_stride floats apart), fout[net][d_out][n]
     int (*nforward)(int gx, int nets, hipStream_t st, const float* qimgs, long img_stride, const float* X, long n, float* fouts,
                     long out_stride);
+    // narrow family, optional: the L leapfrog steps of a transition in one launch, one workgroup per chain, for problems of at most
+    // traj_max_rows rows (kernels_traj.hpp; null / 0: none -- the per-step kernels)
+    int traj_max_rows;
+    int (*traj)(int nchains, hipStream_t st, const NetDev* nd, const float* qimg, long img_stride, const float* eta, const float* X, const float* Y, long n,
+                float* q, float* p, float* g, float* gd, const int* imgmap, double* pstat, int nstat, float eps, int L, const StepCtl* ctl);
     // wide family: k_chain_wide + k_dw_wide + k_reduce_wide
     void (*plan)(long n, WidePlan* plan);
     int (*wlaunch)(const WidePlan* plan, hipStream_t st, const NetDev* nd, const float* qimg, const float* eta,

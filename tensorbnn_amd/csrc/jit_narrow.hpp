@@ -3,6 +3,7 @@
 #pragma once
 #define TBNN_NO_FAST_REGISTRY
 #include "kernels_fast3.hpp"
+#include "kernels_traj.hpp"
 #include "fused_ops.hpp"
 
 template <class S, bool F3>
@@ -30,6 +31,19 @@ struct JitNarrow {
             return -1;
         }
     }
+    // whole trajectories of small problems (kernels_traj.hpp): 16 waves where the images of 16 waves fit, else 4, else none
+    // (-DTBNN_TRAJ_WAVES=0: none -- jit.py's second attempt when only the trajectory kernel of a shape needs scratch memory)
+    static constexpr int TRAJ_NW = (!F3 || TBNN_TRAJ_WAVES == 0) ? 0 : (TBNN_TRAJ_WAVES == 16 && TrajCfg<S, 16>::OK) ? 16 : (TrajCfg<S, 4>::OK ? 4 : 0);
+    static int traj(int nchains, hipStream_t st, const NetDev* nd, const float* qimg, long img_stride, const float* eta, const float* X, const float* Y, long n,
+                    float* q, float* p, float* g, float* gd, const int* imgmap, double* pstat, int nstat, float eps, int L, const StepCtl* ctl) {
+        if constexpr (TRAJ_NW > 0) {
+            hipLaunchKernelGGL((k_traj_fast3<S, TRAJ_NW>), dim3(1, nchains), dim3(64 * TRAJ_NW), 0, st, *nd, qimg, img_stride, eta, X, Y, n, q, p, g, gd, imgmap,
+                               pstat, nstat, eps, L, ctl);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        } else {
+            return -1;
+        }
+    }
     static void image_map(int* map) { ImageMap<S, 0>::run(map); }
     static void fill(FusedOps* o) {
         fused_ops_shape<S>(o, F3 ? "jit-fast3" : "jit-fast");
@@ -38,6 +52,8 @@ struct JitNarrow {
         o->image_map = &image_map; o->grid = &grid; o->launch = &launch;
         o->nforward = F3 ? &nforward : nullptr;
         o->plan = nullptr; o->wlaunch = nullptr; o->wforward = nullptr;
+        o->traj = TRAJ_NW > 0 ? &traj : nullptr;
+        o->traj_max_rows = TRAJ_NW > 0 ? TBNN_TRAJ_MAX_ROWS : 0;
     }
 };
 

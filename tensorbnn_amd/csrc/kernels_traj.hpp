@@ -44,7 +44,9 @@ struct TrajCfg {
     static constexpr int COPY_FLOATS = T * 256 + FPR * 64;                            // NW > 4: every wave's copy first, summed four by four into the 4
     static constexpr int RAW_OFF = DENSE_OFF + P4;
     static constexpr int LDS_FLOATS = RAW_OFF + (NW > FAST_WAVES ? NW * COPY_FLOATS : 0);
-    static constexpr bool OK = (NW == 4 || NW == 16) && C::VL && C::DW3_TILES > 0 && C::EP3_TILES == C::DW3_TILES && KP <= TRAJ_MAX_KP &&
+    // four waves per SIMD have 128 registers each: only networks whose accumulators and fringe sums are a handful (configs[0]: 2 tiles + 5)
+    static constexpr bool REGS_OK = NW == 4 || (4 * T + FPR <= 40 && C::maxMT() <= 2);
+    static constexpr bool OK = (NW == 4 || NW == 16) && REGS_OK && C::VL && C::DW3_TILES > 0 && C::EP3_TILES == C::DW3_TILES && KP <= TRAJ_MAX_KP &&
                                (size_t)LDS_FLOATS * 4 + 256 <= 160 * 1024;
 };
 
@@ -246,11 +248,11 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(NW /
     for (int e = 1 + tid; e < nstat; e += THREADS) pstat[e] = 0.0;
 }
 
-#ifndef TBNN_NO_FAST_REGISTRY
-// ahead-of-time instantiations: the registry ids of kernels_fast3.hpp whose shapes are eligible; 16 waves where they fit
 #ifndef TBNN_TRAJ_WAVES
 #define TBNN_TRAJ_WAVES 16
 #endif
+#ifndef TBNN_NO_FAST_REGISTRY
+// ahead-of-time instantiations: the registry ids of kernels_fast3.hpp whose shapes are eligible; 16 waves where they fit
 template <class S> struct TrajPick { static constexpr int NW = (TBNN_TRAJ_WAVES == 16 && TrajCfg<S, 16>::OK) ? 16 : 4; };
 static inline bool fast3_traj_available(int id) {
     return (id == 1 && TrajCfg<ShapeC1, TrajPick<ShapeC1>::NW>::OK) || (id == 2 && TrajCfg<ShapeTR, TrajPick<ShapeTR>::NW>::OK);

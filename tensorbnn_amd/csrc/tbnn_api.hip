@@ -1078,11 +1078,16 @@ static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, 
     launch_update(h, UPD_FIRST, eps, h->eta, h->q, h->g, ctl, 0);
     // a small problem on an ahead-of-time narrow kernel: the L leapfrog steps in ONE launch, one workgroup per chain (kernels_traj.hpp).
     // Not for a traced transition (per-step energies), a sharded gradient, a profiled run of the per-step kernels.
-    const bool traj = h->traj && !d_trace && L >= 1 && h->kernel == TBNN_KERNEL_FAST && h->fast_ver == 3 && !h->jit && h->wide_id < 0 && h->mid_id < 0 &&
-                      !h->lay && !h->shard && h->profile == 0 && h->n <= TBNN_TRAJ_MAX_ROWS && fast3_traj_available(h->fast_id);
+    const bool traj = h->traj && !d_trace && L >= 1 && h->kernel == TBNN_KERNEL_FAST && h->wide_id < 0 && h->mid_id < 0 && !h->lay && !h->shard &&
+                      h->profile == 0 &&
+                      (h->jit ? (h->jit->family == TBNN_FAMILY_NARROW && h->jit->traj != nullptr && h->n <= h->jit->traj_max_rows)
+                              : (h->fast_ver == 3 && h->n <= TBNN_TRAJ_MAX_ROWS && fast3_traj_available(h->fast_id)));
     if (traj) {
-        if (fast3_traj_launch(h->fast_id, h->C, h->stream, nd, h->qimg, (long)h->img_floats, h->eta, h->dX, h->dY, h->n, h->q, h->p, h->g, h->gd, h->imgmap,
-                              h->pstat, stat_entries(h), eps, L, ctl))
+        const int trc = h->jit ? h->jit->traj(h->C, h->stream, &nd, h->qimg, (long)h->img_floats, h->eta, h->dX, h->dY, h->n, h->q, h->p, h->g, h->gd, h->imgmap,
+                                              h->pstat, stat_entries(h), eps, L, ctl)
+                               : fast3_traj_launch(h->fast_id, h->C, h->stream, nd, h->qimg, (long)h->img_floats, h->eta, h->dX, h->dY, h->n, h->q, h->p, h->g,
+                                                   h->gd, h->imgmap, h->pstat, stat_entries(h), eps, L, ctl);
+        if (trc)
             return fail(-2, "trajectory kernel launch failed");
         h->q_img_valid = false;            // the images the kernel advanced lived in LDS
     }

@@ -203,9 +203,13 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                     f.write(source(dims, hact, lact, bern, fam))
                 # second attempt only when the first one's disassembly shows an asm MFMA right behind a VALU write of its operand
                 # (hazard_lint.py): the same sources with the wait states inside the asm statements
-                for nop in ([], ["-DTBNN_ASM_MFMA_NOP=1"]):
+                notraj = []                                # set when only the optional trajectory kernel of the shape needs scratch memory
+                attempts = [[], ["-DTBNN_ASM_MFMA_NOP=1"]]
+                ai = 0
+                while ai < len(attempts):
+                    nop = attempts[ai]; ai += 1
                     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
-                    cmd += NARROW_FLAGS + extra + nop      # as build.py compiles the kernels (VGPR-form chain MFMAs)
+                    cmd += NARROW_FLAGS + extra + nop + notraj      # as build.py compiles the kernels (VGPR-form chain MFMAs)
                     cmd += ["-Rpass-analysis=kernel-resource-usage", "-o", tmp, src]      # the remarks carry each kernel's ScratchSize
                     if verbose:
                         print(" ".join(cmd), flush=True)
@@ -216,8 +220,12 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                         rc, err = -1, str(e)
                     # a fused kernel that needs scratch memory has lost its register plan (accumulators demoted to a stack array
                     # are read back without the wait states an MFMA result needs): refuse it, the next family takes the shape
-                    spills = [int(m) for m in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", err)]
+                    per_fn = re.findall(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", err, re.S)
+                    spills = [int(v) for _f, v in per_fn]
                     if rc == 0 and any(v > 0 for v in spills):
+                        if not notraj and all(int(v) == 0 or "k_traj_" in f for f, v in per_fn):
+                            notraj = ["-DTBNN_TRAJ_WAVES=0"]; ai = 0          # the per-step kernels are fine: the same library without the trajectory kernel
+                            continue
                         rc, err = 1, f"{src}:1:1: error: kernel family {fam} spills to scratch for this shape ({max(spills)} bytes per lane)\n"
                     if rc != 0:
                         break

@@ -9,17 +9,22 @@ pytestmark = pytest.mark.gpu
 SHAPES = {
     "configs0": ([1, 10, 10, 1], o.ACT_RELU),              # the ahead-of-time instantiations the trajectory kernel exists for
     "trainreg": ([1, 10, 10, 10, 1], o.ACT_TANH),
+    # run-time compiled narrow shapes (the kernel table's `traj` entry): 4 waves per workgroup (their accumulators do not fit four waves per
+    # SIMD), fringe units, two outputs, a single hidden layer
+    "jit_24": ([6, 24, 24, 1], o.ACT_TANH),
+    "jit_fringe_two_outputs": ([7, 17, 33, 2], o.ACT_RELU),
+    "jit_one_hidden": ([2, 12, 1], o.ACT_SIGMOID),
 }
 
 
 def make(native, spec, monkeypatch, traj, **kw):
     monkeypatch.setenv("TBNN_TRAJ", "1" if traj else "0")
     layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
-    return native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, **kw)
+    return native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, jit=True, **kw)
 
 
 @pytest.mark.parametrize("shape", list(SHAPES))
-@pytest.mark.parametrize("n", [7, 100, 1000])
+@pytest.mark.parametrize("n", [7, 100, 1000])          # (1,000 <= TBNN_TRAJ_MAX_ROWS = 1,200)
 def test_trajectory_kernel_transition_vs_oracle_and_two_kernel_step(native, monkeypatch, shape, n):
     dims, act = SHAPES[shape]
     spec, X, Y, theta, eta = o.synth_problem(dims, n, act, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN)

@@ -1,6 +1,6 @@
 """dev: random architectures (whatever family serves them), one injected HMC transition and one hyper transition against the fp64 oracle, and a
 chain group of three against its solo chains bit for bit (free-running on the device's draws):
-  python tools/experiments/transition_fuzz.py [n_shapes] [seed]"""
+  python tools/experiments/transition_fuzz.py [n_shapes] [seed] [family 0..4: narrow, mid-width, tall, wide, anything; default: all] [max rows]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 REC = ("log_accept_ratio", "accepted", "logp_old", "logp_new", "kinetic_old", "kinetic_new", "sjd", "accept_prob")
 bad = 0
 for k in range(N):
-    kind = int(rng.integers(0, 5))
+    kind = int(sys.argv[3]) if len(sys.argv) > 3 else int(rng.integers(0, 5))
     if kind == 0: dims = [int(rng.integers(1, 17))] + [int(rng.integers(2, 65)) for _ in range(int(rng.integers(1, 4)))] + [int(rng.integers(1, 3))]          # narrow
     elif kind == 1: dims = [int(rng.integers(1, 100))] + [int(rng.integers(17, 112)) for _ in range(int(rng.integers(2, 4)))] + [int(rng.integers(1, 3))]     # mid-width
     elif kind == 2: dims = [int(rng.integers(33, 900))] + [int(rng.integers(3, 65)) for _ in range(int(rng.integers(1, 3)))] + [int(rng.integers(1, 3))]      # tall
@@ -22,7 +22,7 @@ for k in range(N):
     act = int(rng.choice([o.ACT_RELU, o.ACT_TANH, o.ACT_SIGMOID, o.ACT_ELU]))
     lik = int(rng.choice([o.LIK_GAUSSIAN, o.LIK_GAUSSIAN, o.LIK_BERNOULLI])) if dims[-1] <= 2 else o.LIK_GAUSSIAN
     prior = int(rng.choice([o.PRIOR_CAUCHY, o.PRIOR_GAUSSIAN]))
-    n = int(rng.choice([rng.integers(1, 64), rng.integers(64, 2500)]))
+    n = int(rng.choice([rng.integers(1, 64), rng.integers(64, int(sys.argv[4]) if len(sys.argv) > 4 else 2500)]))
     spec, X, Y, theta, eta = o.synth_problem(dims, n, act, prior, lik)
     if dims[0] > 64: X = (X / np.sqrt(dims[0] / 16.0)).astype(np.float32)
     if lik == o.LIK_BERNOULLI: theta = (theta * 0.3).astype(np.float32)          # keep the outputs off saturation: a well-conditioned fp32 problem
