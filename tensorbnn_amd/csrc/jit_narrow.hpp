@@ -53,7 +53,7 @@ struct JitNarrow {
         o->nforward = F3 ? &nforward : nullptr;
         o->plan = nullptr; o->wlaunch = nullptr; o->wforward = nullptr;
         o->traj = TRAJ_NW > 0 ? &traj : nullptr;
-        o->traj_max_rows = TRAJ_NW > 0 ? TBNN_TRAJ_MAX_ROWS : 0;
+        o->traj_max_rows = TRAJ_NW == 16 ? TBNN_TRAJ_MAX_ROWS : TRAJ_NW == 4 ? TBNN_TRAJ_MAX_ROWS_4 : 0;
     }
 };
 

@@ -22,8 +22,13 @@
 // Measured at configs[0]'s network, one chain, us per leapfrog step (tools/experiments/traj_time.py): rows 64 / 256 / 512 / 1000 / 2000:
 // 16 waves 2.3 / 3.2 / 4.6 / 7.4 / 12.9, 4 waves 1.6 / 3.3 / 5.6 / 10.0 / 18.8, two-kernel step 14.4 / 9.4 / 9.0 / 8.3 / 10.0;
 // 64 chains at 1000 rows: 8.2 against 11.5.  Above ~1,200 rows the row tiles want more than one workgroup: the two-kernel step.
+// With 4 waves (networks whose accumulators do not fit four waves per SIMD; 6 -> 24 -> 24 -> 1: 3.2 / 6.8 / 11.6 / 21.2 us at 64 / 256 / 512 / 1000
+// rows against 11.3 on the two-kernel step) the crossover is at ~500 rows.
 #ifndef TBNN_TRAJ_MAX_ROWS
-#define TBNN_TRAJ_MAX_ROWS 1200
+#define TBNN_TRAJ_MAX_ROWS 1200          // 16 waves per workgroup
+#endif
+#ifndef TBNN_TRAJ_MAX_ROWS_4
+#define TBNN_TRAJ_MAX_ROWS_4 384         // 4 waves per workgroup
 #endif
 #define TRAJ_MAX_KP 4                    // parameters per thread held in registers: P <= 1024
 
@@ -254,9 +259,11 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(NW /
 #ifndef TBNN_NO_FAST_REGISTRY
 // ahead-of-time instantiations: the registry ids of kernels_fast3.hpp whose shapes are eligible; 16 waves where they fit
 template <class S> struct TrajPick { static constexpr int NW = (TBNN_TRAJ_WAVES == 16 && TrajCfg<S, 16>::OK) ? 16 : 4; };
-static inline bool fast3_traj_available(int id) {
-    return (id == 1 && TrajCfg<ShapeC1, TrajPick<ShapeC1>::NW>::OK) || (id == 2 && TrajCfg<ShapeTR, TrajPick<ShapeTR>::NW>::OK);
+template <class S> static inline long fast3_traj_rows_t() {
+    return !TrajCfg<S, TrajPick<S>::NW>::OK ? 0 : (TrajPick<S>::NW == 16 ? TBNN_TRAJ_MAX_ROWS : TBNN_TRAJ_MAX_ROWS_4);
 }
+// row count up to which registry shape `id` runs its transitions on the trajectory kernel (0: never)
+static inline long fast3_traj_max_rows(int id) { return id == 1 ? fast3_traj_rows_t<ShapeC1>() : id == 2 ? fast3_traj_rows_t<ShapeTR>() : 0; }
 template <class S>
 static inline void fast3_traj_launch_t(int nchains, hipStream_t st, const NetDev& nd, const float* qimg, long img_stride, const float* eta,
                                        const float* X, const float* Y, long n, float* q, float* p, float* g, float* gd, const int* imgmap,

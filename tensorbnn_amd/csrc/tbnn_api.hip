@@ -1081,7 +1081,7 @@ static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, 
     const bool traj = h->traj && !d_trace && L >= 1 && h->kernel == TBNN_KERNEL_FAST && h->wide_id < 0 && h->mid_id < 0 && !h->lay && !h->shard &&
                       h->profile == 0 &&
                       (h->jit ? (h->jit->family == TBNN_FAMILY_NARROW && h->jit->traj != nullptr && h->n <= h->jit->traj_max_rows)
-                              : (h->fast_ver == 3 && h->n <= TBNN_TRAJ_MAX_ROWS && fast3_traj_available(h->fast_id)));
+                              : (h->fast_ver == 3 && h->n <= fast3_traj_max_rows(h->fast_id)));
     if (traj) {
         const int trc = h->jit ? h->jit->traj(h->C, h->stream, &nd, h->qimg, (long)h->img_floats, h->eta, h->dX, h->dY, h->n, h->q, h->p, h->g, h->gd, h->imgmap,
                                               h->pstat, stat_entries(h), eps, L, ctl)

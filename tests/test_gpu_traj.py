@@ -24,7 +24,7 @@ def make(native, spec, monkeypatch, traj, **kw):
 
 
 @pytest.mark.parametrize("shape", list(SHAPES))
-@pytest.mark.parametrize("n", [7, 100, 1000])          # (1,000 <= TBNN_TRAJ_MAX_ROWS = 1,200)
+@pytest.mark.parametrize("n", [7, 100, 380, 1000])     # (16 waves: up to 1,200 rows; 4 waves: up to 384 -- above, both handles take the two-kernel step)
 def test_trajectory_kernel_transition_vs_oracle_and_two_kernel_step(native, monkeypatch, shape, n):
     dims, act = SHAPES[shape]
     spec, X, Y, theta, eta = o.synth_problem(dims, n, act, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN)
