@@ -549,3 +549,30 @@ def test_built_library_has_no_mfma_operand_hazard():
     text = hl.disassemble(nat.LIB_PATH)
     assert text.count("v_mfma_f32_16x16x4") > 1000           # the kernels are in there
     assert hl.hazards(text) == []
+
+
+def test_jit_rebuilds_a_kernel_library_that_shows_the_operand_hazard(tmp_path, monkeypatch):
+    """15 -> 170 -> 114 -> 1 on the wide family: with two waves per SIMD the register allocator parks a-blocks of k_dw_wide in AccVGPRs and brings
+    one back (v_accvgpr_read) straight in front of the inline-asm MFMA that reads it.  jit.build must hand out a library WITHOUT that pair (it
+    rebuilds with the wait states inside the asm statements); compiled as before the check, the same source has it -- which is what makes this
+    test mean something.  No GPU needed: hipcc cross-compiles, llvm-objdump disassembles."""
+    import shutil
+    from tensorbnn_amd import hazard_lint as hl, jit, _native as nat
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) and os.path.exists(os.path.join(hl.LLVM_BIN, "llvm-objdump"))):
+        pytest.skip("needs hipcc and llvm-objdump")
+    monkeypatch.setenv("TBNN_JIT_DIR", str(tmp_path))
+    monkeypatch.setenv("TBNN_JIT_SKIP", "fast3,fast,mid,tall")
+    dims = [15, 170, 114, 1]
+    layers = [(dims[i], dims[i + 1], nat.ACT_RELU if i < len(dims) - 2 else nat.ACT_NONE, nat.PRIOR_CAUCHY) for i in range(len(dims) - 1)]
+    so = jit.build(layers, nat.LIK_GAUSSIAN)
+    assert so and os.path.exists(so)
+    assert hl.check(so) == []
+    # the same translation unit without the switch
+    src = tmp_path / "plain.hip"
+    src.write_text(jit.source(dims, nat.ACT_RELU, nat.ACT_NONE, False, "wide"))
+    plain = tmp_path / "plain.so"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"] + jit.NARROW_FLAGS + ["-o", str(plain), str(src)],
+                   check=True, stderr=subprocess.DEVNULL)
+    found = hl.check(str(plain))
+    assert found and all("k_dw_wide" in f[0] and f[1].startswith("v_accvgpr_read") for f in found), hl.describe(found)
