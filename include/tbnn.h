@@ -190,6 +190,11 @@ int tbnn_set_profiling(tbnn_handle h, int stride);
  * tile done, tile loop done, end, cooperative tail done, staging done, tile slabs done; out16[8..15] = the shader clock at
  * the same points.  Narrow ahead-of-time kernels only; the chain state is not touched. */
 int tbnn_debug_stamps(tbnn_handle h, uint64_t* out16);
+/* measurement (bench.py's roofline): `reps` fused forward+backward passes of the CURRENT state back to back on the chain's stream between ONE
+ * pair of events; *us_per_pass = elapsed / reps.  (An event pair around a single launch, tbnn_set_profiling, carries ~3 us of the pair's own
+ * cost: 45.4 us where rocprofv3 sees 42.6 at configs[1].)  The chain state is not touched.  Reference: the gradient evaluation of one leapfrog
+ * step, network.py:394-408. */
+int tbnn_debug_fused_burst(tbnn_handle h, int32_t reps, float* us_per_pass);
 
 /* ---- predictions and metrics over the staged rows: no host traffic but the result.
  * network.__init__ stages the validation set next to the training set (network.py:47-51). ---- */

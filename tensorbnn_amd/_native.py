@@ -84,6 +84,7 @@ SYMBOLS = [
     ("tbnn_set_epoch", C.c_int, [_H, C.c_uint32]),
     ("tbnn_set_profiling", C.c_int, [_H, C.c_int]),
     ("tbnn_debug_stamps", C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    ("tbnn_debug_fused_burst", C.c_int, [_H, C.c_int32, C.POINTER(C.c_float)]),
     ("tbnn_debug_momentum", C.c_int, [_H, _fp]),
     ("tbnn_set_validation", C.c_int, [_H, _fp, _fp, C.c_int64]),
     ("tbnn_predict", C.c_int, [_H, C.c_int, _fp, _fp]),
@@ -260,6 +261,12 @@ class Chain:
         out = np.empty(self.P, dtype=np.float32)
         _check(lib.tbnn_get_state(self._h, _p(out)))
         return out
+
+    def fused_burst_us(self, reps: int = 100) -> float:
+        """microseconds per fused forward+backward pass at the current state: `reps` passes back to back between one pair of events"""
+        us = C.c_float(0.0)
+        _check(lib.tbnn_debug_fused_burst(self._h, int(reps), C.byref(us)))
+        return float(us.value)
 
     def debug_momentum(self) -> np.ndarray:
         """the momentum the last hmc_step's trajectory ended with (tests: time reversal)"""

@@ -1437,6 +1437,35 @@ extern "C" int tbnn_debug_stamps(tbnn_handle h, uint64_t* out5) {
     return 0;
 }
 
+extern "C" int tbnn_debug_fused_burst(tbnn_handle h, int32_t reps, float* us_per_pass) {
+    if (!us_per_pass || reps < 1) return fail(-1, "fused_burst: reps >= 1 and an output pointer required");
+    NEED(h);
+    if (!h->dX) return fail(-1, "fused_burst: no data");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t PB = (size_t)h->C * h->nd.P * sizeof(float);
+    // the proposal buffers (free between two transitions) take a copy of the current state; its image is built once
+    HIPCHK(hipMemcpyAsync(h->q, h->q_cur, PB, hipMemcpyDeviceToDevice, h->stream));
+    if (h->kernel == TBNN_KERNEL_FAST) {
+        hipLaunchKernelGGL(k_make_image, dim3((h->nd.P + 255) / 256, h->C), dim3(256), 0, h->stream, h->nd.P, (const float*)h->q, h->imgmap, h->qimg, (long)h->nd.P,
+                           (long)h->img_floats);
+        h->q_img_valid = true;
+    }
+    const int saved = h->profile;
+    h->profile = 0;
+    int rc = launch_fwd_bwd(h, h->q, h->eta);              // one untimed pass (first touch)
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int r = 0; r < reps && !rc; ++r) rc = launch_fwd_bwd(h, h->q, h->eta);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->profile = saved;
+    h->q_img_valid = false;
+    if (rc) return rc;
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *us_per_pass = ms * 1000.f / (float)reps;
+    return 0;
+}
+
 #ifdef TBNN_TILE_STAMPS
 extern "C" int tbnn_debug_tile_stamps(tbnn_handle h, uint64_t* out64) {
     NEED(h);

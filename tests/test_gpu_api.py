@@ -321,3 +321,23 @@ def test_create_destroy_returns_device_memory(native):
         cycle()
     lost = base - _free_device_bytes()
     assert lost <= 32 << 20, f"{lost / 2**20:.1f} MiB of device memory did not come back"
+
+
+@pytest.mark.parametrize("dims", [[5, 50, 50, 50, 1], [1, 10, 10, 1]])
+def test_fused_burst_timing_leaves_the_chain_untouched(native, dims):
+    """tbnn_debug_fused_burst (bench.py's throughput figure): a positive time per pass, and the chain goes on exactly as one that was never timed"""
+    spec, X, Y, theta, eta = o.synth_problem(dims, 2048)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    recs = []
+    for timed in (False, True):
+        ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, seed=50, chain_id=1)
+        ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+        r1 = ch.hmc_run(1e-5, 4, 3)
+        if timed:
+            us = ch.fused_burst_us(7)
+            assert 0.5 < us < 5e4, us
+        r2 = ch.hmc_run(1e-5, 4, 3)
+        recs.append(([x["log_accept_ratio"] for x in r1 + r2], ch.get_state()))
+        ch.close()
+    assert recs[0][0] == recs[1][0]
+    np.testing.assert_array_equal(recs[0][1], recs[1][1])
