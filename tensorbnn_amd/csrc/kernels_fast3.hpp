@@ -1754,7 +1754,17 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             // copy costs configs[0] 1 %
             const long ct0 = main_end + blockIdx.x, ct1 = ct0 + gridDim.x;
             if (ncoop > 0 && ct0 < ntiles) CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[0], yc[0], ct0 * 16 + i16 < n);
-            if (ncoop > 1 && ct1 < ntiles) CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[1], yc[1], ct1 * 16 + i16 < n);
+            // Between the two copies: every wave's outstanding memory operations drained and the waves level again.  Found by narrow_fuzz.py
+            // (13 -> 36 -> 16 -> 33 -> 32 -> 2, grid 4, 582 rows: the bias column of dW_2 lost the second tile's share in registers 2, 3 of every lane
+            // group; every build variant alike -- builtin MFMAs only, unpacked relu, asm wait states --, deterministic).  The cause is NOT
+            // isolated: a compiler barrier or 32 wait states in this place change nothing; `s_waitcnt lgkmcnt(0)` alone, `s_waitcnt vmcnt(0)`
+            // alone and `s_barrier` alone each cure it (a pause of a few hundred cycles: the loop form spends ~600 on register moves here);
+            // the build-time hazard check (also with its write-after-write diagnostic) finds nothing in either library.  The barrier costs
+            // ~150 cycles on a path few row counts take (left-over tiles in (G, 2G]).
+            if (ncoop > 1 && ct1 < ntiles) {
+                __syncthreads();
+                CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[1], yc[1], ct1 * 16 + i16 < n);
+            }
         } else {
 #pragma unroll 1
             for (int j = 0; j < ncoop; ++j) {                       // one copy of the body: the second round's rows by select

@@ -16,6 +16,7 @@ import subprocess
 import tempfile
 
 NEED = 2
+WAW = bool(int(os.environ.get("TBNN_LINT_WAW", "0")))     # diagnostic: also report a VALU write of a register an MFMA in flight will write
 LLVM_BIN = os.environ.get("TBNN_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
 
@@ -94,6 +95,11 @@ def hazards(listing: str, need: int = NEED, asm_only: bool = False):
             for regs, txt, age, needed in mwrites:
                 if regs & srcs and age < needed:
                     out.append((kernel, txt, t, age))
+                    break
+        if WAW and wr:
+            for regs, txt, age, needed in mwrites:
+                if regs & wr and age < needed:
+                    out.append((kernel, txt, "WAW " + t, age))
                     break
         mwrites = [[r - wr, x, a + ws, nd] for r, x, a, nd in mwrites if a + ws < nd and (r - wr)]      # (a register written since is that writer's)
         if op.startswith("v_mfma") and args:

@@ -27,6 +27,9 @@ for rep in range(4):
             e64, e32, d = np.abs(g[a:b] - g64[a:b]).max() / sc, np.abs(g[a:b] - g32[a:b]).max() / sc, np.abs(g32[a:b] - g64[a:b]).max() / sc
             if e64 <= 1e-4: continue
             print(f"   layer {li} {nm}: vs fp64 {e64:.2e}, vs fp32 oracle {e32:.2e} (fp32 oracle vs fp64 {d:.2e})")
+            if nm == "b" and e32 > 1e-5:
+                bad = np.nonzero(~(np.abs(g[a:b] - g32[a:b]) <= 1e-5 * sc))[0]
+                print("     off: units", bad.tolist()[:20], "kernel", g[a:b][bad][:6].tolist(), "oracle", g32[a:b][bad][:6].tolist())
             if nm == "W" and e32 > 1e-5:
                 Wg = g[a:b].reshape(l.out_dim, l.in_dim); W0 = g32[a:b].reshape(l.out_dim, l.in_dim)
                 badm = ~(np.abs(Wg - W0) <= 1e-5 * sc); rows, cols = np.nonzero(badm)
