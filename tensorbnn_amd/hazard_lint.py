@@ -16,6 +16,7 @@ import subprocess
 import tempfile
 
 NEED = 2
+LINEAR = bool(int(os.environ.get("TBNN_LINT_LINEAR", "0")))
 WAW = bool(int(os.environ.get("TBNN_LINT_WAW", "0")))     # diagnostic: also report a VALU write of a register an MFMA in flight will write
 LLVM_BIN = os.environ.get("TBNN_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
@@ -69,8 +70,9 @@ def hazards(listing: str, need: int = NEED, asm_only: bool = False):
         op = t.split()[0]
         args = [a.strip() for a in t[len(op):].split(",")]
         if op.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc", "s_swappc")):
-            window, mwrites = [], []          # a disassembly has no labels: what follows a branch may be reached from elsewhere
-            continue
+            if not LINEAR or not op.startswith("s_cbranch"):
+                window, mwrites = [], []      # a disassembly has no labels: what follows a branch may be reached from elsewhere
+                continue                      # (LINEAR, diagnostic: the fall-through path of a conditional branch is followed: false positives possible)
         if op.startswith("v_mfma") and (in_asm or not asm_only):
             src = set()
             for a in args[1:3]:
