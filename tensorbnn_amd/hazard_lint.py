@@ -17,6 +17,7 @@ import tempfile
 
 NEED = 2
 LINEAR = bool(int(os.environ.get("TBNN_LINT_LINEAR", "0")))
+SRCC = bool(int(os.environ.get("TBNN_LINT_SRCC", "0")))
 WAW = bool(int(os.environ.get("TBNN_LINT_WAW", "0")))     # diagnostic: also report a VALU write of a register an MFMA in flight will write
 LLVM_BIN = os.environ.get("TBNN_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 
@@ -75,7 +76,7 @@ def hazards(listing: str, need: int = NEED, asm_only: bool = False):
                 continue                      # (LINEAR, diagnostic: the fall-through path of a conditional branch is followed: false positives possible)
         if op.startswith("v_mfma") and (in_asm or not asm_only):
             src = set()
-            for a in args[1:3]:
+            for a in (args[1:4] if SRCC else args[1:3]):      # (SRCC, diagnostic: the accumulator operand as well)
                 src |= _vregs(a)
             dist = 0
             for txt, wr, ws in reversed(window):
