@@ -314,6 +314,12 @@ __device__ __forceinline__ void mfma_settle(f32x4 (&acc)[N]) {
     if constexpr (N == 7) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]));
     if constexpr (N == 8) asm volatile("s_nop 10" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
 }
+// N consecutive accumulator tiles settled (N up to 8 per statement)
+template <int N>
+__device__ __forceinline__ void coop_settle(f32x4* acc) {
+    if constexpr (N <= 8) mfma_settle(*reinterpret_cast<f32x4 (*)[N]>(acc));
+    else { mfma_settle(*reinterpret_cast<f32x4 (*)[8]>(acc)); coop_settle<N - 8>(acc + 8); }
+}
 // acc * act'(a) for the 4 registers of a tile; SETTLED: the caller has called mfma_settle on acc (or acc is a VALU result)
 template <int ACT, bool SETTLED>
 __device__ __forceinline__ f32x4 actc_bwd_mul4(f32x4 acc, f32x4 a) {

@@ -1122,6 +1122,12 @@ struct Coop3 {
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) dWc[cwoff(l) + nt] = mfma16(a[s], Bop[nt][s], dWc[cwoff(l) + nt]);
+                    // These MFMAs END a wave-uniform block, and at the join behind it the compiler may move their results (registers differ
+                    // between the paths) -- without the wait states an MFMA result needs: its hazard recognizer does not look across the
+                    // join (13 -> 36 -> 16 -> 33 -> 32 -> 2, second cooperative tile: `v_mfma v[52:55]` ... two branches ... `v_mov_b64 v[90:91],
+                    // v[54:55]`: the bias column of dW_2 wrong in registers 2, 3; found by narrow_fuzz.py, seen by hazard_lint.py once it
+                    // followed the control flow).  The results are settled before the block ends.
+                    coop_settle<NT>(&dWc[cwoff(l)]);
                 } else {
                     float* fd = wl + C::fdoff3 + 32 * g;
                     float Fop[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1754,15 +1760,7 @@ __global__ __launch_bounds__(FAST_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             // copy costs configs[0] 1 %
             const long ct0 = main_end + blockIdx.x, ct1 = ct0 + gridDim.x;
             if (ncoop > 0 && ct0 < ntiles) CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[0], yc[0], ct0 * 16 + i16 < n);
-            // Between the two copies: every wave's outstanding memory operations drained and the waves level again.  Found by narrow_fuzz.py
-            // (13 -> 36 -> 16 -> 33 -> 32 -> 2, grid 4, 582 rows: the bias column of dW_2 lost the second tile's share in registers 2, 3 of every lane
-            // group; every build variant alike -- builtin MFMAs only, unpacked relu, asm wait states --, deterministic).  The cause is NOT
-            // isolated: a compiler barrier or 32 wait states in this place change nothing; `s_waitcnt lgkmcnt(0)` alone, `s_waitcnt vmcnt(0)`
-            // alone and `s_barrier` alone each cure it (a pause of a few hundred cycles: the loop form spends ~600 on register moves here);
-            // the build-time hazard check (also with its write-after-write diagnostic) finds nothing in either library.  The barrier costs
-            // ~150 cycles on a path few row counts take (left-over tiles in (G, 2G]).
             if (ncoop > 1 && ct1 < ntiles) {
-                __syncthreads();
                 CO::tile(dWc, FP, stat, lds, wl, xch, wave, lane, i16, g, inv_var, xc[1], yc[1], ct1 * 16 + i16 < n);
             }
         } else {

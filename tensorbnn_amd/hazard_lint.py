@@ -5,8 +5,10 @@ inline asm (accumulators pinned to AccVGPRs, kernels_fast.hpp: mfma16_acc).  Whe
 AccVGPR, it comes back through `v_accvgpr_read` -- a VALU write -- possibly right in front of the asm MFMA: wrong and unrepeatable dW tiles
 (k_dw_wide at 15 -> 170 -> 114 -> 1 with two waves per SIMD, found by tools/experiments/transition_fuzz.py in round 5).
 
-build.py and jit.py disassemble every kernel object they produce and call `hazards()`; a unit with hazards is rebuilt with
--DTBNN_ASM_MFMA_NOP=1 (every asm MFMA carries its own two wait states) and checked again.
+build.py and jit.py disassemble every kernel object they produce and call `check()` (= `hazards_cfg`: the pairs along the control flow of the
+disassembly, branch targets from the encoded offsets -- a pair may straddle a branch or a join); a unit with hazards is rebuilt with
+-DTBNN_ASM_MFMA_NOP=1 (every asm MFMA carries its own two wait states) and checked again; one that still shows a pair (compiler-generated code:
+an MFMA result moved at a join) is refused and the next kernel family takes the shape.
 
 Wait states are counted as the compiler's hazard recognizer counts them: one per instruction between the write and the MFMA, N + 1 for `s_nop N`."""
 import os
@@ -114,6 +116,110 @@ def hazards(listing: str, need: int = NEED, asm_only: bool = False):
     return out
 
 
+def _parse_functions(listing: str):
+    """llvm-objdump -d text -> {function: [(addr, op, args, text)]}"""
+    funcs, cur = {}, None
+    for ln in listing.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(_Z\w+)>:", ln)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        if cur is None or "//" not in ln:
+            continue
+        code, _, cm = ln.partition("//")
+        ma = re.match(r"\s*([0-9A-Fa-f]+):", cm)
+        t = code.strip()
+        if not ma or not t:
+            continue
+        op = t.split()[0]
+        cur.append((int(ma.group(1), 16), op, [a.strip() for a in t[len(op):].split(",")], t))
+    return funcs
+
+
+def hazards_cfg(listing: str, need: int = NEED):
+    """The two checks of `hazards` along the CONTROL FLOW of a disassembly (branch targets from the encoded offsets): a pair may straddle a
+    branch or a join -- the compiler's own hazard recognizer has been seen to miss an MFMA at the end of a wave-uniform `if` block whose result
+    a move at the join reads two instructions later (cooperative tail of k_fwd_bwd_fast3 at 13 -> 36 -> 16 -> 33 -> 32 -> 2, round 5)."""
+    out = []
+    for fn, ins in _parse_functions(listing).items():
+        idx = {a: i for i, (a, _o, _g, _t) in enumerate(ins)}
+
+        def succ(i):
+            a, op, args, _t = ins[i]
+            if op.startswith("s_endpgm"):
+                return []
+            if op.startswith(("s_branch", "s_cbranch")):
+                off = int(args[0])
+                if off >= 32768:
+                    off -= 65536
+                tgt = idx.get(a + 4 + 4 * off)
+                nxt = [tgt] if tgt is not None else []
+                if op.startswith("s_cbranch") and i + 1 < len(ins):
+                    nxt.append(i + 1)
+                return nxt
+            return [i + 1] if i + 1 < len(ins) else []
+
+        def ws_of(op, args):
+            return (int(args[0]) + 1) if op == "s_nop" and args and args[0].isdigit() else 1
+
+        def valu(op):
+            return op.startswith("v_") and not op.startswith(("v_mfma", "v_smfmac"))
+
+        def reads(op, args):
+            r = set()
+            for a in (args if op.startswith(("v_cmp", "v_accvgpr_write")) else args[1:]):
+                r |= _vregs(a.split()[0] if a else a)
+            return r
+
+        def writes(op, args):
+            if op.startswith("v_") and not op.startswith(("v_cmp", "v_accvgpr_write")) and args:
+                return _vregs(args[0])
+            return set()
+
+        for i, (a, op, args, t) in enumerate(ins):
+            # (1) VALU write -> MFMA SrcA / SrcB read
+            if valu(op):
+                wr = writes(op, args)
+                if wr:
+                    stack, seen = [(j, 0) for j in succ(i)], set()
+                    while stack:
+                        j, age = stack.pop()
+                        if age >= need or (j, age) in seen:
+                            continue
+                        seen.add((j, age))
+                        _a, o2, g2, t2 = ins[j]
+                        if o2.startswith("v_mfma"):
+                            src = set()
+                            for x in g2[1:3]:
+                                src |= _vregs(x)
+                            if src & wr:
+                                out.append((fn, t, t2, age))
+                                break
+                        if writes(o2, g2) >= wr and not o2.startswith("v_mfma"):
+                            continue
+                        stack += [(k, age + ws_of(o2, g2)) for k in succ(j)]
+            # (2) MFMA result (ArchVGPRs) -> VALU read before it has landed
+            if op.startswith("v_mfma") and args:
+                dst = _vregs(args[0])
+                if not dst:
+                    continue
+                needed = _mfma_read_need(op)
+                stack, seen, hit = [(j, 0, frozenset(dst)) for j in succ(i)], set(), False
+                while stack and not hit:
+                    j, age, regs = stack.pop()
+                    if age >= needed or not regs or (j, age, regs) in seen:
+                        continue
+                    seen.add((j, age, regs))
+                    _a, o2, g2, t2 = ins[j]
+                    if valu(o2) and reads(o2, g2) & regs:
+                        out.append((fn, t, t2, age))
+                        hit = True
+                        break
+                    regs2 = regs - writes(o2, g2) if not o2.startswith("v_mfma") else regs - _vregs(g2[0]) if g2 else regs
+                    stack += [(k, age + ws_of(o2, g2), frozenset(regs2)) for k in succ(j)]
+    return out
+
+
 def disassemble(path: str) -> str:
     """device code (gfx950) of a fat object / shared library as llvm-objdump text"""
     d = tempfile.mkdtemp(prefix="tbnn_lint_")
@@ -134,8 +240,8 @@ def disassemble(path: str) -> str:
 
 
 def check(path: str, need: int = NEED):
-    """hazards of a compiled object / library (empty list: clean)"""
-    return hazards(disassemble(path), need)
+    """hazards of a compiled object / library (empty list: clean), along its control flow"""
+    return hazards_cfg(disassemble(path), need)
 
 
 def describe(found, limit: int = 3) -> str:

@@ -549,6 +549,30 @@ def test_built_library_has_no_mfma_operand_hazard():
     text = hl.disassemble(nat.LIB_PATH)
     assert text.count("v_mfma_f32_16x16x4") > 1000           # the kernels are in there
     assert hl.hazards(text) == []
+    assert hl.hazards_cfg(text) == []                        # ... and along the control flow (what build.py / jit.py call)
+
+
+def test_hazard_lint_follows_the_control_flow():
+    """the pair the compiler's own hazard recognizer missed (cooperative tail of the narrow kernel, round 5): an MFMA ends a wave-uniform block,
+    two branches later a move at the join reads its result"""
+    from tensorbnn_amd import hazard_lint as hl
+    listing = """
+0000000000001000 <_Z9k_exampleILi2EEvPf>:
+	v_mfma_f32_16x16x4_f32 v[52:55], v55, v51, v[146:149]      // 000000001000: D3C58034
+	s_cbranch_execz 1                                          // 000000001008: BF880001
+	s_branch 3                                                 // 00000000100C: BF820003
+	v_mov_b32_e32 v1, v2                                       // 000000001010: 7E020302
+	v_mov_b32_e32 v3, v2                                       // 000000001014: 7E060302
+	v_mov_b32_e32 v4, v2                                       // 000000001018: 7E080302
+	v_mov_b64_e32 v[90:91], v[54:55]                           // 00000000101C: 7EB47136
+	s_nop 9                                                    // 000000001020: BF800009
+	v_mov_b64_e32 v[88:89], v[52:53]                           // 000000001024: 7EB07134
+	s_endpgm                                                   // 000000001028: BF810000
+"""
+    found = hl.hazards_cfg(listing)
+    # through `s_branch 3` (target 0x101C) the move reads v[54:55] two wait states after the MFMA; the second move sits behind s_nop 9: fine
+    assert [(f[2].split()[0], f[2].split()[1].rstrip(","), f[3]) for f in found] == [("v_mov_b64_e32", "v[90:91]", 2)], found
+    assert hl.hazards(listing) == []                         # the linear scan stops at the branches
 
 
 def test_jit_rebuilds_a_kernel_library_that_shows_the_operand_hazard(tmp_path, monkeypatch):
