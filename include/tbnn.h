@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define TBNN_MAX_LAYERS 16
-#define TBNN_ABI_VERSION 2   /* 2: multi-chain handles (tbnn_create_multi: buffers of set/get_state, hmc_step/run, hyper_step are [chains][...]), tbnn_build_id, tbnn_comm_count, tbnn_hyper_probs_many, tbnn_debug_momentum */
+#define TBNN_ABI_VERSION 3   /* 3: tbnn_lint_status; 2: tbnn_hmc_step_each / _run_each / tbnn_hyper_step_each, tbnn_debug_fused_burst, multi-chain handles (tbnn_create_multi: buffers of set/get_state, hmc_step/run, hyper_step are [chains][...]), tbnn_build_id, tbnn_comm_count, tbnn_hyper_probs_many, tbnn_debug_momentum */
 
 /* activation layer that follows a dense layer
  * (tensorBNN/activationFunctions.py:27-63) */
@@ -91,6 +91,9 @@ int tbnn_abi_version(void);
  * profiles/rocprof_kernel_us.json and pmc_traffic.json carry the id of the library they were measured on, and bench.py
  * quotes them only when it matches */
 const char* tbnn_build_id(void);
+/* what the build-time MFMA hazard check (tensorbnn_amd/hazard_lint.py, through checked_compile.py) did to each kernel unit of the loaded library:
+ * "<unit>: listing checked (<n> repaired: <rule>:<count> ..); disassembly clean; ..." -- a library cannot be built without the check */
+const char* tbnn_lint_status(void);
 /* number of visible HIP devices (<0: error) */
 int tbnn_device_count(void);
 

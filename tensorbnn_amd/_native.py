@@ -22,7 +22,7 @@ PRIOR_CAUCHY, PRIOR_GAUSSIAN = 0, 1
 LIK_GAUSSIAN, LIK_FIXED_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST = 0, 1, 2
 MAX_LAYERS = 16
-ABI_VERSION = 2          # TBNN_ABI_VERSION of include/tbnn.h
+ABI_VERSION = 3          # TBNN_ABI_VERSION of include/tbnn.h
 
 
 class TbnnError(RuntimeError):
@@ -56,6 +56,7 @@ SYMBOLS = [
     ("tbnn_last_error", C.c_char_p, []),
     ("tbnn_abi_version", C.c_int, []),
     ("tbnn_build_id", C.c_char_p, []),
+    ("tbnn_lint_status", C.c_char_p, []),
     ("tbnn_device_count", C.c_int, []),
     ("tbnn_create", C.c_int, [C.POINTER(NetDesc), C.c_int, C.c_uint64, C.c_uint32, C.POINTER(_H)]),
     ("tbnn_create_multi", C.c_int, [C.POINTER(NetDesc), C.c_int, C.c_uint64, C.c_uint32, C.c_int32, C.POINTER(_H)]),
@@ -187,6 +188,11 @@ def _p(a: Optional[np.ndarray]):
 def build_id() -> str:
     """hash of the sources the loaded libtbnn.so was built from (tbnn_build_id)"""
     return lib.tbnn_build_id().decode()
+
+
+def lint_status() -> str:
+    """what the build-time MFMA hazard check did to the kernel units of the loaded library (tbnn_lint_status)"""
+    return lib.tbnn_lint_status().decode()
 
 
 def device_count() -> int:

@@ -1,4 +1,4 @@
-"""Build libtbnn.so in-tree with hipcc for gfx950 (`python -m tensorbnn_amd.build`)."""
+"""Build libtbnn.so in-tree with hipcc for gfx950 (`python -m tensorbnn_amd.build`); every kernel unit through checked_compile (MFMA hazard check)."""
 import os
 import subprocess
 import sys
@@ -28,6 +28,7 @@ def _deps():
     cs = os.path.join(HERE, "csrc")
     d += [os.path.join(cs, f) for f in os.listdir(cs) if f.endswith(".hpp")]
     d.append(os.path.join(HERE, "..", "include", "tbnn.h"))
+    d += [os.path.join(HERE, "hazard_lint.py"), os.path.join(HERE, "checked_compile.py")]      # the check is part of the compile
     return d
 
 
@@ -40,6 +41,8 @@ def sources_id(flags=()) -> str:
         if f.endswith((".hpp", ".hip", ".cpp")):
             hsh.update(f.encode()); hsh.update(open(os.path.join(cs, f), "rb").read())
     hsh.update(open(os.path.join(HERE, "..", "include", "tbnn.h"), "rb").read())
+    for f in ("hazard_lint.py", "checked_compile.py"):
+        hsh.update(open(os.path.join(HERE, f), "rb").read())
     hsh.update(repr((list(flags), sorted(PER_SOURCE_FLAGS.items()))).encode())
     return hsh.hexdigest()[:16]
 
@@ -52,8 +55,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     flags += os.environ.get("TBNN_EXTRA_FLAGS", "").split()      # diagnostic builds (-DWIDE_DBG_...)
     bid = sources_id(flags)
     os.makedirs(OBJ_DIR, exist_ok=True)
-    # one hipcc per translation unit, side by side (the two kernel families take ~1 min each)
-    procs, objs = [], []
+    # one compile per translation unit, side by side (the kernel families take ~1 min each).  Every .hip unit goes through
+    # checked_compile.run: hipcc's own steps replayed with the MFMA hazard check between the device listing and the assembler (wait states
+    # inserted where a pair lacks them), the finished object disassembled and checked again.  No unit is linked unchecked.
+    from concurrent.futures import ThreadPoolExecutor
+    from . import checked_compile
+    jobs, objs = [], []
     for src in SRC:
         obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
         cmd = [hipcc] + flags + PER_SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
@@ -63,22 +70,34 @@ def build(force: bool = False, verbose: bool = True) -> str:
             cmd[1:1] = ["-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics"]   # per-kernel register / scratch remarks on stderr
         if verbose:
             print(" ".join(cmd), flush=True)
-        # stderr to a file per compile: the resource-usage remarks of dozens of kernels overflow a pipe, and a compiler blocked on
-        # a full pipe until its turn to be drained would serialise the side-by-side build
-        errf = open(obj + ".stderr", "w+")
-        procs.append((cmd, subprocess.Popen(cmd, stderr=errf, text=True), errf))
+        jobs.append(cmd)
         objs.append(obj)
-    for cmd, p, errf in procs:
-        p.wait()
-        errf.seek(0); err = errf.read(); errf.close()
+
+    def one(cmd):
+        if cmd[-3].endswith(".hip"):
+            r = checked_compile.run(cmd, keep_listing=cmd[-1][:-2] + ".s" if os.environ.get("TBNN_KEEP_LISTING") == "1" else None)
+            return r.rc, r.stderr, r.status
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        return p.returncode, p.stderr, None
+
+    with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+        results = list(pool.map(one, jobs))
+    statuses = []
+    for cmd, obj, (rc, err, status) in zip(jobs, objs, results):
+        with open(obj + ".stderr", "w") as f:
+            f.write(err)
         remarks = [l for l in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l]
         other = [l for l in err.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l and not l.startswith("In file included from")
-                 and "warnings generated" not in l and "warning generated" not in l]
-        if other and verbose:
+                 and "warnings generated" not in l and "warning generated" not in l and l.strip()]
+        if other and (verbose or rc != 0):
             print("\n".join(other), file=sys.stderr, flush=True)
-        if p.returncode != 0:
-            print("\n".join(other), file=sys.stderr, flush=True)
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+        if rc != 0:
+            raise subprocess.CalledProcessError(rc, cmd)
+        if status is not None:
+            unit = os.path.basename(cmd[-3])
+            statuses.append(f"{unit}: {status}")
+            if verbose:
+                print(f"{unit}: {status}", flush=True)
         # a FUSED kernel (one wave per SIMD, hand-planned register files) that needs scratch has lost its register plan:
         # accumulators demoted to a stack array are read back without the wait states an MFMA result needs
         name = None
@@ -88,25 +107,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
             elif "ScratchSize [bytes/lane]:" in l and name and any(k in name for k in ("k_fwd_bwd_", "k_chain_wide", "k_dw_wide", "k_forward_fast3")):
                 if int(l.split("ScratchSize [bytes/lane]:")[1].split("[")[0]) > 0 and os.environ.get("TBNN_ALLOW_SPILL") != "1":   # (stamped diagnostic builds)
                     raise RuntimeError(f"{os.path.basename(cmd[-3])}: fused kernel {name} spills to scratch")
-    # every kernel object disassembled and checked for VALU-write -> asm-MFMA-read pairs without wait states (hazard_lint.py); a unit that shows
-    # one is rebuilt with the wait states inside the asm statements and must then be clean
-    from . import hazard_lint
-    for (cmd, _p, _e), obj in zip(procs, objs):
-        if not cmd[-3].endswith(".hip"):
-            continue
-        try:
-            found = hazard_lint.check(obj)
-        except (OSError, subprocess.CalledProcessError, RuntimeError) as e:      # no disassembler on this machine: built as it is, said so
-            print(f"{os.path.basename(obj)}: not checked for MFMA operand hazards ({e})", file=sys.stderr, flush=True)
-            continue
-        if found:
-            print(f"{os.path.basename(obj)}: {len(found)} asm MFMAs behind a VALU write of their operand ({hazard_lint.describe(found, 2)}): "
-                  "rebuilding with -DTBNN_ASM_MFMA_NOP=1", file=sys.stderr, flush=True)
-            cmd2 = cmd[:1] + ["-DTBNN_ASM_MFMA_NOP=1"] + cmd[1:]
-            subprocess.run(cmd2, check=True, stderr=subprocess.DEVNULL)
-            found = hazard_lint.check(obj)
-            if found:
-                raise RuntimeError(f"{os.path.basename(obj)}: MFMA operand hazards remain: {hazard_lint.describe(found)}")
+    # what the check did, linked into the library: tbnn_lint_status()
+    lsrc = os.path.join(OBJ_DIR, "lint_status.cpp")
+    with open(lsrc, "w") as f:
+        text = "; ".join(statuses).replace("\\", "/").replace('"', "'")
+        f.write('extern "C" const char* tbnn_lint_status(void) { return "' + text + '"; }\n')
+    lobj = os.path.join(OBJ_DIR, "lint_status.o")
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O1", "-fPIC", "-c", lsrc, "-o", lobj])
+    objs.append(lobj)
     # link next to the target and rename: a rank that waits for the file (bench.py) never maps a half-written library
     tmp = OUT + f".{os.getpid()}.tmp"
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs

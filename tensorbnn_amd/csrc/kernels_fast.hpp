@@ -359,8 +359,18 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 }
 // sum over the 4 lane groups, broadcast to every lane (row i16); C is the inline constant 0 (a bias travelling in C
 // would cost four v_mov to splat it, one v_add afterwards is cheaper)
-__device__ __forceinline__ float gsum_mfma(float p) {
-    return mfma16(1.f, p, f32x4{0.f, 0.f, 0.f, 0.f})[0];
+// Only register 0 of the result is used.  The other three are dead the moment the MFMA is issued as far as the register allocator knows -- and
+// the MFMA writes them eight passes LATER: an inline-asm VALU instruction (relu_step2, pkmul2 ..: invisible to the compiler's hazard recognizer)
+// allocated to one of them would have its result overwritten when the MFMA lands (round 6, hazard_lint rule R2c: `v_pk_mul_f32 v[40:41] .. clamp`
+// one instruction behind `v_mfma_f32_16x16x4_f32 v[38:41]` in the configs[1] kernel; every reader happened to come before the MFMA landed).
+// `then` is the consumer of the sum, compiler-generated VALU code (which waits for the result by itself); the empty asm behind it keeps the
+// three unused registers reserved until then.
+template <class F>
+__device__ __forceinline__ float gsum_mfma(float p, F then) {
+    const f32x4 r = mfma16(1.f, p, f32x4{0.f, 0.f, 0.f, 0.f});
+    float z = then(r[0]);
+    asm("" : "+v"(z) : "v"(r[1]), "v"(r[2]), "v"(r[3]));
+    return z;
 }
 
 

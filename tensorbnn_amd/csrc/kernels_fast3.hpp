@@ -304,8 +304,7 @@ struct Fwd3 {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const float z = gsum_mfma(pacc[f]) + lds[C::boff(l) + C::fslot(l, f)];
-                T.af[l][f] = actc_fwd<S::act(l)>(z);
+                T.af[l][f] = gsum_mfma(pacc[f], [&](float s) { return actc_fwd<S::act(l)>(s + lds[C::boff(l) + C::fslot(l, f)]); });
                 if (g == f) v[0] = T.af[l][f];
             }
             T.a[C::aroff(l) + MT] = v;
@@ -410,10 +409,8 @@ struct Fwd3 {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                float z;
-                if constexpr (TBNN_F3_M4) z = gsum_mfma(pacc[f]) + lds[C::boff(l) + C::fslot(l, f)];
-                else z = gsum(pf[f]) + lds[C::boff(l) + C::fslot(l, f)];
-                T.af[l][f] = actc_fwd<S::act(l)>(z);
+                if constexpr (TBNN_F3_M4) T.af[l][f] = gsum_mfma(pacc[f], [&](float s) { return actc_fwd<S::act(l)>(s + lds[C::boff(l) + C::fslot(l, f)]); });
+                else T.af[l][f] = actc_fwd<S::act(l)>(gsum(pf[f]) + lds[C::boff(l) + C::fslot(l, f)]);
                 if (g == f) v[0] = T.af[l][f];
             }
             T.a[C::aroff(l) + MT] = v;
@@ -709,7 +706,7 @@ struct Bwd3 {
                     dzp[m] = actc_bwd_mul4<S::act(l - 1), (MTP >= 1 && MTP <= 4)>(acc[m], T.a[C::aroff(l - 1) + m]);
 #pragma unroll
                 for (int f = 0; f < NFP; ++f)
-                    dzpf[f] = actc_bwd_mul<S::act(l - 1)>(gsum_mfma(pacc[f]), T.af[l - 1][f]);
+                    dzpf[f] = gsum_mfma(pacc[f], [&](float s) { return actc_bwd_mul<S::act(l - 1)>(s, T.af[l - 1][f]); });
 #else
             // fringe units of layer l-1 first (their shuffles land under the MFMAs)
             float pf[NFP > 0 ? NFP : 1];
@@ -750,7 +747,10 @@ struct Bwd3 {
                     dzp[m] = actc_bwd_mul4<S::act(l - 1), (MTP >= 1 && MTP <= 4)>(acc[m], T.a[C::aroff(l - 1) + m]);
 #pragma unroll
                 for (int f = 0; f < NFP; ++f)
-                    dzpf[f] = actc_bwd_mul<S::act(l - 1)>(TBNN_F3_M4 ? gsum_mfma(pacc[f]) : gsum(pf[f]), T.af[l - 1][f]);
+                    {
+                    if constexpr (TBNN_F3_M4) dzpf[f] = gsum_mfma(pacc[f], [&](float s) { return actc_bwd_mul<S::act(l - 1)>(s, T.af[l - 1][f]); });
+                    else dzpf[f] = actc_bwd_mul<S::act(l - 1)>(gsum(pf[f]), T.af[l - 1][f]);
+                }
 #endif
             } else {
                 // all-fringe layer (the VALU last layer): K = NF fringe deltas, weights W_l[o][slot] read per lane
@@ -1076,7 +1076,7 @@ struct Coop3 {
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
-                const float a = actc_fwd<S::act(l)>(gsum_mfma(pacc[f]) + lds[C::boff(l) + C::fslot(l, f)]);
+                const float a = gsum_mfma(pacc[f], [&](float s) { return actc_fwd<S::act(l)>(s + lds[C::boff(l) + C::fslot(l, f)]); });
                 if (g == f) mine[0] = a;
                 if (g == 0) xb[XAF + 16 * f + i16] = a;
             }
@@ -1178,7 +1178,7 @@ struct Coop3 {
                 const f32x4 pacc = fringe_partials<S, K>(lds + C::toff(l) + (16 * MTP + 4 * (i16 & 3)) * C::LDT(l) + 4 * g, dz);
 #pragma unroll
                 for (int f = 0; f < NFP; ++f) {
-                    dzpf[f] = actc_bwd_mul<S::act(l - 1)>(gsum_mfma(pacc[f]), T.af[l - 1][f]);
+                    dzpf[f] = gsum_mfma(pacc[f], [&](float s) { return actc_bwd_mul<S::act(l - 1)>(s, T.af[l - 1][f]); });
                     if (g == f) odz[0] = dzpf[f];
                     if constexpr (XCHG) { if (g == 0) xb[XAF + 16 * f + i16] = dzpf[f]; }
                 }

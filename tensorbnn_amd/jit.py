@@ -58,6 +58,8 @@ def _sources_stamp() -> str:
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "tbnn.h"), "rb").read())
+    for f in ("hazard_lint.py", "checked_compile.py"):          # the check is part of the compile: new rules, new libraries
+        h.update(open(os.path.join(HERE, f), "rb").read())
     return h.hexdigest()
 
 
@@ -106,7 +108,7 @@ def mid_fits(dims) -> bool:
     perm = r4(tr(1) * _cdiv(dims[0], 16) * 256 + sum(16 * tr(l + 1) for l in range(nl - 1)) + dims[-1] * 16 * tr(nl - 1) + dims[-1])
     img = r4(perm + sum(16 * tr(l + 1) * (16 * tr(l) + 4) for l in range(1, nl - 1)))
     maxt = max(tr(l) for l in range(1, nl))
-    wave = (ta(0) + sum(ta(l) for l in range(1, nl - 1)) + maxt) * 256
+    wave = (ta(0) + sum(ta(l) for l in range(1, nl - 1)) + 2 * maxt) * 256      # (MidCfg::WAVE_FLOATS: two delta regions)
     return (img + 4 * wave) * 4 + 64 <= 160 * 1024
 
 
@@ -174,6 +176,11 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
         return None
     dims, hact, lact, bern = sh
     extra = os.environ.get("TBNN_JIT_FLAGS", "").split()          # diagnostic builds (-DTBNN_WPAD=8 ...); part of the cache key
+    if os.environ.get("TBNN_JIT_LOG"):                            # which shapes a run asked for (tests/jit_shapes.json is made from this: `prebuild`)
+        import json
+        with open(os.environ["TBNN_JIT_LOG"], "a") as f:
+            f.write(json.dumps({"layers": [list(map(int, l)) for l in layers], "likelihood": int(likelihood),
+                                "skip": os.environ.get("TBNN_JIT_SKIP", ""), "flags": os.environ.get("TBNN_JIT_FLAGS", "")}) + "\n")
     key = hashlib.sha1(f"{dims}|{hact}|{lact}|{bern}|{_sources_stamp()}|{extra}|{families(dims)}".encode()).hexdigest()[:20]
     d = cache_dir()
     so, failed = os.path.join(d, f"tbnn_{key}.so"), os.path.join(d, f"tbnn_{key}.fail")
@@ -201,47 +208,35 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                 tmp = so + f".{os.getpid()}.tmp"
                 with open(src, "w") as f:
                     f.write(source(dims, hact, lact, bern, fam))
-                # second attempt only when the first one's disassembly shows an asm MFMA right behind a VALU write of its operand
-                # (hazard_lint.py): the same sources with the wait states inside the asm statements
+                # compiled through checked_compile.run: hipcc's own steps with the MFMA hazard check (hazard_lint.py) between the device
+                # listing and the assembler -- wait states inserted where a pair lacks them, the finished library disassembled and checked
+                # again; a library is never handed out unchecked
+                from . import checked_compile
                 notraj = []                                # set when only the optional trajectory kernel of the shape needs scratch memory
-                attempts = [[], ["-DTBNN_ASM_MFMA_NOP=1"]]
-                ai = 0
-                while ai < len(attempts):
-                    nop = attempts[ai]; ai += 1
+                status = ""
+                while True:
                     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
-                    cmd += NARROW_FLAGS + extra + nop + notraj      # as build.py compiles the kernels (VGPR-form chain MFMAs)
+                    cmd += NARROW_FLAGS + extra + notraj            # as build.py compiles the kernels (VGPR-form chain MFMAs)
                     cmd += ["-Rpass-analysis=kernel-resource-usage", "-o", tmp, src]      # the remarks carry each kernel's ScratchSize
                     if verbose:
                         print(" ".join(cmd), flush=True)
-                    try:
-                        r = subprocess.run(cmd, capture_output=True, text=True)      # a child process: never an exec of this one
-                        rc, err = r.returncode, r.stderr
-                    except OSError as e:
-                        rc, err = -1, str(e)
+                    r = checked_compile.run(cmd)                    # child processes: never an exec of this one
+                    rc, err, status = r.rc, r.stderr, r.status
                     # a fused kernel that needs scratch memory has lost its register plan (accumulators demoted to a stack array
                     # are read back without the wait states an MFMA result needs): refuse it, the next family takes the shape
                     per_fn = re.findall(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", err, re.S)
                     spills = [int(v) for _f, v in per_fn]
                     if rc == 0 and any(v > 0 for v in spills):
                         if not notraj and all(int(v) == 0 or "k_traj_" in f for f, v in per_fn):
-                            notraj = ["-DTBNN_TRAJ_WAVES=0"]; ai = 0          # the per-step kernels are fine: the same library without the trajectory kernel
+                            notraj = ["-DTBNN_TRAJ_WAVES=0"]          # the per-step kernels are fine: the same library without the trajectory kernel
                             continue
                         rc, err = 1, f"{src}:1:1: error: kernel family {fam} spills to scratch for this shape ({max(spills)} bytes per lane)\n"
-                    if rc != 0:
-                        break
-                    try:
-                        from . import hazard_lint
-                        found = hazard_lint.check(tmp)
-                    except Exception as e:          # no disassembler on this machine: the library is used as built
-                        print(f"tensorbnn_amd: kernel library not checked for MFMA operand hazards ({e})", file=sys.stderr, flush=True)
-                        found = []
-                    if not found:
-                        break
-                    if nop:
-                        rc, err = 1, f"{src}:1:1: error: kernel family {fam}: MFMA operand hazards remain ({hazard_lint.describe(found)})\n"
-                    elif verbose:
-                        print(f"tensorbnn_amd: {len(found)} asm MFMAs behind a VALU write of their operand ({hazard_lint.describe(found, 1)}): "
-                              "rebuilding with their own wait states", file=sys.stderr, flush=True)
+                    break
+                if rc == 0 and verbose:
+                    print(f"tensorbnn_amd: {fam} kernels of {dims}: {status}", file=sys.stderr, flush=True)
+                if rc == 0:
+                    with open(so + ".lint", "w") as f:
+                        f.write(f"{fam}: {status}\n")
                 for f_ in (src,):
                     if os.path.exists(f_):
                         os.remove(f_)
@@ -257,7 +252,8 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                 # diagnostic (<file>:<line>:<col>: error:) says something about the shape
                 located = re.search(r"^[^\s:][^:\n]*:\d+:\d+: (fatal )?error:", err, re.M) is not None
                 transient = re.search(r"unable to execute command|No space left|Killed|signal|unable to open output file|Cannot allocate memory", err) is not None
-                if rc < 0 or not located or transient:
+                crashed = "PLEASE submit a bug report" in err          # an internal compiler error on this shape's code: it will crash again
+                if (rc < 0 or not located or transient) and not crashed:
                     deterministic = False
                 log.append(f"[{fam}] rc={rc}\n{err[-2000:]}")
             if deterministic:
@@ -270,6 +266,45 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
             return None
         finally:
             fcntl.flock(lockf, fcntl.LOCK_UN)
+
+
+def _prebuild_one(job):
+    import warnings
+    layers, likelihood, skip, flags = job
+    os.environ["TBNN_JIT_SKIP"], os.environ["TBNN_JIT_FLAGS"] = skip, flags
+    os.environ.pop("TBNN_JIT_LOG", None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return build([tuple(l) for l in layers], likelihood) is not None
+
+
+def prebuild(jobs, processes: int = 6) -> int:
+    """Compile (into the cache: tensorbnn_amd/_jit travels with the tree) the kernel libraries of a list of shapes -- dicts as TBNN_JIT_LOG writes
+    them -- side by side; returns how many have a library afterwards.  __graft_entry__.build() calls it with tests/jit_shapes.json, so that a GPU
+    test run finds its run-time instantiations built and checked instead of compiling them on the GPU box."""
+    import json
+    from multiprocessing import get_context
+    uniq = {json.dumps(j, sort_keys=True): j for j in jobs}
+    todo = [(j["layers"], j["likelihood"], j.get("skip", ""), j.get("flags", "")) for j in uniq.values()]
+    keep = {k: os.environ.get(k) for k in ("TBNN_JIT_SKIP", "TBNN_JIT_FLAGS")}
+    try:
+        with get_context("spawn").Pool(max(1, min(processes, len(todo)))) as pool:
+            done = pool.map(_prebuild_one, todo, chunksize=1)
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return sum(done)
+
+
+def lint_status(path: str) -> str:
+    """what the build-time MFMA hazard check did to a cached kernel library (written next to it by `build`)"""
+    try:
+        return open(path + ".lint").read().strip()
+    except OSError:
+        return "unknown (library built before the check was part of the compile)"
 
 
 def ensure_registered(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> bool:

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(native):
         assert hasattr(lib, s), f"{s} declared in include/tbnn.h but not exported"
     bound = {name for name, _, _ in native.SYMBOLS}
     assert set(syms) == bound, (set(syms) ^ bound)
-    assert native.lib.tbnn_abi_version() == native.ABI_VERSION == 2
+    assert native.lib.tbnn_abi_version() == native.ABI_VERSION == 3
 
 
 def test_no_cpu_fallback(native):

@@ -1,0 +1,139 @@
+"""Seeded fuzz shards of every kernel family in the suite (round 6; VERDICT round 5: four silent wrong-gradient defects were found by the
+fuzzers under tools/experiments/, none by `-m gpu`).  tests/fuzz_shapes.py: 8 random architectures each for the narrow, mid-width, tall, wide and
+layered families + round 5's failing shapes -- log-prob, gradient (per tensor) and forward against the fp64 oracle through the C ABI, EVERY launch
+repeated three times and required bit-identical (an MFMA hazard pair shows as an unrepeatable result before it shows as a wrong one) -- and 8
+random transitions (an injected HMC step with both decisions + a hyper step) against the oracle.  The run-time instantiations are compiled by
+__graft_entry__.build() (jit.prebuild) through the checked compile; a case whose family cannot express the shape fails, it does not skip."""
+import os
+
+import numpy as np
+import pytest
+
+import fuzz_shapes as fz
+import tbnn_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+CASES = fz.cases()
+TRANS = fz.transition_cases()
+
+
+def _id(c):
+    return f"{c['family']}-{'x'.join(map(str, c['dims']))}-n{c['n']}-a{c['act']}l{c['lik']}p{c['prior']}"
+
+
+def _problem(c):
+    spec, X, Y, theta, eta = o.synth_problem(c["dims"], c["n"], c["act"], c["prior"], c["lik"])
+    if c["dims"][0] > 64:
+        X = (X / np.sqrt(c["dims"][0] / 16.0)).astype(np.float32)          # keep a long fan-in's pre-activations O(1)
+    if c["lik"] == o.LIK_BERNOULLI:
+        theta = (theta * 0.3).astype(np.float32)                          # outputs off saturation: a well-conditioned fp32 problem
+    return spec, X, Y, theta, eta
+
+
+def _relu_kink(spec, theta, X):
+    """smallest |pre-activation| of a relu hidden layer relative to the layer's mean |z| (fp64): below ~1e-6 the fp32 sign of that z depends on
+    the summation order, and one (row, unit) whose relu derivative flips moves the gradient by O(1 / rows) -- the problem, not the kernel"""
+    a = X.astype(np.float64)
+    worst = np.inf
+    for l, (ow, ob) in list(zip(spec.layers, spec.offsets()))[:-1]:
+        z = a @ theta[ow:ob].reshape(l.out_dim, l.in_dim).astype(np.float64).T + theta[ob:ob + l.out_dim].astype(np.float64)
+        if l.act == o.ACT_RELU:
+            worst = min(worst, np.abs(z).min() / max(np.abs(z).mean(), 1e-30))
+        a = (np.maximum(z, 0) if l.act == o.ACT_RELU else np.tanh(z) if l.act == o.ACT_TANH else 1 / (1 + np.exp(-z)) if l.act == o.ACT_SIGMOID
+             else np.where(z > 0, z, np.exp(np.minimum(z, 0)) - 1))
+    return worst
+
+
+@pytest.fixture
+def family_env(monkeypatch):
+    def set_(c):
+        monkeypatch.setenv("TBNN_JIT_SKIP", c["skip"])
+        if c["family"] == "layered":
+            monkeypatch.setenv("TBNN_TALL", "0")
+            monkeypatch.setenv("TBNN_MID", "0")
+    return set_
+
+
+@pytest.mark.parametrize("c", CASES, ids=_id)
+def test_value_gradient_forward_vs_fp64_and_repeatable(native, family_env, c):
+    family_env(c)
+    spec, X, Y, theta, eta = _problem(c)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    assert layers == fz.layers_of(c)
+    ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, jit=c["family"] != "layered")
+    try:
+        name = ch.kernel_name
+        want = {"narrow": ("fast3", "fast<"), "mid": ("mid",), "tall": ("tall",), "wide": ("wide",), "layered": ("layered",)}[c["family"]]
+        assert any(w in name for w in want), f"{c['dims']} runs on {name}, not on the {c['family']} family"
+        ch.set_data(X, Y)
+        lp, g, st = ch.logp_grad(theta, eta)
+        for _ in range(2):                                   # three launches, bit for bit
+            lp2, g2, st2 = ch.logp_grad(theta, eta)
+            assert lp2 == lp and np.array_equal(g2, g), f"{name}: a repeated launch differs (max {np.abs(g2 - g).max():.3e})"
+        m = min(c["n"], 500)
+        f = ch.forward(X[:m], theta)
+        assert np.array_equal(ch.forward(X[:m], theta), f)
+    finally:
+        ch.close()
+    lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)[:2]
+    f64 = o.forward(spec, theta, X[:m], np.float64)
+    e_lp = abs(lp - lp64) / max(abs(lp64), 1.0)
+    blocks = [(a, b) for l, (ow, ob) in zip(spec.layers, spec.offsets()) for a, b in ((ow, ob), (ob, ob + l.out_dim))]
+    e_g = max(np.abs(g[a:b] - g64[a:b]).max() / max(np.abs(g64[a:b]).max(), 1e-3) for a, b in blocks)
+    e_f = float(np.abs(f - f64).max())
+    ok = e_lp <= 4e-6 and e_g <= 1e-4 and e_f <= 1e-4
+    why = ""
+    if not ok:
+        # an ill-conditioned fp32 problem (the fp32 ORACLE is itself far from fp64): the kernel must then sit on the fp32 oracle
+        lp32, g32 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float32)[:2]
+        e_lp32 = abs(lp - lp32) / max(abs(lp64), 1.0)
+        e_g32 = max(np.abs(g[a:b] - g32[a:b]).max() / max(np.abs(g64[a:b]).max(), 1e-3) for a, b in blocks)
+        d32 = max(np.abs(g32[a:b] - g64[a:b]).max() / max(np.abs(g64[a:b]).max(), 1e-3) for a, b in blocks)
+        ok = e_g32 <= max(3e-6, 0.02 * d32) and e_lp32 <= 4e-6 and e_f <= 1e-4
+        why = f"fp32 oracle {d32:.1e} from fp64, kernel {e_g32:.1e} from the fp32 oracle"
+    if not ok and c["act"] == o.ACT_RELU:
+        kk = _relu_kink(spec, theta, X)
+        ok = kk < 3e-6 and e_lp <= 4e-6 and e_f <= 1e-4 and e_g <= 20.0 / max(c["n"], 1)
+        why += f"; relu pre-activation within {kk:.1e} of 0"
+    assert ok, f"{name}: logp {e_lp:.2e} (4e-6) gradient {e_g:.2e} (1e-4) forward {e_f:.2e} (1e-4) {why}"
+
+
+@pytest.mark.parametrize("c", TRANS, ids=_id)
+def test_transition_and_hyper_transition_vs_oracle(native, c):
+    spec, X, Y, theta, eta = _problem(c)
+    layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
+    rng = np.random.default_rng(abs(hash(tuple(c["dims"]))) % (1 << 31))
+    p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+    L, eps = c["L"], c["eps"]
+    ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, seed=50, chain_id=2, jit=True)
+    try:
+        name = ch.kernel_name
+        ch.set_data(X, Y)
+        lp64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)[0]
+        for log_u in (-1e30, 1e30):                          # an accept and a reject
+            ch.set_state(theta); ch.set_hypers(eta)
+            out = ch.hmc_step(eps, L, p0=p0, log_u=log_u)
+            ref = o.weight_step(spec, theta, eta, X, Y, eps, L, p0, log_u, np.float64)
+            tol = 2e-2 + 1e-4 * abs(ref.log_accept_ratio) + 4e-7 * abs(lp64)
+            assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= tol, (name, out["log_accept_ratio"], ref.log_accept_ratio, tol)
+            assert bool(out["accepted"]) == ref.accepted, name
+            assert np.abs(ch.get_state() - ref.theta).max() <= 1e-5 * max(1.0, np.abs(ref.theta).max()), name
+            again = None
+            for _ in range(2):
+                ch.set_state(theta); ch.set_hypers(eta)
+                o2 = ch.hmc_step(eps, L, p0=p0, log_u=log_u)
+                assert o2["log_accept_ratio"] == out["log_accept_ratio"] and o2["logp_new"] == out["logp_new"], f"{name}: a repeated transition differs"
+                s2 = ch.get_state()
+                assert again is None or np.array_equal(again, s2)
+                again = s2
+        if spec.n_hypers:
+            ph = rng.standard_normal(spec.n_hypers).astype(np.float32)
+            ch.set_state(theta); ch.set_hypers(eta)
+            ch.logp_grad(theta, eta)                         # the cached statistic the hyper target uses
+            out = ch.hyper_step(1e-4, 9, p0=ph, log_u=-1e30)
+            ref = o.hyper_step(spec, eta, theta, X, Y, 1e-4, 9, ph, -1e30, np.float64)
+            assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-3 * abs(ref.log_accept_ratio), name
+            assert np.allclose(ch.get_hypers(), ref.theta, rtol=1e-4, atol=1e-5), name
+    finally:
+        ch.close()

@@ -510,93 +510,3 @@ def test_cpu_quota_warning(monkeypatch, tmp_path):
         warnings.simplefilter("always")
         nat._warn_cpu_quota_once()
     assert not w
-
-
-# ---- build-time check of the compiled kernels (tensorbnn_amd/hazard_lint.py): no asm MFMA right behind a VALU write of its operand
-def test_hazard_lint_finds_the_pair_and_counts_wait_states():
-    from tensorbnn_amd import hazard_lint as hl
-    listing = """
-0000000000001000 <_Z9k_exampleILi1EEvPf>:
-	v_accvgpr_read_b32 v60, a94                                // 000000001000: D3D8403C 1800015E
-	s_waitcnt vmcnt(1)                                         // 000000001008: BF8C0F71
-	v_mfma_f32_16x16x4_f32 a[76:79], v6, v60, a[76:79]         // 00000000100C: D3C2804C 0D32790
-	v_accvgpr_read_b32 v61, a95                                // 000000001014: D3D8403D 1800015F
-	s_nop 1                                                    // 00000000101C: BF800001
-	v_mfma_f32_16x16x4_f32 a[76:79], v7, v61, a[76:79]         // 000000001020: D3C2804C 0D327B07
-	v_fma_f32 v8, v1, v2, v3                                   // 000000001028
-	v_mov_b32_e32 v9, v10                                      // 000000001030
-	v_mfma_f32_16x16x4_f32 a[0:3], v8, v62, a[0:3]             // 000000001034
-	v_mov_b32_e32 v11, v10                                     // 00000000103C
-	v_mov_b32_e32 v12, v10                                     // 000000001040
-	v_mov_b32_e32 v14, v10                                     // 000000001044
-	v_mfma_f32_16x16x4_f32 a[0:3], v13, v11, a[0:3]            // 000000001048
-"""
-    found = hl.hazards(listing)
-    # pair 1: one wait state (the s_waitcnt) between -> hazard; pair 2: s_nop 1 = two -> fine; pair 3: v_fma then one instruction -> hazard;
-    # pair 4: two instructions between the write and the MFMA -> fine
-    assert [(f[1].split()[0], f[3]) for f in found] == [("v_accvgpr_read_b32", 1), ("v_fma_f32", 1)], found
-    assert all(f[0] == "_Z9k_exampleILi1EEvPf" for f in found)
-    assert len(hl.hazards(listing, need=3)) == 4
-    assert "k_example" in hl.describe(found)
-
-
-def test_built_library_has_no_mfma_operand_hazard():
-    """the product library's device code, disassembled: what build.py checked object by object when it built it"""
-    import os
-    from tensorbnn_amd import hazard_lint as hl, _native as nat
-    if not os.path.exists(os.path.join(hl.LLVM_BIN, "llvm-objdump")):
-        pytest.skip("no llvm-objdump on this machine")
-    text = hl.disassemble(nat.LIB_PATH)
-    assert text.count("v_mfma_f32_16x16x4") > 1000           # the kernels are in there
-    assert hl.hazards(text) == []
-    assert hl.hazards_cfg(text) == []                        # ... and along the control flow (what build.py / jit.py call)
-
-
-def test_hazard_lint_follows_the_control_flow():
-    """the pair the compiler's own hazard recognizer missed (cooperative tail of the narrow kernel, round 5): an MFMA ends a wave-uniform block,
-    two branches later a move at the join reads its result"""
-    from tensorbnn_amd import hazard_lint as hl
-    listing = """
-0000000000001000 <_Z9k_exampleILi2EEvPf>:
-	v_mfma_f32_16x16x4_f32 v[52:55], v55, v51, v[146:149]      // 000000001000: D3C58034
-	s_cbranch_execz 1                                          // 000000001008: BF880001
-	s_branch 3                                                 // 00000000100C: BF820003
-	v_mov_b32_e32 v1, v2                                       // 000000001010: 7E020302
-	v_mov_b32_e32 v3, v2                                       // 000000001014: 7E060302
-	v_mov_b32_e32 v4, v2                                       // 000000001018: 7E080302
-	v_mov_b64_e32 v[90:91], v[54:55]                           // 00000000101C: 7EB47136
-	s_nop 9                                                    // 000000001020: BF800009
-	v_mov_b64_e32 v[88:89], v[52:53]                           // 000000001024: 7EB07134
-	s_endpgm                                                   // 000000001028: BF810000
-"""
-    found = hl.hazards_cfg(listing)
-    # through `s_branch 3` (target 0x101C) the move reads v[54:55] two wait states after the MFMA; the second move sits behind s_nop 9: fine
-    assert [(f[2].split()[0], f[2].split()[1].rstrip(","), f[3]) for f in found] == [("v_mov_b64_e32", "v[90:91]", 2)], found
-    assert hl.hazards(listing) == []                         # the linear scan stops at the branches
-
-
-def test_jit_rebuilds_a_kernel_library_that_shows_the_operand_hazard(tmp_path, monkeypatch):
-    """15 -> 170 -> 114 -> 1 on the wide family: with two waves per SIMD the register allocator parks a-blocks of k_dw_wide in AccVGPRs and brings
-    one back (v_accvgpr_read) straight in front of the inline-asm MFMA that reads it.  jit.build must hand out a library WITHOUT that pair (it
-    rebuilds with the wait states inside the asm statements); compiled as before the check, the same source has it -- which is what makes this
-    test mean something.  No GPU needed: hipcc cross-compiles, llvm-objdump disassembles."""
-    import shutil
-    from tensorbnn_amd import hazard_lint as hl, jit, _native as nat
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not (os.path.exists(hipcc) and os.path.exists(os.path.join(hl.LLVM_BIN, "llvm-objdump"))):
-        pytest.skip("needs hipcc and llvm-objdump")
-    monkeypatch.setenv("TBNN_JIT_DIR", str(tmp_path))
-    monkeypatch.setenv("TBNN_JIT_SKIP", "fast3,fast,mid,tall")
-    dims = [15, 170, 114, 1]
-    layers = [(dims[i], dims[i + 1], nat.ACT_RELU if i < len(dims) - 2 else nat.ACT_NONE, nat.PRIOR_CAUCHY) for i in range(len(dims) - 1)]
-    so = jit.build(layers, nat.LIK_GAUSSIAN)
-    assert so and os.path.exists(so)
-    assert hl.check(so) == []
-    # the same translation unit without the switch
-    src = tmp_path / "plain.hip"
-    src.write_text(jit.source(dims, nat.ACT_RELU, nat.ACT_NONE, False, "wide"))
-    plain = tmp_path / "plain.so"
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"] + jit.NARROW_FLAGS + ["-o", str(plain), str(src)],
-                   check=True, stderr=subprocess.DEVNULL)
-    found = hl.check(str(plain))
-    assert found and all("k_dw_wide" in f[0] and f[1].startswith("v_accvgpr_read") for f in found), hl.describe(found)

@@ -1,5 +1,5 @@
-"""dev (no GPU): compile random shapes of one kernel family with jit.build and report what the build-time hazard check did -- clean at once,
-rebuilt with the asm wait states, or refused (a pair the rebuild does not remove: compiler-generated, e.g. an MFMA result moved at a join):
+"""dev (no GPU): compile random shapes of one kernel family with jit.build and report what the build-time hazard check (hazard_lint through
+checked_compile) did -- clean at once, repaired (how many pairs of which rule got their wait states), or refused (no kernel of the family):
   python tools/experiments/lint_fuzz.py narrow|mid|tall|wide [n_shapes] [seed] [processes]"""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,7 +30,11 @@ def one(job):
                 m = [l for l in t.splitlines() if "error:" in l]
                 why = m[-1][-220:] if m else why
         return dims, "REFUSED", why
-    return dims, ("rebuilt with asm wait states" if "rebuilding with their own wait states" in txt else "clean"), ""
+    st = jit.lint_status(so)
+    import re
+    m = re.search(r"listing checked \((\d+) repaired(?:: ([^)]*))?\)", st)
+    n = int(m.group(1)) if m else -1
+    return dims, ("clean" if n == 0 else "repaired" if n > 0 else "UNKNOWN"), (m.group(2) or "") if m else st
 
 if __name__ == "__main__":
     from tensorbnn_amd import jit
@@ -45,8 +49,11 @@ if __name__ == "__main__":
     from multiprocessing import Pool
     with Pool(NP) as pool:
         res = pool.map(one, jobs, chunksize=1)
-    tally = {}
+    tally, rules = {}, {}
     for dims, what, why in res:
         tally[what] = tally.get(what, 0) + 1
-        if what != "clean": print(dims, what, why)
-    print(FAM, tally)
+        if what != "clean": print(dims, what, why, flush=True)
+        for kv in (why.split() if what == "repaired" else []):
+            k, v = kv.split(":")
+            rules[k] = rules.get(k, 0) + int(v)
+    print(FAM, tally, "pairs repaired by rule:", rules)
