@@ -420,6 +420,7 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx, repeats=1):
                     "frac_hbm_note": "algorithmic bytes / kernel time / 6.29 TB/s (measured copy rate); frac_mfma: algorithmic FLOP / kernel time / 157.3 TF/s",
                     "rocprof_kernel_us": rp_us, "rocprof_source": rp_src,
                     "profile_build_match": prof_c["match"], "build_id": nat.build_id(), "profiled_build": prof_c["profiled_build"],
+                    "hazard_check": nat.lint_status(),
                     "traffic": traffic, "kernel_us": round(k_us, 2), "kernel_us_burst": round(k_burst_us, 2) if k_burst_us else None,
                     "kernel_us_note": "kernel_us: mean of the event pairs around single launches inside the timed region (+~3 us of pair cost); "
                                       "kernel_us_burst: passes back to back between one event pair after it (throughput: launches overlap head and tail)",

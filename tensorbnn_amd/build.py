@@ -110,6 +110,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # what the check did, linked into the library: tbnn_lint_status()
     lsrc = os.path.join(OBJ_DIR, "lint_status.cpp")
     with open(lsrc, "w") as f:
+        allf = " ".join(flags + sum(PER_SOURCE_FLAGS.values(), []))
+        statuses.append("asm MFMA wait states " + ("off" if "-DTBNN_ASM_MFMA_NOP=0" in allf else "on"))
         text = "; ".join(statuses).replace("\\", "/").replace('"', "'")
         f.write('extern "C" const char* tbnn_lint_status(void) { return "' + text + '"; }\n')
     lobj = os.path.join(OBJ_DIR, "lint_status.o")

@@ -205,11 +205,15 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #define TBNN_ACC_AGPR 1
 #endif
 // TBNN_ASM_MFMA_NOP=1: every asm MFMA carries two wait states of its own.  The hardware wants them between a VALU write of a VGPR and an MFMA
-// that reads it as SrcA / SrcB; the compiler keeps them for its own MFMAs and inserts nothing around inline asm.  An operand the register
-// allocator parked in an AccVGPR comes back through v_accvgpr_read (a VALU write), possibly right in front of the asm MFMA: build.py / jit.py
-// disassemble every unit (tensorbnn_amd/hazard_lint.py) and rebuild one that shows such a pair with this switch.
+// that reads it as SrcA / SrcB / SrcC; the compiler keeps them for its own MFMAs and inserts nothing around inline asm.  An operand the register
+// allocator parked in an AccVGPR comes back through v_accvgpr_read (a VALU write), possibly right in front of the asm MFMA (round 5: wrong,
+// unrepeatable dW tiles of k_dw_wide).
+// Round 6: ON by default -- the rule of the container's HIP guide (section 5.7: a pair with one side inside an asm string needs its s_nop INSIDE
+// the string).  Measured against the build without them (bench.py, two alternating runs each): configs[1] -0.1 .. -0.3 %, configs[3] -0.35 %,
+// configs[4] 0.0 %: the two wait states hide under the previous MFMA's passes.  The check in the compile (hazard_lint through checked_compile)
+// stays as the belt for every other pair.
 #ifndef TBNN_ASM_MFMA_NOP
-#define TBNN_ASM_MFMA_NOP 0
+#define TBNN_ASM_MFMA_NOP 1
 #endif
 #if TBNN_ASM_MFMA_NOP
 #define TBNN_MFMA_PRE "s_nop 1\n\t"

@@ -489,10 +489,11 @@ def test_built_library_has_no_mfma_hazard():
 
 def test_checked_compile_repairs_what_the_plain_compile_leaves(tmp_path, monkeypatch):
     """15 -> 170 -> 114 -> 1 on the wide family: with two waves per SIMD the register allocator parks a-blocks of k_dw_wide in AccVGPRs and brings
-    one back (v_accvgpr_read) straight in front of the inline-asm MFMA that reads it (round 5: wrong, unrepeatable dW tiles).  jit.build must hand
-    out a library WITHOUT any finding and say what it did; compiled plainly, the same source has findings -- which is what makes this test mean
-    something.  No GPU needed: hipcc cross-compiles, llvm-objdump disassembles."""
-    from tensorbnn_amd import jit, _native as nat
+    one back (v_accvgpr_read) straight in front of the inline-asm MFMA that reads it (round 5: wrong, unrepeatable dW tiles).  Since round 6 every
+    asm MFMA carries its own two wait states (TBNN_ASM_MFMA_NOP=1, the default): jit.build hands out a library without any finding.  Compiled
+    plainly WITHOUT them the same source shows the pair -- which is what makes this test mean something -- and the checked compile of that
+    variant repairs it in the listing.  No GPU needed: hipcc cross-compiles, llvm-objdump disassembles."""
+    from tensorbnn_amd import jit, checked_compile as cc, _native as nat
     if not _tools():
         pytest.skip("needs hipcc and llvm-objdump")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -504,16 +505,21 @@ def test_checked_compile_repairs_what_the_plain_compile_leaves(tmp_path, monkeyp
     assert so and os.path.exists(so)
     assert hl.check(so) == []
     st = jit.lint_status(so)
-    m = re.search(r"listing checked \((\d+) repaired", st)
-    assert st.startswith("wide:") and m and int(m.group(1)) > 0 and "R1" in st and "disassembly clean" in st, st
-    # the same translation unit, compiled plainly
+    assert st.startswith("wide:") and "listing checked" in st and "disassembly clean" in st, st
+    # the same translation unit without the wait states in the asm statements, compiled plainly
     src = tmp_path / "plain.hip"
     src.write_text(jit.source(dims, nat.ACT_RELU, nat.ACT_NONE, False, "wide"))
     plain = tmp_path / "plain.so"
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"] + jit.NARROW_FLAGS + ["-o", str(plain), str(src)],
-                   check=True, stderr=subprocess.DEVNULL)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-DTBNN_ASM_MFMA_NOP=0"] + jit.NARROW_FLAGS
+    subprocess.run(cmd + ["-o", str(plain), str(src)], check=True, stderr=subprocess.DEVNULL)
     found = hl.check(str(plain))
     assert any("k_dw_wide" in f[0] and f[1].startswith("v_accvgpr_read") and f[4].startswith("R1") for f in found), hl.describe(found)
+    # ... and through the checked compile
+    fixed = tmp_path / "fixed.so"
+    r = cc.run(cmd + ["-o", str(fixed), str(src)])
+    m = re.search(r"listing checked \((\d+) repaired: ([^)]*)\)", r.status)
+    assert r.rc == 0 and m and int(m.group(1)) > 0 and "R1" in m.group(2) and "disassembly clean" in r.status, r.status
+    assert hl.check(str(fixed)) == []
 
 
 def test_checked_compile_needs_no_disassembler(tmp_path, monkeypatch):
