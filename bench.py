@@ -389,6 +389,11 @@ def run_workload(name, steps, warmup, args, rank, world, dev, ctx, repeats=1):
             print(f"bench: fused burst not measured ({e})", file=sys.stderr)
     flops = algorithmic_flops(DIMS, N_ROWS)
     kernel_name = ch.kernel_name
+    try:                                     # which kernels ran the leapfrog steps of the timed transitions (small narrow problems: one launch for all L)
+        if ch.last_transition_path == "trajectory":
+            kernel_name = "traj:" + kernel_name
+    except Exception:
+        pass
     theta_end, eta_end = (ch.get_state(), ch.get_hypers()) if rank == 0 else (None, None)
     P = ch.P
     if comm is not None:

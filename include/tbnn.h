@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define TBNN_MAX_LAYERS 16
-#define TBNN_ABI_VERSION 3   /* 3: tbnn_lint_status; 2: tbnn_hmc_step_each / _run_each / tbnn_hyper_step_each, tbnn_debug_fused_burst, multi-chain handles (tbnn_create_multi: buffers of set/get_state, hmc_step/run, hyper_step are [chains][...]), tbnn_build_id, tbnn_comm_count, tbnn_hyper_probs_many, tbnn_debug_momentum */
+#define TBNN_ABI_VERSION 3   /* 3: tbnn_lint_status, tbnn_last_transition_path; 2: tbnn_hmc_step_each / _run_each / tbnn_hyper_step_each, tbnn_debug_fused_burst, multi-chain handles (tbnn_create_multi: buffers of set/get_state, hmc_step/run, hyper_step are [chains][...]), tbnn_build_id, tbnn_comm_count, tbnn_hyper_probs_many, tbnn_debug_momentum */
 
 /* activation layer that follows a dense layer
  * (tensorBNN/activationFunctions.py:27-63) */
@@ -120,6 +120,10 @@ int tbnn_param_count(tbnn_handle h);  /* P */
 int tbnn_hyper_count(tbnn_handle h);  /* H */
 /* name of the kernel variant in use ("fast3<...>", "mid<...>", "wide<...>", "layered<...>", "generic") */
 const char* tbnn_kernel_name(tbnn_handle h);
+/* which kernels ran the leapfrog steps of the LAST transition: "per-step" (a fused pass + k_update per step) or "trajectory" (small narrow
+ * problems: the L steps in one launch, kernels_traj.hpp); "none" before the first.  The choice does not depend on tbnn_set_profiling; a traced
+ * transition (trace_logp) always takes the per-step kernels, whose sums run in another order: not bit-equal to the untraced one. */
+const char* tbnn_last_transition_path(tbnn_handle h);
 
 /* trainX / trainY staging, network.py:41-45.  X [n,d_in] row-major, Y [n,d_out]. */
 int tbnn_set_data(tbnn_handle h, const float* X, const float* Y, int64_t n);

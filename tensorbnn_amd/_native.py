@@ -65,6 +65,7 @@ SYMBOLS = [
     ("tbnn_param_count", C.c_int, [_H]),
     ("tbnn_hyper_count", C.c_int, [_H]),
     ("tbnn_kernel_name", C.c_char_p, [_H]),
+    ("tbnn_last_transition_path", C.c_char_p, [_H]),
     ("tbnn_set_data", C.c_int, [_H, _fp, _fp, C.c_int64]),
     ("tbnn_set_data_device", C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64]),
     ("tbnn_set_state", C.c_int, [_H, _fp]),
@@ -235,6 +236,11 @@ class Chain:
     @property
     def kernel_name(self) -> str:
         return lib.tbnn_kernel_name(self._h).decode()
+
+    @property
+    def last_transition_path(self) -> str:
+        """"per-step" | "trajectory": the kernels that ran the last transition's leapfrog steps"""
+        return lib.tbnn_last_transition_path(self._h).decode()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -439,6 +445,11 @@ class ChainGroup:
     @property
     def kernel_name(self) -> str:
         return lib.tbnn_kernel_name(self._h).decode()
+
+    @property
+    def last_transition_path(self) -> str:
+        """"per-step" | "trajectory": the kernels that ran the last transition's leapfrog steps"""
+        return lib.tbnn_last_transition_path(self._h).decode()
 
     def close(self):
         if getattr(self, "_h", None):

@@ -199,7 +199,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // FAR says the same accumulator is revisited only after at least TWO other MFMAs; otherwise the builtin is used.  (Round 5: with
 // ONE other 16x16x4 MFMA in between -- two accumulator tiles taken in turn -- the asm form read a stale accumulator: 8.5e-2 relative
 // error in dW of a 7 -> 17 -> 33 -> 2 network on the narrow family's hand-threaded dW block; a 4x4x1 form accumulating into its predecessor's
-// result likewise.  The wide family's k_dw_wide keeps its two-tile turns, back to back at the full issue rate: parity-tested as they are.)  Operands come from LDS loads; the kernels drain the pipe
+// result likewise.  The wide family's k_dw_wide takes its a-blocks in PAIRS when a wave owns two M tiles -- four accumulators in turn, kernels_wide.hpp: QM == 2, DW0_FAR.)  Operands come from LDS loads; the kernels drain the pipe
 // (mfma_drain) before the epilogue reads the accumulators.  TBNN_ACC_AGPR=0: builtin everywhere.
 #ifndef TBNN_ACC_AGPR
 #define TBNN_ACC_AGPR 1

@@ -94,6 +94,8 @@ struct tbnn_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int profile = 0; long launch_no = 0;   // profile: event pair around every profile-th fwd+bwd launch
     std::vector<hipEvent_t> pev; size_t pev_used = 0;   // pooled events: created once, re-used after every drain (no allocator in the timed loop)
+    std::vector<int> pev_div;                           // leapfrog steps the pair's launch covered (1: a fused pass; L: a trajectory launch)
+    const char* last_path = "none";                     // which kernels ran the last transition's leapfrog steps (tbnn_last_transition_path)
     // hyper workspace
     float* hyp_ws = nullptr;
     // per-chain step control (tbnn_hmc_step_each / tbnn_hyper_step_each): [C] on the device, staged through pinned memory
@@ -407,6 +409,7 @@ static int create_impl(const tbnn_net_desc* desc, int device, uint64_t seed, uin
 extern "C" int tbnn_param_count(tbnn_handle h) { NEED(h); return h->nd.P; }
 extern "C" int tbnn_hyper_count(tbnn_handle h) { NEED(h); return h->nd.H; }
 extern "C" const char* tbnn_kernel_name(tbnn_handle h) { return h ? h->kernel_name.c_str() : ""; }
+extern "C" const char* tbnn_last_transition_path(tbnn_handle h) { return h ? h->last_path : ""; }
 extern "C" int tbnn_set_profiling(tbnn_handle h, int stride) {
     NEED(h);
     h->profile = stride > 0 ? stride : 0;
@@ -686,6 +689,7 @@ static int launch_fwd_bwd(tbnn_ctx* h, const float* q, const float* eta, const S
             hipEventCreate(&a); hipEventCreate(&b); h->pev.push_back(a); h->pev.push_back(b);
         }
         a = h->pev[h->pev_used]; b = h->pev[h->pev_used + 1]; h->pev_used += 2;
+        h->pev_div.push_back(1);
         hipEventRecord(a, h->stream);
     }
     // the one-slab-per-workgroup families take all chains of a multi-chain handle in ONE launch (gridDim.y = chain); the others
@@ -777,9 +781,11 @@ static float drain_profile(tbnn_ctx* h) {
     double tot = 0.0; int cnt = 0;
     for (size_t i = 0; i + 1 < h->pev_used; i += 2) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, h->pev[i], h->pev[i + 1]) == hipSuccess) { tot += ms * 1000.0; ++cnt; }
+        const int div = i / 2 < h->pev_div.size() ? h->pev_div[i / 2] : 1;
+        if (hipEventElapsedTime(&ms, h->pev[i], h->pev[i + 1]) == hipSuccess) { tot += ms * 1000.0 / (div > 0 ? div : 1); ++cnt; }
     }
     h->pev_used = 0;                      // the events stay in the pool
+    h->pev_div.clear();
     return cnt ? (float)(tot / cnt) : 0.f;
 }
 
@@ -1077,16 +1083,26 @@ static int enqueue_transition(tbnn_ctx* h, float eps, int L, const float* d_p0, 
     hipLaunchKernelGGL(k_begin, dim3(1, h->C), dim3(1024), 0, h->stream, nd, d_p0, d_logu, h->epoch, h->key0, h->key1, h->p, h->sc, h->seed_hi);
     launch_update(h, UPD_FIRST, eps, h->eta, h->q, h->g, ctl, 0);
     // a small problem on an ahead-of-time narrow kernel: the L leapfrog steps in ONE launch, one workgroup per chain (kernels_traj.hpp).
-    // Not for a traced transition (per-step energies), a sharded gradient, a profiled run of the per-step kernels.
+    // Not for a traced transition (per-step energies) or a sharded gradient.  Profiling (tbnn_set_profiling) does NOT change the path (round 6;
+    // ADVICE round 5): a profiled trajectory launch is bracketed by one event pair and reported per leapfrog step (its time / L).
     const bool traj = h->traj && !d_trace && L >= 1 && h->kernel == TBNN_KERNEL_FAST && h->wide_id < 0 && h->mid_id < 0 && !h->lay && !h->shard &&
-                      h->profile == 0 &&
                       (h->jit ? (h->jit->family == TBNN_FAMILY_NARROW && h->jit->traj != nullptr && h->n <= h->jit->traj_max_rows)
                               : (h->fast_ver == 3 && h->n <= fast3_traj_max_rows(h->fast_id)));
+    h->last_path = traj ? "trajectory" : "per-step";
     if (traj) {
+        hipEvent_t ea = nullptr, eb = nullptr;
+        const bool prof = h->profile > 0 && (h->launch_no++ % h->profile) == 0;
+        if (prof) {
+            if (h->pev_used + 2 > h->pev.size()) { hipEventCreate(&ea); hipEventCreate(&eb); h->pev.push_back(ea); h->pev.push_back(eb); }
+            ea = h->pev[h->pev_used]; eb = h->pev[h->pev_used + 1]; h->pev_used += 2;
+            h->pev_div.push_back(L);
+            hipEventRecord(ea, h->stream);
+        }
         const int trc = h->jit ? h->jit->traj(h->C, h->stream, &nd, h->qimg, (long)h->img_floats, h->eta, h->dX, h->dY, h->n, h->q, h->p, h->g, h->gd, h->imgmap,
                                               h->pstat, stat_entries(h), eps, L, ctl)
                                : fast3_traj_launch(h->fast_id, h->C, h->stream, nd, h->qimg, (long)h->img_floats, h->eta, h->dX, h->dY, h->n, h->q, h->p, h->g,
                                                    h->gd, h->imgmap, h->pstat, stat_entries(h), eps, L, ctl);
+        if (prof) hipEventRecord(eb, h->stream);
         if (trc)
             return fail(-2, "trajectory kernel launch failed");
         h->q_img_valid = false;            // the images the kernel advanced lived in LDS
@@ -1441,6 +1457,7 @@ extern "C" int tbnn_debug_fused_burst(tbnn_handle h, int32_t reps, float* us_per
     if (!us_per_pass || reps < 1) return fail(-1, "fused_burst: reps >= 1 and an output pointer required");
     NEED(h);
     if (!h->dX) return fail(-1, "fused_burst: no data");
+    if (h->shard) return fail(-1, "fused_burst: not on a row-sharded handle (every pass would be a collective; the other ranks are not in this call)");
     HIPCHK(hipSetDevice(h->device));
     const size_t PB = (size_t)h->C * h->nd.P * sizeof(float);
     // the proposal buffers (free between two transitions) take a copy of the current state; its image is built once
@@ -1450,14 +1467,15 @@ extern "C" int tbnn_debug_fused_burst(tbnn_handle h, int32_t reps, float* us_per
                            (long)h->img_floats);
         h->q_img_valid = true;
     }
-    const int saved = h->profile;
-    h->profile = 0;
+    struct ProfileOff {                                    // restored on EVERY exit (HIPCHK returns early)
+        tbnn_ctx* h; int saved;
+        explicit ProfileOff(tbnn_ctx* h_) : h(h_), saved(h_->profile) { h->profile = 0; }
+        ~ProfileOff() { h->profile = saved; h->q_img_valid = false; }
+    } guard(h);
     int rc = launch_fwd_bwd(h, h->q, h->eta);              // one untimed pass (first touch)
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < reps && !rc; ++r) rc = launch_fwd_bwd(h, h->q, h->eta);
     HIPCHK(hipEventRecord(h->ev1, h->stream));
-    h->profile = saved;
-    h->q_img_valid = false;
     if (rc) return rc;
     HIPCHK(hipEventSynchronize(h->ev1));
     float ms = 0.f;

@@ -95,3 +95,26 @@ def test_trajectory_kernel_free_running_chain_and_group(native, monkeypatch):
             assert a["log_accept_ratio"] == b["log_accept_ratio"] and a["accepted"] == b["accepted"]
         np.testing.assert_array_equal(gs[c], s.get_state())
         s.close()
+
+
+def test_profiling_does_not_change_the_path(native, monkeypatch):
+    """bench.py switches profiling on after its warm-up; the timed transitions must run on the kernels the warm-up and every user
+    run on.  With tbnn_set_profiling the trajectory kernel is still taken, the chain is bit for bit the unprofiled one, and the reported time per
+    leapfrog step is the trajectory launch's time / L."""
+    dims, act = SHAPES["configs0"]
+    spec, X, Y, theta, eta = o.synth_problem(dims, 1000, act, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN)
+    runs = {}
+    for prof in (0, 3):
+        ch = make(native, spec, monkeypatch, True, seed=50, chain_id=1)
+        ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
+        assert ch.last_transition_path == "none"
+        ch.set_profiling(prof)
+        recs = ch.hmc_run(3e-4, 20, 12)
+        assert ch.last_transition_path == "trajectory"
+        runs[prof] = ([r["log_accept_ratio"] for r in recs], ch.get_state(), [r["fwdbwd_us"] for r in recs])
+        # a traced transition needs the per-step energies: the per-step kernels
+        ch.hmc_step(3e-4, 5, trace=True)
+        assert ch.last_transition_path == "per-step"
+        ch.close()
+    assert runs[0][0] == runs[3][0] and np.array_equal(runs[0][1], runs[3][1])
+    assert all(u == 0 for u in runs[0][2]) and 0.5 < max(runs[3][2]) < 100.0          # us per leapfrog step of a 1,000-row, 1-10-10-1 trajectory
