@@ -238,6 +238,24 @@ __device__ __forceinline__ void mfma4_acc(f32x4& c, float a, float b) {        /
     c = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 #endif
 }
+// An accumulator tile born in AccVGPRs.  `acc = f32x4{0, 0, 0, 0}` is a v_mov into ArchVGPRs as far as the register allocator is concerned: the
+// loop-carried value of a "+a" accumulator then has TWO register classes (VGPR from the initialisation, AGPR from the asm MFMAs), the copies
+// between them cannot be coalesced, and the allocator keeps the tile in ArchVGPRs across the loop's back edge -- k_dw_wide at configs[3] moved
+// 36 of its 43 tiles AGPR -> VGPR at the top of every row-tile pair and VGPR -> AGPR in front of each block (300 VALU moves per 430 MFMAs, on
+// a machine where the f32 MFMA and the VALU share the issue slot: round 6, found in the disassembly after PMC showed one non-MFMA VALU
+// instruction per MFMA).  Written through asm "=a" outputs the initial value is of the accumulators' own class.
+__device__ __forceinline__ f32x4 acc_zero() {
+#if TBNN_ACC_AGPR
+    float z0, z1, z2, z3;
+    asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z0));
+    asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z1));
+    asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z2));
+    asm volatile("v_accvgpr_write_b32 %0, 0" : "=a"(z3));
+    return f32x4{z0, z1, z2, z3};
+#else
+    return f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+}
 __device__ __forceinline__ void mfma_drain() {
 #if TBNN_ACC_AGPR
     asm volatile("s_nop 15\n\ts_nop 15");

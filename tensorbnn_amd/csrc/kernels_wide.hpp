@@ -854,7 +854,7 @@ __device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, l
     const float* zbase = store + C::dz_off(l, ntiles);
     f32x4 acc[NT > 0 ? NT : 1];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[t] = acc_zero();
     // left-over pairs of this wave: p = wave + 4q -> (m = 4 QM + p / TA, u = p % TA); invalid ones recompute pair 0
     int pm[QPd], pu[QPd];
     bool pv[QPd];
@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, l
     const float* zbase = store + C::dz_off(l, ntiles);
     f32x4 acc[NT > 0 ? NT : 1];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[t] = acc_zero();
     // left-over pairs of this wave: p = wave + 4q -> (m = 4 QM + p / TA, u = p % TA); invalid ones recompute pair 0
     int pm[QP > 0 ? QP : 1], pu[QP > 0 ? QP : 1];
     bool pv[QP > 0 ? QP : 1];
