@@ -387,8 +387,18 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // one instruction behind `v_mfma_f32_16x16x4_f32 v[38:41]` in the configs[1] kernel; every reader happened to come before the MFMA landed).
 // `then` is the consumer of the sum, compiler-generated VALU code (which waits for the result by itself); the empty asm behind it keeps the
 // three unused registers reserved until then.
+__device__ __forceinline__ float gsum(float p);
+// Round 6: the lane-group sum of the fringe units runs on the row-swap instructions (gsum: 4 VALU instructions) by default.  The MFMA form
+// (ones x p, rounds 4-5) costs the matrix pipe 8 passes per sum and makes its consumer wait 10 wait states for register 0 of the result
+// (the configs[1] tile loop carried ~85 wait states of s_nop behind its 11 lane-sum MFMAs); measured on one box, alternating runs of
+// bench.py --workload c2: 20,749 / 20,723 leapfrog steps/s with the MFMA form, 20,967 / 20,959 with the swaps (+1.1 %; the fused pass by
+// hipEvent 45.45 -> 44.98 us).  The two forms add the four lane groups in different orders (fp32 rounding: not bit-equal).
+#ifndef TBNN_GSUM_PERMLANE
+#define TBNN_GSUM_PERMLANE 1
+#endif
 template <class F>
 __device__ __forceinline__ float gsum_mfma(float p, F then) {
+    if constexpr (TBNN_GSUM_PERMLANE) return then(gsum(p));      // A/B: the lane-group sum on the row-swap instructions (4 VALU, no matrix pipe time, no 10-wait-state read)
     const f32x4 r = mfma16(1.f, p, f32x4{0.f, 0.f, 0.f, 0.f});
     float z = then(r[0]);
     asm("" : "+v"(z) : "v"(r[1]), "v"(r[2]), "v"(r[3]));

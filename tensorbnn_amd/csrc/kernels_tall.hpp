@@ -371,8 +371,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 #endif
             }
         };
+#ifndef TALL_DBG_NOC       // timing experiment only (no dW_0 at all: wrong gradients): what the pass costs WITHOUT phase C and without its slab stores --
+                           // the first kernel of a two-pass form whose second pass would contract delta_0^T X over column stripes (round 6, NOTES)
         ldT(0, Bq[0]);
         if (Gr * 4 > 1) ldT(1, Bq[1]);
+#endif
         TALL_STAMP_G(21);
         __syncthreads();
         TALL_STAMP_G(22);
@@ -533,6 +536,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 
         // ---- C: dW_0 += delta_0^T [x, 1] over the group's tiles, this wave's column tiles; one k-step (rows 4 s .. 4 s + 3 of
         // tile tg) at a time, its rows requested two k-steps ahead
+#ifdef TALL_DBG_NOC
+        if constexpr (!FWD) {                                  // delta_0 of this wave's tile leaves for HBM instead (what the second pass would read)
+            if (wave < Gr) {
+                const float* db0 = lds + C::DB0_OFF + wave * (MT0 * 256);
+                float* dst = slabs + ((size_t)(grp * Gr + wave) * MT0) * 256;          // (inside the slab area: its contents mean nothing in this build)
+#pragma unroll
+                for (int t = 0; t < MT0; ++t) *reinterpret_cast<f32x4*>(dst + t * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(db0 + t * 256 + lane * 4);
+            }
+        }
+#else
         if constexpr (!FWD) {
 #pragma unroll
             for (int q = 0; q < 4 * G; ++q) {
@@ -570,6 +583,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                     }
             }
         }
+#endif
     }
     TALL_STAMP(18);
     if constexpr (!FWD) {
@@ -587,6 +601,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
     // wave's own share of the staging area (the exchange buffer, dead by now; written [m][n], read back lane-linearly: lane l holds row
     // l / 4, columns 4 (l % 4) .. +3)
     // and leave as 16-byte write-through stores -- a 4-byte sc1 store is one fabric write per lane
+#ifndef TALL_DBG_NOC
     {
         constexpr int out0 = C::out(0);
         sfor<0, MT0>(SFOR_LAMBDA(t) {
@@ -639,6 +654,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
             }
         });
     }
+#endif
     TALL_STAMP(19);
     const double wtot = wave_sum_lane0(stat);
     if (lane == 0) red[wave] = wtot;
