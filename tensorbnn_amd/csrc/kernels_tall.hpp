@@ -574,10 +574,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                     if (C::FR0 && t == C::MTF) Aop[t] = db0[t * 256 + (4 * s + g) * 16 + 4 * (lane & 3)];
                     else Aop[t] = db0[t * 256 + 64 * s + lane];
                 }
+                // column-tile-major: a fringe tile's 2-pass 4x4x1 then follows an 8-pass 16x16x4, whose passes hide the two wait states the
+                // asm form carries in front (TBNN_ASM_MFMA_NOP); thirteen 4x4x1 in a row paid them in full (8 cycles each behind an 8-cycle
+                // MFMA: round 6)
 #pragma unroll
-                for (int t = 0; t < MT0; ++t)
+                for (int c = 0; c < CH; ++c)
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) {
+                    for (int t = 0; t < MT0; ++t) {
                         if (C::FR0 && t == C::MTF) mfma4_acc<(ACC_A && MT0 * CH > 2)>(dW0[t * CH + c], Aop[t], Bop[c]);
                         else mfma16_acc<(ACC_A && MT0 * CH > 2)>(dW0[t * CH + c], Aop[t], Bop[c]);
                     }

@@ -111,7 +111,14 @@ GROUPS = {
 def test_chain_group_on_device_draws_vs_oracle(native, family):
     """tbnn_create_multi: 4 chains behind one handle, chain c on the key (seed, chain_id + c).  60 epochs of burn-in on the
     device (not compared: they only move the chains to where the energy error matters), then 14 epochs + one group hyper
-    transition + 6 epochs, chains 1 and 3 against fp64 oracle chains started from the burned states"""
+    transition + 6 epochs, chains 1 and 3 against fp64 oracle chains on the same Philox stream.
+
+    The oracle chain is set back on the DEVICE's state every two epochs (hmc_run in runs of two) resp. every epoch (hmc_step).  A relu
+    network of this size is chaotic in fp32: a free-running fp32 ORACLE chain is 1e-3 away from the fp64 one after 50 epochs and 10-20 x the
+    tolerance off in its log accept ratios (tools/experiments/freerun_dlar.py; one pre-activation whose fp32 sign depends on the summation
+    order is enough to start it), so two chains that are compared over 20 epochs without ever meeting agree or not by luck -- round 6: the
+    lane-group sums moved from an MFMA to the row-swap instructions, another summation order, and chain 3 left its oracle at epoch 7.  What
+    the test is about -- every transition on the device's own draws is the oracle's transition from the same state -- does not need that."""
     dims, n, act, prior, lik, eps, kname = GROUPS[family]
     spec, X, Y, theta, eta = o.synth_problem(dims, n, act, prior, lik)
     C, c0, L, BURN, E1, E2, EPS_H, L_H = 4, 5, 5, 60, 14, 6, 2e-4, 10
@@ -122,12 +129,20 @@ def test_chain_group_on_device_draws_vs_oracle(native, family):
     grp.set_data(X, Y); grp.set_state(thetas); grp.set_hypers(eta)
     grp.hmc_run(eps, L, BURN)
     start, eta0 = grp.get_state(), grp.get_hypers()
-    r1 = grp.hmc_run(eps, L, E1)
-    mid_state = grp.get_state()
+    r1, s1 = [[] for _ in range(C)], [start]
+    for _ in range(E1 // 2):                                      # tbnn_hmc_run in runs of two epochs, the state read between them
+        rr = grp.hmc_run(eps, L, 2)
+        for c in range(C):
+            r1[c] += rr[c]
+        s1.append(grp.get_state())
+    mid_state = s1[-1]
     rh = grp.hyper_step(EPS_H, L_H)
     eta1 = grp.get_hypers()
-    r2 = [grp.hmc_step(eps, L) for _ in range(E2)]                # the per-epoch entry point too: [epoch][chain]
-    final = grp.get_state()
+    r2, s2 = [], [mid_state]
+    for _ in range(E2):                                           # the per-epoch entry point too: [epoch][chain]
+        r2.append(grp.hmc_step(eps, L))
+        s2.append(grp.get_state())
+    final = s2[-1]
     grp.close()
     t = Tally()
     with np.errstate(all="ignore"):
@@ -135,12 +150,16 @@ def test_chain_group_on_device_draws_vs_oracle(native, family):
             th, et = start[c].astype(np.float64), eta0[c].astype(np.float64)
             for k in range(E1):
                 ep = BURN + k
+                if k % 2 == 0:
+                    th = s1[k // 2][c].astype(np.float64)          # the device's state at the start of this run of two
                 p0, lu = draws(spec.n_params, c0 + c, ep)
                 ref = o.weight_step(spec, th, et, X, Y, eps, L, p0, lu, np.float64)
                 if t.add(r1[c][k], ref.log_accept_ratio, lu, ref.logp_old):
                     th = ref.theta_proposed.astype(np.float64)
-            err = float(np.abs(mid_state[c] - th).max() / np.abs(th).max())
-            assert err <= 1e-4, (c, err)
+                if k % 2 == 1:                                     # ... and where the two epochs took it
+                    err = float(np.abs(s1[k // 2 + 1][c] - th).max() / np.abs(th).max())
+                    assert err <= 1e-5, (c, k, err)
+            th = mid_state[c].astype(np.float64)
             # the hyper transition draws on the epoch counter of the weight transition before it, purposes 2 / 3
             p0h, luh = draws(spec.n_hypers, c0 + c, BURN + E1 - 1, hyper=True)
             refh = o.hyper_step(spec, et, th, X, Y, EPS_H, L_H, p0h, luh, np.float64)
@@ -152,12 +171,13 @@ def test_chain_group_on_device_draws_vs_oracle(native, family):
             np.testing.assert_allclose(eta1[c], et, rtol=1e-4, atol=1e-5)
             for k in range(E2):
                 ep = BURN + E1 + k
+                th = s2[k][c].astype(np.float64)
                 p0, lu = draws(spec.n_params, c0 + c, ep)
                 ref = o.weight_step(spec, th, et, X, Y, eps, L, p0, lu, np.float64)
                 if t.add(r2[k][c], ref.log_accept_ratio, lu, ref.logp_old):
                     th = ref.theta_proposed.astype(np.float64)
-            err = float(np.abs(final[c] - th).max() / np.abs(th).max())
-            assert err <= 1e-4, (c, err)
+                err = float(np.abs(s2[k + 1][c] - th).max() / np.abs(th).max())
+                assert err <= 1e-5, (c, k, err)
     t.check(f"chain group [{family}] chains 1, 3")
     assert max(abs(x) for x in t.lars) > 0.05             # not a test of lar = 0
     assert np.abs(final[1] - final[3]).max() > 0
