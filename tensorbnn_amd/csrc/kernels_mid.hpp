@@ -102,19 +102,23 @@ struct MidCfg {
     static constexpr int out(int l) { return S::D[l + 1]; }
     static constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
     static constexpr int r4(int a) { return (a + 3) & ~3; }
-    static constexpr int NM = NL - 2;                 // middle layers 1 .. NM
-    static constexpr int LL = NL - 1;                 // last layer (VALU)
+    static constexpr int LL = NL - 1;                 // last layer
     static constexpr int d_in = in(0), d_out = out(LL);
-    static_assert(d_out <= 2, "last layer runs on the VALU (<= 2 outputs)");
+    // <= 2 outputs: the last layer runs on the VALU (16 FMAs per output instead of a padded MFMA tile).  3 .. 16 outputs (round 6;
+    // network.add takes any stack, tensorBNN/network.py:173-191, and BernoulliLikelihood sums over [d_out, n], likelihood.py:226-236): the
+    // last layer is one more MFMA layer -- ONE output tile, its activation the network's last one -- and the likelihood reads the tile
+    static constexpr bool VL = d_out <= 2;
+    static constexpr int NM = VL ? NL - 2 : NL - 1;   // MFMA layers behind layer 0: 1 .. NM
+    static_assert(d_out <= 16, "the last layer is one output tile at most");
     static_assert(d_in <= MID_MAX_FANIN, "layer-0 fan-in: x and its prefetch copy live in registers");
     // a_l = input of layer l (l = 1..LL) in the padded slot order of kernels_fast.hpp (slot_of / unit_of / ones_slot)
     static constexpr int TR(int l) { return cdiv(in(l), 16); }          // register tiles (real units)
     static constexpr int TA(int l) { return cdiv(in(l) + 1, 16); }      // block tiles (with the ones slot)
     static constexpr int ksteps(int K, int kg) { int rem = K - 16 * kg; return rem >= 16 ? 4 : (rem <= 0 ? 0 : (rem + 3) / 4); }
     static constexpr int KG(int K) { return cdiv(K, 16); }
-    static constexpr int maxT() { int m = 0; for (int l = 1; l <= LL; ++l) m = TR(l) > m ? TR(l) : m; return m; }
+    static constexpr int maxT() { int m = 0; for (int l = 1; l <= (VL ? LL : NL); ++l) m = TR(l) > m ? TR(l) : m; return m; }
     static constexpr int MAXT = maxT();
-    static constexpr int maxTA() { int m = cdiv(in(0) + 1, 16); for (int l = 1; l <= NL - 2; ++l) m = TA(l) > m ? TA(l) : m; return m; }
+    static constexpr int maxTA() { int m = cdiv(in(0) + 1, 16); for (int l = 1; l <= NM; ++l) m = TA(l) > m ? TA(l) : m; return m; }
     // layer 0
     static constexpr int KG0 = KG(d_in), NT0 = cdiv(d_in + 1, 16), MT0 = TR(1);
     // ---- dW accumulator tiles: layer 0: MT0 x NT0, middle layer l: TR(l+1) x TA(l)
@@ -129,10 +133,10 @@ struct MidCfg {
     static constexpr int W0_OFF = 0;
     static constexpr int W0_FLOATS = MT0 * KG0 * 256;
     static constexpr int boff(int l) { int o = W0_OFF + W0_FLOATS; for (int m = 0; m < l; ++m) o += 16 * TR(m + 1); return o; }
-    static constexpr int WLP = 16 * TR(LL);
+    static constexpr int WLP = VL ? 16 * TR(LL) : 0;                    // (the VALU last layer's own image; an MFMA last layer is a middle layer's)
     static constexpr int WL_OFF = boff(NM + 1);
     static constexpr int BL_OFF = WL_OFF + d_out * WLP;
-    static constexpr int PERM_FLOATS = r4(BL_OFF + d_out);
+    static constexpr int PERM_FLOATS = r4(BL_OFF + (VL ? d_out : 0));
     static constexpr int LDM(int l) { return 16 * TR(l) + MID_WPAD; }
     static constexpr int wmoff(int l) { int o = PERM_FLOATS; for (int m = 1; m < l; ++m) o += 16 * TR(m + 1) * LDM(m); return o; }
     static constexpr int IMG_FLOATS = r4(wmoff(NM + 1));
@@ -154,10 +158,11 @@ struct MidCfg {
 };
 
 template <class S>
-struct MidLast {               // per-lane partial sums of the VALU last layer's dW / db
+struct MidLast {               // per-lane partial sums of the VALU last layer's dW / db (nothing when the last layer is an MFMA layer)
     using C = MidCfg<S>;
-    f32x4 acc[C::d_out][C::TR(C::LL)];
-    float accb[C::d_out];
+    static constexpr int NO = C::VL ? C::d_out : 1, NT = C::VL ? C::TR(C::LL) : 1;
+    f32x4 acc[NO][NT];
+    float accb[NO];
 };
 
 // FWD: forward pass only (network.predict, network.py:141-171; predictor.py:132-155 with blockIdx.y = network):
@@ -191,7 +196,10 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
     const long W = (long)gridDim.x * MID_WAVES;
 
     // rows of this wave's first tile: requested before the image loads (their latency hides under the prologue)
-    float xn[C::KG0 * 4], yn[d_out];
+    // targets of a row: <= 2 outputs: y[o] in every lane group; else the D layout of the output tile (lane (row, g): slots 4g .. 4g + 3)
+    constexpr int YN = C::VL ? d_out : 4;
+    constexpr int LRO = MidLast<S>::NO, LRT = MidLast<S>::NT;
+    float xn[C::KG0 * 4], yn[YN];
     auto fetch = [&](long tile) {
         const long row = tile * 16 + i16;
         const bool ok = tile < ntiles && row < n;
@@ -201,7 +209,10 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
             xn[k] = (ok && u >= 0) ? X[row * d_in + u] : 0.f;
         }
 #pragma unroll
-        for (int o = 0; o < d_out; ++o) yn[o] = (!FWD && ok) ? Y[row * d_out + o] : 0.f;
+        for (int o = 0; o < YN; ++o) {
+            const int u = C::VL ? o : unit_of(d_out, 4 * g + o, false);
+            yn[o] = (!FWD && ok && u >= 0) ? Y[row * d_out + u] : 0.f;
+        }
     };
     long tile = (long)blockIdx.x * MID_WAVES + wave;
     fetch(tile);
@@ -232,15 +243,15 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
     for (int t = 0; t < (FWD ? 1 : C::DW_TILES); ++t) dW[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     MidLast<S> LR;
 #pragma unroll
-    for (int o = 0; o < d_out; ++o) {
+    for (int o = 0; o < LRO; ++o) {
         LR.accb[o] = 0.f;
 #pragma unroll
-        for (int t = 0; t < C::TR(LL); ++t) LR.acc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < LRT; ++t) LR.acc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // operand registers that are requested ahead of their layer (and, for layer 0, ahead of their tile)
     f32x4 Apre[C::MAXT], Bpre[C::MAXT];                    // first A group and bias tiles of the next MFMA layer
-    f32x4 wL[d_out][C::TR(LL)];                            // last layer's weights, slot order: lane (r, g) holds slots 16t+4g..+3
+    f32x4 wL[LRO][LRT];                                    // VALU last layer's weights, slot order: lane (r, g) holds slots 16t+4g..+3
     // slot `slot` of `nslot`: the loads are dealt out over the MFMA slots of the k-group they are issued under
     auto preload_mid = [&](auto l_, int slot, int nslot) __attribute__((always_inline)) {
         constexpr int l = decltype(l_)::value;
@@ -261,11 +272,13 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
             }
     };
     auto preload_last = [&](int slot, int nslot) __attribute__((always_inline)) {
+        if constexpr (C::VL) {
 #pragma unroll
-        for (int o = 0; o < d_out; ++o)
+            for (int o = 0; o < d_out; ++o)
 #pragma unroll
-            for (int t = 0; t < C::TR(LL); ++t)
-                if ((o * C::TR(LL) + t) % nslot == slot) wL[o][t] = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
+                for (int t = 0; t < C::TR(LL); ++t)
+                    if ((o * C::TR(LL) + t) % nslot == slot) wL[o][t] = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
+        }
     };
     if constexpr (!FWD) preload_l0(0, 1);
 
@@ -275,11 +288,11 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
 #endif
         MSTAMP(0);
         const bool rvalid = tile * 16 + i16 < n;
-        float x[C::KG0 * 4], y[d_out];
+        float x[C::KG0 * 4], y[YN];
 #pragma unroll
         for (int k = 0; k < C::KG0 * 4; ++k) x[k] = xn[k];
 #pragma unroll
-        for (int o = 0; o < d_out; ++o) y[o] = yn[o];
+        for (int o = 0; o < YN; ++o) y[o] = yn[o];
         fetch(tile + W);
         if constexpr (!FWD) {
             // x blocks for dW_0 (slot order, the ones slot behind the last input unit)
@@ -373,14 +386,22 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[t][r] = actc_fwd<S::HACT>(acc[t][r]);
+                for (int r = 0; r < 4; ++r) a[t][r] = actc_fwd<S::act(l)>(acc[t][r]);
         });
         MSTAMP(2);
 
         // ---- last layer on the VALU: f_o = b_o + sum_u W[o][u] a_LL[u] (packed FMAs kept packed: pkfma*, kernels_fast.hpp)
-        constexpr int TP = C::TR(LL);
-        float dzl[d_out];
-        {
+        constexpr int TP = LRT;
+        float dzl[LRO];
+        if constexpr (!C::VL && FWD) {
+            // MFMA last layer: a[0] is the output tile (lane (row i16, g): slots 4g .. 4g + 3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = unit_of(d_out, 4 * g + r, false);
+                if (rvalid && u >= 0) fout[(size_t)u * n + tile * 16 + i16] = a[0][r];      // [d_out][n]
+            }
+        }
+        if constexpr (C::VL) {
 #pragma unroll
             for (int o = 0; o < d_out; ++o) {
                 f32x2 p2 = {0.f, 0.f};
@@ -411,7 +432,14 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
         }
         if constexpr (!FWD) {
         f32x4 dz[C::MAXT];
-        {
+        if constexpr (!C::VL) {
+            // likelihood on the output tile: delta_LL (w.r.t. the pre-activation) in the D layout, every (row, output) element once
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = unit_of(d_out, 4 * g + r, false);
+                dz[0][r] = (rvalid && u >= 0) ? lik_delta<S>(a[0][r], y[r], inv_var, true, stat) : 0.f;
+            }
+        } else {
             // dW_LL partial sums and delta_{LL-1} = (W_LL^T dz_LL) * act'(a_LL)
             const f32x2 dd = {dzl[0], dzl[d_out - 1]};
 #pragma unroll
@@ -631,8 +659,8 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                 }
         });
     });
-    {
-        // last layer: reduce the per-row partials over the 16 lanes of a lane group, then over the 4 waves
+    if constexpr (C::VL) {
+        // VALU last layer: reduce the per-row partials over the 16 lanes of a lane group, then over the 4 waves
         constexpr int TP = C::TR(LL), inL = C::in(LL);
         float* lb = lds;                               // [wave][o][slot], then [wave][o] biases
         static_assert(MID_WAVES * d_out * (16 * TP + 1) <= C::LDS_FLOATS, "last-layer staging does not fit");
@@ -680,12 +708,12 @@ static void mid_image_map(int* map) {
                 const int ck = slot_of(in, k);
                 int m0;
                 if (l == 0) m0 = C::W0_OFF + (((ri / 16) * C::KG0 + ck / 16) * 64 + ((ck % 16) / 4) * 16 + ri % 16) * 4 + ck % 4;
-                else if (l == C::LL) m0 = C::WL_OFF + i * C::WLP + ck;
+                else if (C::VL && l == C::LL) m0 = C::WL_OFF + i * C::WLP + ck;
                 else m0 = C::wmoff(l) + ri * C::LDM(l) + ck;
                 map[ow + i * in + k] = m0;
                 map[P + ow + i * in + k] = -1;
             }
-            map[ow + in * out + i] = l == C::LL ? C::BL_OFF + i : C::boff(l) + ri;
+            map[ow + in * out + i] = (C::VL && l == C::LL) ? C::BL_OFF + i : C::boff(l) + ri;
             map[P + ow + in * out + i] = -1;
         }
     }

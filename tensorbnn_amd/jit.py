@@ -13,7 +13,7 @@ Family choice (first that compiles wins; a shape no family accepts is remembered
 runs on the layered kernels):
   * narrow (`k_fwd_bwd_fast3`, else `k_fwd_bwd_fast`): every dW accumulator in one wave's registers --
     fan-in <= 16, at most NARROW_TILES 16x16 dW tiles in total;
-  * mid (`k_fwd_bwd_mid`): >= 3 dense layers, <= 2 outputs, fan-in <= 128, at most 63 dW tiles over the MFMA
+  * mid (`k_fwd_bwd_mid`): >= 3 dense layers, <= 16 outputs (3 .. 16: the last layer is an MFMA layer too), fan-in <= 128, at most 63 dW tiles over the MFMA
     layers and weight images + operand blocks within 160 KB of LDS (`mid_fits`): one fused kernel, nothing through HBM;
   * tall (`k_fwd_bwd_tall`): a long first-layer fan-in (33 .. a few thousand columns) in front of narrow hidden layers
     (<= 64 units), <= 2 outputs: the fan-in split over the four waves of a workgroup, W_0 and dW_0 in registers
@@ -85,7 +85,7 @@ def families(dims) -> list:
         if dims[-1] <= 2 and nl >= 2:
             out.append("fast3")
         out.append("fast")
-    if nl >= 3 and dims[-1] <= 2 and dims[0] <= MID_MAX_FANIN and mid_fits(dims):
+    if nl >= 3 and dims[-1] <= 16 and dims[0] <= MID_MAX_FANIN and mid_fits(dims):
         out.append("mid")
     if nl >= 2 and dims[-1] <= 2 and dims[0] > 32 and tall_fits(dims):
         out.append("tall")
@@ -97,18 +97,21 @@ def families(dims) -> list:
 
 def mid_fits(dims) -> bool:
     """the mid-width fused kernel (kernels_mid.hpp, MidCfg): every dW tile of the MFMA layers in one wave's AccVGPRs (<= 63
-    tiles) and the weight images + per-wave operand blocks in 160 KB of LDS"""
+    tiles) and the weight images + per-wave operand blocks in 160 KB of LDS.  <= 2 outputs: the last layer runs on the VALU; 3 .. 16
+    outputs: it is one more MFMA layer (one output tile)"""
     nl = len(dims) - 1
+    vl = dims[-1] <= 2
+    nm = nl - 2 if vl else nl - 1               # MFMA layers behind layer 0: 1 .. nm
     tr = lambda l: _cdiv(dims[l], 16)           # tiles of a_l (input of layer l)
     ta = lambda l: _cdiv(dims[l] + 1, 16)
-    tiles = tr(1) * ta(0) + sum(tr(l + 1) * ta(l) for l in range(1, nl - 1))
+    tiles = tr(1) * ta(0) + sum(tr(l + 1) * ta(l) for l in range(1, nm + 1))
     if tiles > 63:
         return False
     r4 = lambda a: (a + 3) & ~3
-    perm = r4(tr(1) * _cdiv(dims[0], 16) * 256 + sum(16 * tr(l + 1) for l in range(nl - 1)) + dims[-1] * 16 * tr(nl - 1) + dims[-1])
-    img = r4(perm + sum(16 * tr(l + 1) * (16 * tr(l) + 4) for l in range(1, nl - 1)))
-    maxt = max(tr(l) for l in range(1, nl))
-    wave = (ta(0) + sum(ta(l) for l in range(1, nl - 1)) + 2 * maxt) * 256      # (MidCfg::WAVE_FLOATS: two delta regions)
+    perm = r4(tr(1) * _cdiv(dims[0], 16) * 256 + sum(16 * tr(l + 1) for l in range(nm + 1)) + (dims[-1] * 16 * tr(nl - 1) + dims[-1] if vl else 0))
+    img = r4(perm + sum(16 * tr(l + 1) * (16 * tr(l) + 4) for l in range(1, nm + 1)))
+    maxt = max(tr(l) for l in range(1, nl if vl else nl + 1))
+    wave = (ta(0) + sum(ta(l) for l in range(1, nm + 1)) + 2 * maxt) * 256      # (MidCfg::WAVE_FLOATS: two delta regions)
     return (img + 4 * wave) * 4 + 64 <= 160 * 1024
 
 

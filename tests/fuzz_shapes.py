@@ -39,7 +39,7 @@ def _dims(rng, fam):
     if fam == "narrow":
         return [int(rng.integers(1, 17))] + [_edge(rng, 2, 64) for _ in range(int(rng.integers(1, 5)))] + [int(rng.integers(1, 3))]
     if fam == "mid":
-        return [_edge(rng, 1, 128)] + [_edge(rng, 17, 112) for _ in range(int(rng.integers(2, 4)))] + [int(rng.integers(1, 3))]
+        return [_edge(rng, 1, 128)] + [_edge(rng, 17, 112) for _ in range(int(rng.integers(2, 4)))] + [int(rng.choice([1, 2, 2, 3, 5, 10, 16]))]      # (3 .. 16 outputs: the MFMA last layer, round 6)
     if fam == "tall":
         return [int(rng.integers(33, 1000))] + [_edge(rng, 3, 64) for _ in range(int(rng.integers(1, 4)))] + [int(rng.integers(1, 3))]
     if fam == "wide":

@@ -1,0 +1,100 @@
+"""GPU: networks with MORE THAN TWO outputs on a fused kernel (round 6).  network.add takes any stack of layers (tensorBNN/network.py:173-191),
+GaussianLikelihood / BernoulliLikelihood sum over [d_out, n] (likelihood.py:88-94, 226-236); until round 6 the mid-width family ran its last layer
+on the VALU (<= 2 outputs) and every wider output went to the layered family.  3 .. 16 outputs: the last layer is one more MFMA layer of
+k_fwd_bwd_mid (one output tile, the likelihood reads the tile).  Against the fp64 oracle through the C ABI: value, gradient per tensor, forward,
+an injected transition with both decisions, a hyper transition, 20 free-running epochs on the device's draws (the oracle set back on the device's
+state every epoch: test_gpu_freerun), ragged row counts, every launch repeated bit for bit."""
+import numpy as np
+import pytest
+
+import tbnn_oracle as o
+from test_gpu_freerun import Tally, draws, layers_of, SEED
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # dims, rows, hidden activation, prior, likelihood
+    "gauss5": ([20, 64, 64, 5], 4000, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
+    "bern10": ([30, 80, 80, 10], 3001, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI),         # ragged last tile
+    "tanh3_two_middle": ([7, 33, 18, 50, 3], 777, o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN),
+    "bern16_full_tile": ([12, 40, 48, 16], 1234, o.ACT_ELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI),
+    "few_rows": ([20, 64, 64, 5], 9, o.ACT_SIGMOID, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN),
+}
+
+
+def problem(name):
+    dims, n, act, prior, lik = CASES[name]
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, act, prior, lik)
+    if lik == o.LIK_BERNOULLI:
+        theta = (theta * 0.3).astype(np.float32)          # outputs off saturation: a well-conditioned fp32 problem
+    return spec, X, Y, theta, eta
+
+
+def chain(native, monkeypatch, spec, **kw):
+    monkeypatch.setenv("TBNN_JIT_SKIP", "fast3,fast,tall,wide")
+    ch = native.Chain(layers_of(spec), likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, jit=True, **kw)
+    assert ch.kernel_name.startswith("jit-mid<"), ch.kernel_name
+    return ch
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_value_gradient_forward(native, monkeypatch, name):
+    spec, X, Y, theta, eta = problem(name)
+    assert spec.layers[-1].out_dim > 2
+    ch = chain(native, monkeypatch, spec)
+    ch.set_data(X, Y)
+    lp, g, st = ch.logp_grad(theta, eta)
+    for _ in range(2):
+        lp2, g2, _s = ch.logp_grad(theta, eta)
+        assert lp2 == lp and np.array_equal(g, g2)
+    f = ch.forward(X[:500], theta)
+    assert np.array_equal(f, ch.forward(X[:500], theta))
+    ch.close()
+    lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)[:2]
+    assert abs(lp - lp64) <= 4e-6 * max(abs(lp64), 1.0), (lp, lp64)
+    for l, (ow, ob) in zip(spec.layers, spec.offsets()):
+        for a, b in ((ow, ob), (ob, ob + l.out_dim)):
+            assert np.abs(g[a:b] - g64[a:b]).max() <= 1e-4 * max(np.abs(g64[a:b]).max(), 1e-3), (name, a, b)
+    f64 = o.forward(spec, theta, X[:500], np.float64)
+    assert f.shape == f64.shape == (spec.layers[-1].out_dim, min(500, X.shape[0]))
+    assert np.abs(f - f64).max() <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["gauss5", "bern10", "tanh3_two_middle"])
+def test_transitions(native, monkeypatch, name):
+    spec, X, Y, theta, eta = problem(name)
+    rng = np.random.default_rng(4)
+    p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+    ch = chain(native, monkeypatch, spec, seed=SEED, chain_id=2)
+    ch.set_data(X, Y)
+    lp64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)[0]
+    for log_u in (-1e30, 1e30):
+        ch.set_state(theta); ch.set_hypers(eta)
+        out = ch.hmc_step(3e-5, 4, p0=p0, log_u=log_u)
+        ref = o.weight_step(spec, theta, eta, X, Y, 3e-5, 4, p0, log_u, np.float64)
+        assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-4 * abs(ref.log_accept_ratio) + 4e-7 * abs(lp64)
+        assert bool(out["accepted"]) == ref.accepted
+        assert np.abs(ch.get_state() - ref.theta).max() <= 1e-5 * max(1.0, np.abs(ref.theta).max())
+    ph = rng.standard_normal(spec.n_hypers).astype(np.float32)
+    ch.set_state(theta); ch.set_hypers(eta)
+    ch.logp_grad(theta, eta)
+    out = ch.hyper_step(1e-4, 9, p0=ph, log_u=-1e30)
+    ref = o.hyper_step(spec, eta, theta, X, Y, 1e-4, 9, ph, -1e30, np.float64)
+    assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-3 * abs(ref.log_accept_ratio)
+    assert np.allclose(ch.get_hypers(), ref.theta, rtol=1e-4, atol=1e-5)
+    # 20 epochs on the device's own draws, the oracle set back on the device's state every epoch
+    ch.set_state(theta); ch.set_hypers(eta); ch.set_epoch(0)
+    t, th = Tally(), theta.astype(np.float64)
+    eps = 2e-4 if name != "bern10" else 1e-3
+    with np.errstate(all="ignore"):
+        for ep in range(20):
+            rec = ch.hmc_run(eps, 5, 1)[0]
+            p0e, lu = draws(spec.n_params, 2, ep)
+            ref = o.weight_step(spec, th, eta, X, Y, eps, 5, p0e, lu, np.float64)
+            took = t.add(rec, ref.log_accept_ratio, lu, ref.logp_old)
+            want = ref.theta_proposed.astype(np.float64) if took else th
+            got = ch.get_state().astype(np.float64)
+            assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), ep
+            th = got
+    ch.close()
+    t.check(f"multi-output [{name}]")
