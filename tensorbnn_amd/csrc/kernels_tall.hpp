@@ -77,15 +77,18 @@ struct TallCfg {
     static constexpr int out(int l) { return S::D[l + 1]; }
     static constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
     static constexpr int r4(int a) { return (a + 3) & ~3; }
-    static constexpr int NM = NL - 2;                 // middle layers 1 .. NM (MFMA, weights in LDS)
-    static constexpr int LL = NL - 1;                 // last layer (VALU)
+    static constexpr int LL = NL - 1;                 // last layer
     static constexpr int d_in = in(0), d_out = out(LL);
-    static_assert(d_out <= 2, "last layer runs on the VALU (<= 2 outputs)");
+    // <= 2 outputs: the last layer on the VALU; 3 .. 16 (round 6, as kernels_mid.hpp): one more MFMA layer with ONE output tile, the
+    // likelihood reads the tile -- a ten-class 784 -> 20 -> 20 -> 10 is the reference's MNIST tutorial with all its digits
+    static constexpr bool VL = d_out <= 2;
+    static constexpr int NM = VL ? NL - 2 : NL - 1;   // MFMA layers behind layer 0: 1 .. NM (weights in LDS)
+    static_assert(d_out <= 16, "the last layer is one output tile at most");
     static constexpr int TR(int l) { return cdiv(in(l), 16); }          // register tiles of a_l (l >= 1: slot order of kernels_fast.hpp)
     static constexpr int TA(int l) { return cdiv(in(l) + 1, 16); }      // block tiles of a_l (with the ones slot)
     static constexpr int ksteps(int K, int kg) { int rem = K - 16 * kg; return rem >= 16 ? 4 : (rem <= 0 ? 0 : (rem + 3) / 4); }
     static constexpr int KG(int K) { return cdiv(K, 16); }
-    static constexpr int maxT() { int m = 0; for (int l = 1; l <= LL; ++l) m = TR(l) > m ? TR(l) : m; return m; }
+    static constexpr int maxT() { int m = 0; for (int l = 1; l <= (VL ? LL : NL); ++l) m = TR(l) > m ? TR(l) : m; return m; }
     static constexpr int MAXT = maxT();
     // layer 0: the rows' columns in their own order (slot = column, the ones slot at column d_in), split over the waves
     static constexpr int MT0 = TR(1);
@@ -111,10 +114,10 @@ struct TallCfg {
     //   row-major [16 TR(l+1) out slots][LDM(l)] (pitch == 4 mod 8: the strided W^T reads of the delta chain are conflict-free)
     static constexpr int W0_FLOATS = MT0 * NTP * 256;
     static constexpr int boff(int l) { int o = 0; for (int m = 0; m < l; ++m) o += 16 * TR(m + 1); return o; }   // in the LDS part
-    static constexpr int WLP = 16 * TR(LL);
+    static constexpr int WLP = VL ? 16 * TR(LL) : 0;
     static constexpr int WL_OFF = boff(NM + 1);
     static constexpr int BL_OFF = WL_OFF + d_out * WLP;
-    static constexpr int PERM_FLOATS = r4(BL_OFF + d_out);
+    static constexpr int PERM_FLOATS = r4(BL_OFF + (VL ? d_out : 0));
     static constexpr int LDM(int l) { return 16 * TR(l) + MID_WPAD; }
     static constexpr int wmoff(int l) { int o = PERM_FLOATS; for (int m = 1; m < l; ++m) o += 16 * TR(m + 1) * LDM(m); return o; }
     static constexpr int SMALL_FLOATS = r4(wmoff(NM + 1));              // the LDS-resident part
@@ -152,22 +155,23 @@ struct TallCfg {
     static_assert(LDS_MAIN == lds_main(GMAX), "LDS layout");
     // epilogue staging of the middle layers' dW tiles ([wave][tile][lane] x 16 B) and of the last layer's sums
     static constexpr int EP_FLOATS = NW * (DWM_TILES > 0 ? DWM_TILES : 1) * 256;
-    static constexpr int LL_FLOATS = NW * d_out * (16 * TR(LL) + 1);
+    static constexpr int LL_FLOATS = VL ? NW * d_out * (16 * TR(LL) + 1) : 0;
     static constexpr int LDS_FLOATS = LDS_MAIN > EP_FLOATS ? (LDS_MAIN > LL_FLOATS ? LDS_MAIN : LL_FLOATS) : (EP_FLOATS > LL_FLOATS ? EP_FLOATS : LL_FLOATS);
     // ---- parameters
     static constexpr int offW(int l) { int p = 0; for (int m = 0; m < l; ++m) p += in(m) * out(m) + out(m); return p; }
     static constexpr int P() { return offW(NL); }
     static constexpr bool LDS_OK = LDS_FLOATS * 4 + 64 <= 160 * 1024;
     // a wave's registers, roughly: its chunks of W_0 and dW_0, the rows' chunk, the narrow layers' accumulators + working set
-    static constexpr int REG_EST = 2 * 4 * MT0 * CH + 4 * CH + 4 * DWM_TILES + 4 * d_out * TR(LL) + 12 * MAXT + 48;
+    static constexpr int REG_EST = 2 * 4 * MT0 * CH + 4 * CH + 4 * DWM_TILES + (VL ? 4 * d_out * TR(LL) : 0) + 12 * MAXT + 48;
 };
 template <class S> struct TallPick { static constexpr int NW = 4; };
 
 template <class S, int NW>
 struct TallLast {              // per-lane partial sums of the VALU last layer's dW / db
     using C = TallCfg<S, NW>;
-    f32x4 acc[C::d_out][C::TR(C::LL)];
-    float accb[C::d_out];
+    static constexpr int NO = C::VL ? C::d_out : 1, NT = C::VL ? C::TR(C::LL) : 1;      // (nothing when the last layer is an MFMA layer)
+    f32x4 acc[NO][NT];
+    float accb[NO];
 };
 
 // FWD: forward pass only (network.predict, network.py:141-171; predictor.py:132-155 with blockIdx.y = network)
@@ -289,18 +293,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int t = 0; t < ((FWD || C::DWM_TILES == 0) ? 1 : C::DWM_TILES); ++t) dWm[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     TallLast<S, NW> LR;
+    constexpr int LRO = TallLast<S, NW>::NO, LRT = TallLast<S, NW>::NT, YN = C::VL ? d_out : 4;
 #pragma unroll
-    for (int o = 0; o < d_out; ++o) {
+    for (int o = 0; o < LRO; ++o) {
         LR.accb[o] = 0.f;
 #pragma unroll
-        for (int t = 0; t < C::TR(LL); ++t) LR.acc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < LRT; ++t) LR.acc[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // last layer's weights, slot order: lane (r, g) holds slots 16t+4g .. +3
-    f32x4 wL[d_out][C::TR(LL)];
+    // VALU last layer's weights, slot order: lane (r, g) holds slots 16t+4g .. +3
+    f32x4 wL[LRO][LRT];
+    if constexpr (C::VL) {
 #pragma unroll
-    for (int o = 0; o < d_out; ++o)
+        for (int o = 0; o < d_out; ++o)
 #pragma unroll
-        for (int t = 0; t < C::TR(LL); ++t) wL[o][t] = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
+            for (int t = 0; t < C::TR(LL); ++t) wL[o][t] = *reinterpret_cast<const f32x4*>(lds + C::WL_OFF + o * C::WLP + 16 * t + 4 * g);
+    }
 
     const bool tail_wave = 16 * (kt0 + CH) > d_in;             // (wave-uniform) this wave holds the end of the rows
     for (; grp < ngroups; grp += gridDim.x) {
@@ -388,9 +395,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
         if (slot < Gr) {
         const long tile = grp * Gr + slot;
         const bool rvalid = tile * 16 + i16 < n;
-        float y[d_out];
+        float y[YN];          // <= 2 outputs: y[o] in every lane group; else the D layout of the output tile (lane (row, g): slots 4g .. 4g + 3)
 #pragma unroll
-        for (int o = 0; o < d_out; ++o) y[o] = (!FWD && rvalid) ? Y[(tile * 16 + i16) * d_out + o] : 0.f;
+        for (int o = 0; o < YN; ++o) {
+            const int u = C::VL ? o : unit_of(d_out, 4 * g + o, false);
+            y[o] = (!FWD && rvalid && u >= 0) ? Y[(tile * 16 + i16) * d_out + u] : 0.f;
+        }
         f32x4 a[C::MAXT];                  // the current layer's input a_l, D layout: tile t reg j of lane (r, g) = slot 16t+4g+j of row r
         {
             const f32x4* ex = reinterpret_cast<const f32x4*>(lds + C::EX_OFF) + slot * (TALL_WAVES * MT0 * 64);
@@ -439,12 +449,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[t][r] = actc_fwd<S::HACT>(acc[t][r]);
+                for (int r = 0; r < 4; ++r) a[t][r] = actc_fwd<S::act(l)>(acc[t][r]);
         });
 
         // ---- last layer on the VALU: f_o = b_o + sum_u W[o][u] a_LL[u]
-        constexpr int TP = C::TR(LL);
-        float dzl[d_out];
+        constexpr int TP = LRT;
+        float dzl[LRO];
+        if constexpr (!C::VL && FWD) {
+            // MFMA last layer: a[0] is the output tile (lane (row i16, g): slots 4g .. 4g + 3)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = unit_of(d_out, 4 * g + r, false);
+                if (rvalid && u >= 0) fout[(size_t)u * n + tile * 16 + i16] = a[0][r];      // [d_out][n]
+            }
+        }
+        if constexpr (C::VL) {
 #pragma unroll
         for (int o = 0; o < d_out; ++o) {
             float p = 0.f;
@@ -460,9 +479,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 dzl[o] = rvalid ? lik_delta<S>(fi, y[o], inv_var, g == 0, stat) : 0.f;
             }
         }
+        }
         if constexpr (!FWD) {
         f32x4 dz[C::MAXT];
-        {
+        if constexpr (!C::VL) {
+            // likelihood on the output tile: delta_LL (w.r.t. the pre-activation) in the D layout, every (row, output) element once
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int u = unit_of(d_out, 4 * g + r, false);
+                dz[0][r] = (rvalid && u >= 0) ? lik_delta<S>(a[0][r], y[r], inv_var, true, stat) : 0.f;
+            }
+        } else {
             // the last layer's dW / db sums of this tile's rows; delta_{LL-1} = (W_LL^T dz_LL) * act'(a_LL)
 #pragma unroll
             for (int o = 0; o < d_out; ++o) {
@@ -691,8 +718,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) __attribute__((amdgpu_waves_per_eu
                 }
         });
     }
-    {
-        // last layer: reduce the per-row partials over the 16 lanes of a lane group, then over the 4 waves
+    if constexpr (C::VL) {
+        // VALU last layer: reduce the per-row partials over the 16 lanes of a lane group, then over the 4 waves
         constexpr int TP = C::TR(LL), inL = C::in(LL);
         float* lb = lds;                               // [wave][o][slot], then [wave][o] biases
         __syncthreads();
@@ -739,12 +766,12 @@ static void tall_image_map(int* map) {
             for (int k = 0; k < in; ++k) {
                 int m0;
                 if (l == 0) m0 = (((ri / 16) * C::NTP + k / 16) * 64 + ((k % 16) / 4) * 16 + ri % 16) * 4 + k % 4;
-                else if (l == C::LL) m0 = C::W0_FLOATS + C::WL_OFF + i * C::WLP + slot_of(in, k);
+                else if (C::VL && l == C::LL) m0 = C::W0_FLOATS + C::WL_OFF + i * C::WLP + slot_of(in, k);
                 else m0 = C::W0_FLOATS + C::wmoff(l) + ri * C::LDM(l) + slot_of(in, k);
                 map[ow + i * in + k] = m0;
                 map[P + ow + i * in + k] = -1;
             }
-            map[ow + in * out + i] = C::W0_FLOATS + (l == C::LL ? C::BL_OFF + i : C::boff(l) + ri);
+            map[ow + in * out + i] = C::W0_FLOATS + ((C::VL && l == C::LL) ? C::BL_OFF + i : C::boff(l) + ri);
             map[P + ow + in * out + i] = -1;
         }
     }

@@ -16,7 +16,7 @@ runs on the layered kernels):
   * mid (`k_fwd_bwd_mid`): >= 3 dense layers, <= 16 outputs (3 .. 16: the last layer is an MFMA layer too), fan-in <= 128, at most 63 dW tiles over the MFMA
     layers and weight images + operand blocks within 160 KB of LDS (`mid_fits`): one fused kernel, nothing through HBM;
   * tall (`k_fwd_bwd_tall`): a long first-layer fan-in (33 .. a few thousand columns) in front of narrow hidden layers
-    (<= 64 units), <= 2 outputs: the fan-in split over the four waves of a workgroup, W_0 and dW_0 in registers
+    (<= 64 units), <= 16 outputs (3 .. 16: the last layer is an MFMA layer too): the fan-in split over the four waves of a workgroup, W_0 and dW_0 in registers
     (`tall_fits`) -- the reference's MNIST example 784 -> 20 -> 20 -> 1;
   * wide (`k_chain_wide` + `k_dw_wide`): >= 3 dense layers, <= 2 outputs, fan-in <= 32,
     hidden widths <= 256.
@@ -87,7 +87,7 @@ def families(dims) -> list:
         out.append("fast")
     if nl >= 3 and dims[-1] <= 16 and dims[0] <= MID_MAX_FANIN and mid_fits(dims):
         out.append("mid")
-    if nl >= 2 and dims[-1] <= 2 and dims[0] > 32 and tall_fits(dims):
+    if nl >= 2 and dims[-1] <= 16 and dims[0] > 32 and tall_fits(dims):
         out.append("tall")
     if nl >= 3 and dims[-1] <= 2 and dims[0] <= 32 and max(dims[1:-1]) <= 256:
         out.append("wide")
@@ -118,23 +118,25 @@ def mid_fits(dims) -> bool:
 def tall_fits(dims) -> bool:
     """the tall-fan-in fused kernel (kernels_tall.hpp, TallCfg): a wave's chunk of W_0 and of dW_0 in its registers, the narrow
     layers' images, the exchange buffers and the per-wave operand blocks in 160 KB of LDS (an estimate: the build refuses a
-    kernel that spills and the next family takes the shape)"""
+    kernel that spills and the next family takes the shape).  <= 2 outputs: the last layer on the VALU; 3 .. 16: one more MFMA layer"""
     nl = len(dims) - 1
     if max(dims[1:-1]) > 64:
         return False
+    vl = dims[-1] <= 2
+    nm = nl - 2 if vl else nl - 1               # MFMA layers behind layer 0: 1 .. nm
     tr = lambda l: _cdiv(dims[l], 16)
     ta = lambda l: _cdiv(dims[l] + 1, 16)
     mt0, ch = tr(1), _cdiv(ta(0), 4)
-    dwm = sum(tr(l + 1) * ta(l) for l in range(1, nl - 1))
+    dwm = sum(tr(l + 1) * ta(l) for l in range(1, nm + 1))
     vgpr = 4 * mt0 * ch + 6 * ch + 70
     agpr = 4 * mt0 * ch + 4 * dwm
     if vgpr > 256 or vgpr + agpr > 500:
         return False
     r4 = lambda a: (a + 3) & ~3
-    perm = r4(sum(16 * tr(l + 1) for l in range(nl - 1)) + dims[-1] * 16 * tr(nl - 1) + dims[-1])
-    small = r4(perm + sum(16 * tr(l + 1) * (16 * tr(l) + 4) for l in range(1, nl - 1)))
+    perm = r4(sum(16 * tr(l + 1) for l in range(nm + 1)) + (dims[-1] * 16 * tr(nl - 1) + dims[-1] if vl else 0))
+    small = r4(perm + sum(16 * tr(l + 1) * (16 * tr(l) + 4) for l in range(1, nm + 1)))
     # exchange buffer of a group's 4 tiles | dW_0 staging of the epilogue, delta_0 of the group, per-wave a_l / delta_l blocks of the middle layers
-    wave = (sum(ta(l) for l in range(1, nl - 1)) + sum(tr(l + 1) for l in range(1, nl - 1))) * 256
+    wave = (sum(ta(l) for l in range(1, nm + 1)) + sum(tr(l + 1) for l in range(1, nm + 1))) * 256
     return (small + max(16 * mt0, 4 * ch) * 256 + 4 * mt0 * 256 + 4 * wave) * 4 + 64 <= 160 * 1024
 
 
