@@ -30,6 +30,7 @@ import sys
 from typing import Optional, Sequence
 
 NARROW_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]      # keep in step with build.py
+TALL_NOP = ["-DTBNN_ASM_MFMA_NOP=0"]                      # the tall family: no wait states inside its asm MFMAs (build.py says why); the check repairs
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -186,7 +187,7 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
         with open(os.environ["TBNN_JIT_LOG"], "a") as f:
             f.write(json.dumps({"layers": [list(map(int, l)) for l in layers], "likelihood": int(likelihood),
                                 "skip": os.environ.get("TBNN_JIT_SKIP", ""), "flags": os.environ.get("TBNN_JIT_FLAGS", "")}) + "\n")
-    key = hashlib.sha1(f"{dims}|{hact}|{lact}|{bern}|{_sources_stamp()}|{extra}|{families(dims)}".encode()).hexdigest()[:20]
+    key = hashlib.sha1(f"{dims}|{hact}|{lact}|{bern}|{_sources_stamp()}|{extra}|{families(dims)}|{NARROW_FLAGS}|{TALL_NOP}".encode()).hexdigest()[:20]
     d = cache_dir()
     so, failed = os.path.join(d, f"tbnn_{key}.so"), os.path.join(d, f"tbnn_{key}.fail")
     if os.path.exists(so):
@@ -221,7 +222,7 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                 status = ""
                 while True:
                     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
-                    cmd += NARROW_FLAGS + extra + notraj            # as build.py compiles the kernels (VGPR-form chain MFMAs)
+                    cmd += NARROW_FLAGS + (TALL_NOP if fam == "tall" else []) + extra + notraj      # as build.py compiles the kernels (VGPR-form chain MFMAs)
                     cmd += ["-Rpass-analysis=kernel-resource-usage", "-o", tmp, src]      # the remarks carry each kernel's ScratchSize
                     if verbose:
                         print(" ".join(cmd), flush=True)

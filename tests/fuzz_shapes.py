@@ -4,6 +4,8 @@ from MFMA hazard pairs; all found by those fuzzers, none by the suite as it stoo
 every case here (tensorbnn_amd/jit.prebuild), so that the GPU run finds them built and checked.
 
 A case: dict(family, dims, n, act, lik, prior, skip) -- `skip` is the TBNN_JIT_SKIP that makes the family named take the shape."""
+import os
+
 import numpy as np
 
 ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU = 1, 2, 3, 5
@@ -47,7 +49,10 @@ def _dims(rng, fam):
     return [_edge(rng, 1, 600)] + [_edge(rng, 2, 300) for _ in range(int(rng.integers(1, 4)))] + [int(rng.choice([1, 2, 3, 5, 10, 17]))]
 
 
-def cases(per_family: int = 8, seed: int = 606):
+def cases(per_family: int = None, seed: int = None):
+    # TBNN_FUZZ_SEED / TBNN_FUZZ_PER_FAMILY: a one-off larger draw (the suite's own shard is the default)
+    seed = int(os.environ.get("TBNN_FUZZ_SEED", "606")) if seed is None else seed
+    per_family = int(os.environ.get("TBNN_FUZZ_PER_FAMILY", "8")) if per_family is None else per_family
     out = []
     for fi, fam in enumerate(("narrow", "mid", "tall", "wide", "layered")):
         got, idx = 0, 0
@@ -77,8 +82,10 @@ def cases(per_family: int = 8, seed: int = 606):
     return out
 
 
-def transition_cases(count: int = 8, seed: int = 707):
+def transition_cases(count: int = None, seed: int = None):
     """whatever family serves the shape (no TBNN_JIT_SKIP): an injected transition and a hyper transition"""
+    seed = int(os.environ.get("TBNN_FUZZ_SEED", "606")) + 101 if seed is None else seed
+    count = int(os.environ.get("TBNN_FUZZ_TRANSITIONS", "8")) if count is None else count
     rng = np.random.default_rng(seed)
     out = []
     kinds = ["narrow", "mid", "tall", "wide", "layered", "narrow", "mid", "tall"]
