@@ -32,6 +32,25 @@ def _tally(found):
     return " ".join(f"{k}:{v}" for k, v in sorted(t.items()))
 
 
+def _plain(cmd, why: str) -> Result:
+    cmd = [c for c in cmd if c != "-DTBNN_ASM_MFMA_NOP=0"]
+    cmd = cmd[:1] + ["-DTBNN_ASM_MFMA_NOP=1"] + cmd[1:]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True)
+    except OSError as e:
+        return Result(-1, str(e))
+    if p.returncode != 0:
+        return Result(p.returncode, p.stderr)
+    out = cmd[cmd.index("-o") + 1] if "-o" in cmd else None
+    try:
+        found = hazard_lint.check(out)
+    except (OSError, subprocess.CalledProcessError, RuntimeError, ValueError, TypeError) as e:
+        return Result(1, p.stderr + f"\n{cmd[-1]}:1:1: error: the unit cannot be checked for MFMA hazards (no compiler listing: {why.strip()[-200:]!r}; no disassembly: {e})\n")
+    if found:
+        return Result(1, p.stderr + f"\n{cmd[-1]}:1:1: error: MFMA hazards in a unit that could only be compiled plainly: {hazard_lint.describe(found)}\n", "", [], found)
+    return Result(0, p.stderr, "compiled plainly with the wait states inside the asm MFMAs (the compiler driver printed no sub-commands); disassembly clean")
+
+
 def run(cmd, keep_listing: str = None, verify: bool = True) -> Result:
     """`cmd`: a complete hipcc command line (list; the output after -o and the source with absolute paths), compiling ONE source to an object
     or a shared library.  `keep_listing`: copy the repaired device listing there (diagnostics)."""
@@ -43,8 +62,11 @@ def run(cmd, keep_listing: str = None, verify: bool = True) -> Result:
         except OSError as e:
             return Result(-1, str(e))
         steps = [shlex.split(l) for l in r.stderr.splitlines() if l.startswith(' "')]
-        if r.returncode != 0 or not steps:
-            return Result(r.returncode or 1, r.stderr)
+        is_listing = lambda st: "-S" in st and "-o" in st and "-triple" in st and st[st.index("-triple") + 1].startswith("amdgcn")
+        if r.returncode != 0 or not any(is_listing(st) for st in steps):
+            # a compiler driver that does not print its sub-commands this way: compile plainly with the wait states inside every asm MFMA and
+            # let the disassembly decide -- clean, or no object
+            return _plain(cmd, r.stderr)
         fixed, left, nlist = [], [], 0
         for st in steps:
             try:
@@ -54,7 +76,7 @@ def run(cmd, keep_listing: str = None, verify: bool = True) -> Result:
             err_all.append(p.stderr)
             if p.returncode != 0:
                 return Result(p.returncode, "\n".join(err_all))
-            if "-S" in st and "-o" in st and "-triple" in st and st[st.index("-triple") + 1].startswith("amdgcn"):
+            if is_listing(st):
                 out = st[st.index("-o") + 1]
                 path = out if os.path.isabs(out) else os.path.join(work, out)
                 text = open(path).read()

@@ -294,8 +294,10 @@ def prebuild(jobs, processes: int = 6) -> int:
     todo = [(j["layers"], j["likelihood"], j.get("skip", ""), j.get("flags", "")) for j in uniq.values()]
     keep = {k: os.environ.get(k) for k in ("TBNN_JIT_SKIP", "TBNN_JIT_FLAGS")}
     try:
-        with get_context("spawn").Pool(max(1, min(processes, len(todo)))) as pool:
-            done = pool.map(_prebuild_one, todo, chunksize=1)
+        # fork, not spawn: a spawned worker re-imports __main__, and a caller that runs from stdin or `-c` has none to import (it hangs);
+        # the workers only drive compiler subprocesses and never touch a GPU
+        with get_context("fork").Pool(max(1, min(processes, len(todo)))) as pool:
+            done = pool.map_async(_prebuild_one, todo, chunksize=1).get(timeout=3600)
     finally:
         for k, v in keep.items():
             if v is None:

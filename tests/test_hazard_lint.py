@@ -490,9 +490,9 @@ def test_built_library_has_no_mfma_hazard():
 def test_checked_compile_repairs_what_the_plain_compile_leaves(tmp_path, monkeypatch):
     """15 -> 170 -> 114 -> 1 on the wide family: with two waves per SIMD the register allocator parks a-blocks of k_dw_wide in AccVGPRs and brings
     one back (v_accvgpr_read) straight in front of the inline-asm MFMA that reads it (round 5: wrong, unrepeatable dW tiles).  Since round 6 every
-    asm MFMA carries its own two wait states (TBNN_ASM_MFMA_NOP=1, the default): jit.build hands out a library without any finding.  Compiled
-    plainly WITHOUT them the same source shows the pair -- which is what makes this test mean something -- and the checked compile of that
-    variant repairs it in the listing.  No GPU needed: hipcc cross-compiles, llvm-objdump disassembles."""
+    asm MFMA carries its own two wait states (TBNN_ASM_MFMA_NOP=1, the default): jit.build hands out a library without any finding.  The same
+    source compiled plainly WITHOUT them, and through the checked compile: the latter repairs what the former shows (a pair that is certainly
+    left by a plain compile: test_checked_compile_needs_no_disassembler).  No GPU needed: hipcc cross-compiles, llvm-objdump disassembles."""
     from tensorbnn_amd import jit, checked_compile as cc, _native as nat
     if not _tools():
         pytest.skip("needs hipcc and llvm-objdump")
@@ -513,12 +513,15 @@ def test_checked_compile_repairs_what_the_plain_compile_leaves(tmp_path, monkeyp
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-DTBNN_ASM_MFMA_NOP=0"] + jit.NARROW_FLAGS
     subprocess.run(cmd + ["-o", str(plain), str(src)], check=True, stderr=subprocess.DEVNULL)
     found = hl.check(str(plain))
-    assert any("k_dw_wide" in f[0] and f[1].startswith("v_accvgpr_read") and f[4].startswith("R1") for f in found), hl.describe(found)
-    # ... and through the checked compile
+    # (round 5: `v_accvgpr_read` of a parked a-block straight in front of the asm MFMA, R1.  Round 6 gave the accumulators their own register class
+    # from birth -- acc_zero -- and the register pressure behind the parking went with it: the pair may be gone from this shape; whatever the plain
+    # compile shows, the checked compile of the same source must have repaired exactly when there was something to repair)
+    assert all(f[4].split()[0] in ("R1", "R2a", "R2b", "R2c", "R2d", "R3", "R4") for f in found), hl.describe(found)
     fixed = tmp_path / "fixed.so"
     r = cc.run(cmd + ["-o", str(fixed), str(src)])
-    m = re.search(r"listing checked \((\d+) repaired: ([^)]*)\)", r.status)
-    assert r.rc == 0 and m and int(m.group(1)) > 0 and "R1" in m.group(2) and "disassembly clean" in r.status, r.status
+    m = re.search(r"listing checked \((\d+) repaired", r.status)
+    assert r.rc == 0 and m and "disassembly clean" in r.status, r.status
+    assert (int(m.group(1)) > 0) == bool(found), (r.status, hl.describe(found))
     assert hl.check(str(fixed)) == []
 
 
@@ -549,3 +552,24 @@ __global__ void k(float* p, float a, float b) {
     i = fixed.index("v_mfma_f32_16x16x4_f32")
     assert re.search(r"s_nop \d+\n(\s*;[^\n]*\n)*\s*v_mul_f32", fixed[i:]), fixed[i:i + 400]
     assert hl.hazards_cfg(fixed) == []
+
+
+def test_checked_compile_with_a_driver_that_prints_no_subcommands(tmp_path, monkeypatch):
+    """another toolchain may not answer `-###` the way this hipcc does: the unit is then compiled plainly with the wait states inside every asm MFMA
+    and must pass the disassembly check -- clean, or no object; never an unchecked one"""
+    from tensorbnn_amd import checked_compile as cc
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not _tools():
+        pytest.skip("needs hipcc and llvm-objdump")
+    wrapper = tmp_path / "hipcc_quiet"
+    wrapper.write_text(f"#!/bin/sh\nfor a in \"$@\"; do [ \"$a\" = \"-###\" ] && exit 0; done\nexec {hipcc} \"$@\"\n")
+    wrapper.chmod(0o755)
+    src = tmp_path / "k.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n__global__ void k(float* p) { p[threadIdx.x] = 1.f; }\n")
+    out = tmp_path / "k.o"
+    r = cc.run([str(wrapper), "--offload-arch=gfx950", "-O3", "-c", str(src), "-o", str(out)])
+    assert r.rc == 0 and out.exists() and "compiled plainly" in r.status and "disassembly clean" in r.status, (r.status, r.stderr[-300:])
+    # ... and without a disassembler there is nothing to vouch for it
+    monkeypatch.setattr(hl, "LLVM_BIN", str(tmp_path / "nowhere"))
+    r = cc.run([str(wrapper), "--offload-arch=gfx950", "-O3", "-c", str(src), "-o", str(tmp_path / "k2.o")])
+    assert r.rc != 0 and "cannot be checked" in r.stderr
