@@ -508,6 +508,11 @@ def _short_roof(r):
     keep = ("bound", "achieved", "peak", "unit", "frac", "frac_rocprof", "frac_mfma", "frac_hbm", "rocprof_source", "profile_build_match", "traffic",
             "kernel_us", "end_to_end_frac")          # ("kernel" is config.kernel: not repeated on the short line)
     out = {k: r[k] for k in keep if k in r}
+    if r.get("hazard_check"):                      # the build-time MFMA hazard check, in short: units checked / pairs repaired in their listings
+        import re
+        hc = r["hazard_check"]
+        fixed = sum(int(x) for x in re.findall(r"[(](\d+) repaired", hc))
+        out["hazard_check"] = f"{hc.count('listing checked')} units checked in the compile, {fixed} pairs repaired"
     if out.get("rocprof_source"):
         out["rocprof_source"] = out["rocprof_source"].replace("profiles/", "")
     if "launch latency" in str(out.get("bound", "")):
