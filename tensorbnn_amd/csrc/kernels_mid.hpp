@@ -116,6 +116,20 @@ struct MidCfg {
     static constexpr int TA(int l) { return cdiv(in(l) + 1, 16); }      // block tiles (with the ones slot)
     static constexpr int ksteps(int K, int kg) { int rem = K - 16 * kg; return rem >= 16 ? 4 : (rem <= 0 ? 0 : (rem + 3) / 4); }
     static constexpr int KG(int K) { return cdiv(K, 16); }
+    // Fringe (round 6; VERDICT rounds 3-5, configs[4]: 100 = 6 x 16 + 4 units pay for 112): a layer side of 16 T + F units with 1 <= F <= 4 runs its last
+    // tile on the 16-block v_mfma_f32_4x4x1 -- 8 cycles per k-step instead of 32 -- where the operands allow it without new LDS traffic:
+    //   fr_out(l): layer l's OUTPUT units in the forward pass (A operand: the image rows of the F units, the same 16-byte reads as a full tile's);
+    //   fr_in(l):  layer l's INPUT units in the delta chain (A operand: the image columns of the F units, the same strided 4-byte reads).
+    // The D layout of the previous layer is the 4x4x1 form's B operand as it stands (block = (k phase g, row quad), as the narrow family uses it);
+    // the four k phases are summed with the row-swap instructions (gsum) and unit 16 T + e lands in register 0 of lane group e: its slot (slot_of).
+    // Worth it when the k loop is long (>= 8 k-steps: the sums cost ~20 VALU instructions).  dW's fringe strips are not built.
+#ifndef MID_FRINGE
+#define MID_FRINGE 1
+#endif
+    static constexpr bool fr_units(int U) { return MID_FRINGE && U > 16 && U % 16 >= 1 && U % 16 <= 4; }
+    static constexpr int total_ksteps(int K) { return (K + 3) / 4; }
+    static constexpr bool fr_out(int l) { return l >= 1 && fr_units(out(l)) && total_ksteps(in(l)) >= 8; }
+    static constexpr bool fr_in(int l) { return l >= 1 && fr_units(in(l)) && total_ksteps(out(l)) >= 8; }
     static constexpr int maxT() { int m = 0; for (int l = 1; l <= (VL ? LL : NL); ++l) m = TR(l) > m ? TR(l) : m; return m; }
     static constexpr int MAXT = maxT();
     static constexpr int maxTA() { int m = cdiv(in(0) + 1, 16); for (int l = 1; l <= NM; ++l) m = TA(l) > m ? TA(l) : m; return m; }
@@ -256,11 +270,12 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
     auto preload_mid = [&](auto l_, int slot, int nslot) __attribute__((always_inline)) {
         constexpr int l = decltype(l_)::value;
         const float* wrow = lds + C::wmoff(l) + i16 * C::LDM(l) + 4 * g;
+        const float* frow = lds + C::wmoff(l) + (4 * (lane & 3)) * C::LDM(l) + 4 * g;       // fringe tile: lane (k phase g, row quad, i): unit 16 T + i = slot 16 T + 4 i
 #pragma unroll
         for (int t = 0; t < C::TR(l + 1); ++t)
             if (t % nslot == slot) {
                 Bpre[t] = *reinterpret_cast<const f32x4*>(lds + C::boff(l) + 16 * t + 4 * g);
-                Apre[t] = load_ks(wrow + 16 * t * C::LDM(l), C::ksteps(C::in(l), 0));
+                Apre[t] = load_ks(((C::fr_out(l) && t == C::TR(l + 1) - 1) ? frow : wrow) + 16 * t * C::LDM(l), C::ksteps(C::in(l), 0));
             }
     };
     auto preload_l0 = [&](int slot, int nslot) __attribute__((always_inline)) {
@@ -358,10 +373,14 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                 }
             }
             constexpr int MT = C::TR(l + 1), K = C::in(l), KGn = C::KG(K);
+            constexpr bool FR = C::fr_out(l);
+            constexpr int MTF = FR ? MT - 1 : MT;                 // full tiles; tile MTF: the fringe units on the 4x4x1 form
             f32x4 acc[MT], An[MT];
 #pragma unroll
-            for (int t = 0; t < MT; ++t) { acc[t] = Bpre[t]; An[t] = Apre[t]; }
+            for (int t = 0; t < MT; ++t) { acc[t] = (FR && t == MTF) ? f32x4{0.f, 0.f, 0.f, 0.f} : Bpre[t]; An[t] = Apre[t]; }
+            const float fbias = FR ? Bpre[FR ? MTF : 0][0] : 0.f;  // lane group e: the bias of unit 16 MTF + e (slot 16 MTF + 4 e)
             const float* wrow = lds + C::wmoff(l) + i16 * C::LDM(l) + 4 * g;
+            const float* frow = lds + C::wmoff(l) + (4 * (lane & 3)) * C::LDM(l) + 4 * g;
             sfor<0, KGn>(SFOR_LAMBDA(kg) {
                 constexpr int kg = SFOR_VAL(kg);
                 f32x4 A[MT];
@@ -372,9 +391,10 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                 for (int s = 0; s < C::ksteps(K, kg); ++s) {
 #pragma unroll
                     for (int t = 0; t < MT; ++t) {
-                        acc[t] = mfma16(A[t][s], a[kg][s], acc[t]);
+                        if (FR && t == MTF) acc[t] = mfma4(A[t][s], a[kg][s], acc[t]);
+                        else acc[t] = mfma16(A[t][s], a[kg][s], acc[t]);
                         if (s == 0) {
-                            if constexpr (kg + 1 < KGn) An[t] = load_ks(wrow + 16 * t * C::LDM(l) + 16 * (kg + 1), C::ksteps(K, kg + 1));
+                            if constexpr (kg + 1 < KGn) An[t] = load_ks(((FR && t == MTF) ? frow : wrow) + 16 * t * C::LDM(l) + 16 * (kg + 1), C::ksteps(K, kg + 1));
                             else if constexpr (l < NM) preload_mid(std::integral_constant<int, (l < NM ? l + 1 : l)>{}, t, MT);
                             else preload_last(t, MT);
                             MID_FENCE();
@@ -383,10 +403,18 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                     MID_FENCE();
                 }
             });
+            if constexpr (FR) {
+                // register i of lane (k phase g, row): unit 16 MTF + i over the k slots of phase g; the four phases summed, unit 16 MTF + g kept
+                float z[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[i] = gsum(acc[MTF][i]);
+                const float sel = g == 0 ? z[0] : (g == 1 ? z[1] : (g == 2 ? z[2] : z[3]));
+                acc[MTF] = f32x4{sel + fbias, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[t][r] = actc_fwd<S::act(l)>(acc[t][r]);
+                for (int r = 0; r < 4; ++r) a[t][r] = (FR && t == MTF && r > 0) ? 0.f : actc_fwd<S::act(l)>(acc[t][r]);
         });
         MSTAMP(2);
 
@@ -484,7 +512,8 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
         };
         auto chain_load = [&](auto l_, int kg, int u) __attribute__((always_inline)) {
             constexpr int l = decltype(l_)::value;
-            const float* wcol = lds + C::wmoff(l) + 4 * g * C::LDM(l) + i16;
+            // (fringe tile of the chain's output = layer l's input units 16 T .. 16 T + F - 1: lane (k phase g, row quad, i) reads column slot 16 T + 4 i)
+            const float* wcol = lds + C::wmoff(l) + 4 * g * C::LDM(l) + ((C::fr_in(l) && u == C::TR(l) - 1) ? 4 * (lane & 3) : i16);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 if (s < C::ksteps(C::out(l), kg)) Wn[s][u] = wcol[(16 * kg + s) * C::LDM(l) + 16 * u];
@@ -537,7 +566,7 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                     if constexpr (k < NWg) extra(std::integral_constant<int, k>{});
                     else if constexpr (k < NWg + NCg) {
                         constexpr int c = k - NWg, u = c / 2, h = c % 2;
-                        const float* wcol = lds + C::wmoff(l) + 4 * g * C::LDM(l) + i16;
+                        const float* wcol = lds + C::wmoff(l) + 4 * g * C::LDM(l) + ((C::fr_in(l) && u == MU - 1) ? 4 * (lane & 3) : i16);
 #pragma unroll
                         for (int s2 = 2 * h; s2 < 2 * h + 2; ++s2)
                             if (s2 < C::ksteps(K, kg + 1)) Wn[s2][u] = wcol[(16 * (kg + 1) + s2) * C::LDM(l) + 16 * u];
@@ -545,7 +574,8 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                 };
                 sfor<0, NMFg>(SFOR_LAMBDA(j) {
                     constexpr int j = SFOR_VAL(j), sj = j / MU, uj = j % MU;
-                    acc[uj] = mfma16(A[sj][uj], dz[kg][sj], acc[uj]);
+                    if constexpr (C::fr_in(l) && uj == MU - 1) acc[uj] = mfma4(A[sj][uj], dz[kg][sj], acc[uj]);
+                    else acc[uj] = mfma16(A[sj][uj], dz[kg][sj], acc[uj]);
                     // operations k with k * SPAN / NOPS == j
                     constexpr int k0 = NOPS > 0 ? (j * NOPS + SPAN - 1) / SPAN : 0, k1 = NOPS > 0 ? ((j + 1) * NOPS + SPAN - 1) / SPAN : 0;
                     constexpr int ka = k0 < NOPS ? k0 : NOPS, kb = j + 1 >= NMFg ? NOPS : (k1 < NOPS ? k1 : NOPS);
@@ -557,6 +587,12 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
             f32x4 dzp[C::MAXT];
             constexpr bool PKR = S::act(l - 1) == TBNN_ACT_RELU && TBNN_F3_RELU_PK && MU <= 8;
             if constexpr (PKR) mfma_settle(acc);
+            if constexpr (C::fr_in(l)) {
+                float z[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[i] = gsum(acc[MU - 1][i]);
+                acc[MU - 1] = f32x4{g == 0 ? z[0] : (g == 1 ? z[1] : (g == 2 ? z[2] : z[3])), 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int u = 0; u < MU; ++u) dzp[u] = actc_bwd_mul4<S::act(l - 1), PKR>(acc[u], al[u]);
             MSTAMP(4 + 2 * SFOR_VAL(li));
