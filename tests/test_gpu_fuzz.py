@@ -70,6 +70,14 @@ def test_value_gradient_forward_vs_fp64_and_repeatable(native, family_env, c):
             if os.environ.get("TBNN_FUZZ_SEED") and jit.build(layers, spec.likelihood) is None:
                 pytest.skip(f"a one-off draw: the build refuses the {c['family']} kernel of {c['dims']} (spills), {name} takes it")
             assert False, f"{c['dims']} runs on {name}, not on the {c['family']} family"
+        if c["family"] != "layered":
+            # the library this chain runs on went through the hazard check inside its compile, and says so (never an unchecked unit)
+            from tensorbnn_amd import jit
+            so = jit.build(layers, spec.likelihood)
+            if so is not None:                               # (None: a registry shape by chance -- libtbnn's own status covers it)
+                st_ = jit.lint_status(so)
+                assert st_.startswith(("fast", "mid", "tall", "wide")) and ("listing checked" in st_ or "disassembly clean" in st_), st_
+            assert "listing checked" in native.lint_status()
         ch.set_data(X, Y)
         lp, g, st = ch.logp_grad(theta, eta)
         for _ in range(2):                                   # three launches, bit for bit
