@@ -106,3 +106,29 @@ def test_transitions(native, monkeypatch, name):
             th = got
     ch.close()
     t.check(f"multi-output [{name}]")
+
+
+@pytest.mark.parametrize("name", ["gauss5", "mnist10"])
+def test_chain_group_equals_solo_chains(native, monkeypatch, name):
+    """several chains behind one handle (gridDim.y = chain) on the multi-output kernels: chain c is the solo chain chain_id + c, bit for bit"""
+    spec, X, Y, theta, eta = problem(name)
+    fam = CASES[name][5]
+    monkeypatch.setenv("TBNN_JIT_SKIP", SKIP[fam])
+    C, eps, L, E = 3, (1e-3 if name == "mnist10" else 2e-4), 4, 5
+    rng = np.random.default_rng(8)
+    thetas = (theta[None, :] * (1.0 + 0.03 * rng.standard_normal((C, theta.size)))).astype(np.float32)
+    etas = np.tile(eta, (C, 1)).astype(np.float32)
+    grp = native.ChainGroup(layers_of(spec), C, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, seed=SEED, chain_id=4, jit=True)
+    assert grp.kernel_name.startswith(f"jit-{fam}<")
+    grp.set_data(X, Y); grp.set_state(thetas); grp.set_hypers(etas)
+    recs = grp.hmc_run(eps, L, E)
+    states = grp.get_state()
+    grp.close()
+    for c in range(C):
+        ch = chain(native, monkeypatch, name, spec, seed=SEED, chain_id=4 + c)
+        ch.set_data(X, Y); ch.set_state(thetas[c]); ch.set_hypers(etas[c])
+        solo = ch.hmc_run(eps, L, E)
+        assert [r["log_accept_ratio"] for r in solo] == [r["log_accept_ratio"] for r in recs[c]]
+        assert [r["accepted"] for r in solo] == [r["accepted"] for r in recs[c]]
+        assert np.array_equal(ch.get_state(), states[c])
+        ch.close()
