@@ -91,6 +91,8 @@ def run(cmd, keep_listing: str = None, verify: bool = True) -> Result:
         if nlist == 0:
             return Result(1, "\n".join(err_all) + "\nchecked_compile: hipcc produced no gfx950 listing to check\n")
         status = f"listing checked ({len(fixed)} repaired{': ' + _tally(fixed) if fixed else ''})"
+        if hazard_lint.RULES_OFF:                                  # a diagnostic switch must not pass for a full check
+            status += f" WITH RULES SWITCHED OFF: {','.join(sorted(hazard_lint.RULES_OFF))}"
         if left:
             return Result(1, "\n".join(err_all) + f"\n{cmd[-1]}:1:1: error: MFMA hazards without a local repair: {hazard_lint.describe(left)}\n", status, fixed, left)
         if verify and "-o" in cmd and hazard_lint.available():

@@ -242,7 +242,8 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
                     print(f"tensorbnn_amd: {fam} kernels of {dims}: {status}", file=sys.stderr, flush=True)
                 if rc == 0:
                     with open(so + ".lint", "w") as f:
-                        f.write(f"{fam}: {status}\n")
+                        nop_off = fam == "tall" or "-DTBNN_ASM_MFMA_NOP=0" in extra
+                        f.write(f"{fam}: {status}; wait states inside the asm MFMAs: {'off (left to the check)' if nop_off else 'on'}\n")
                 for f_ in (src,):
                     if os.path.exists(f_):
                         os.remove(f_)
