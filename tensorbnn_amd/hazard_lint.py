@@ -21,6 +21,9 @@ matrix instruction is priced at the worst case of the table, 16 passes and the X
   R2c mfma->valu     ... read OR overwritten by a VALU instruction: P + 2                   (GFX940_SMFMA_N_PassWriteVgprVALUMemExpReadWaitStates, ..VALUWaw..)
   R2d mfma->mem      ... used as data or address of an LDS / global / buffer / flat / scratch / export instruction: P + 2        (same helper)
   R3  exec->mfma     a VALU instruction writes EXEC (v_cmpx), an MFMA follows: 4              (checkMAIHazards90A: VALUWritesExecWaitStates)
+  R5  trans->valu    a transcendental instruction (v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin / v_cos) writes a VGPR, a VALU instruction that is
+                     not itself transcendental reads it: 1 wait state     (checkVALUHazards: TransDefWaitstates, hasTransForwardingHazard = gfx940+).
+                     The kernels keep their inline-asm packed instructions away from such results at the source (MidCfg's PKA); this is the net under that.
   R4  load->use      a register loaded by an LDS or vector-memory instruction is touched before an `s_waitcnt` that covers the load.  The
                      compiler counts its own loads; a load issued from an asm string (nf_load's `ds_read_b128 a[..]`) is invisible to it, and
                      a copy or spill the register allocator puts between that load and the hand-written wait would read the register early.
@@ -110,6 +113,13 @@ def is_valu(op):
 
 def is_mem(op):
     return op.startswith(_MEM)
+
+
+_TRANS = re.compile(r"^v_(exp|log|rcp|rcp_iflag|rsq|sqrt|sin|cos)(_legacy)?_(f16|f32|bf16)")
+
+
+def is_trans(op):
+    return _TRANS.match(op) is not None
 
 
 def mfma_passes(op: str) -> int:
@@ -332,6 +342,12 @@ def _scan_function(fn, ins, out):
                 stack += [(k, age + y.ws, regs2) for k in succ[j]]
             for j, age in sorted(hits.items()):
                 out.append((fn, x.text, ins[j].text, age, "R1 valu->mfma", NEED, x.addr, ins[j].addr, x.line, ins[j].line))
+        # ---- R5: transcendental result -> non-transcendental VALU read
+        if "R5" not in RULES_OFF and is_trans(x.op) and x.wr:
+            for j in succ[i]:
+                y = ins[j]
+                if y.op.startswith("v_") and not is_trans(y.op) and (y.rd & x.wr):
+                    out.append((fn, x.text, y.text, 0, "R5 trans->valu", 1, x.addr, y.addr, x.line, y.line))
         # ---- R3: VALU write of EXEC -> MFMA
         if "R3" not in RULES_OFF and x.wexec:
             stack, seen, hits = [(j, 0) for j in succ[i]], set(), {}

@@ -194,6 +194,30 @@ def test_r3_exec_write_then_mfma():
     assert rules(hl.hazards_cfg(listing)) == [("R3", 3, 4)]
 
 
+def test_r5_transcendental_result_read_by_the_next_valu_instruction():
+    listing = lst("""
+	v_exp_f32_e32 v0, v1
+	v_pk_mul_f32 v[4:5], v[0:1], v[2:3]
+	v_rcp_f32_e32 v6, v7
+	s_nop 0
+	v_mul_f32_e32 v8, v6, v9
+	v_exp_f32_e32 v0, v1
+	v_rcp_f32_e32 v10, v0
+	v_log_f32_e32 v11, v12
+	v_mov_b32_e32 v20, v21
+	v_add_f32_e32 v13, v11, v11
+	s_endpgm
+""")
+    # the packed multiply right behind v_exp reads its result: hazard; behind s_nop 0: fine; a transcendental reader: fine; one instruction between: fine
+    assert rules(hl.hazards_cfg(listing)) == [("R5", 0, 1)]
+    new, fixed, left = hl.fix_listing(slist("""
+	v_exp_f32_e32 v0, v1
+	v_pk_mul_f32 v[4:5], v[0:1], v[2:3]
+	s_endpgm
+"""))
+    assert left == [] and "s_nop 0" in new and hl.hazards_cfg(new) == []
+
+
 # ---- R4: a loaded register touched before a wait that covers the load
 def test_r4_register_of_an_asm_load_touched_before_the_wait():
     """nf_load's `ds_read_b128 a[..]` is inline asm: the compiler does not count it, and a copy the register allocator puts between the load
@@ -405,6 +429,13 @@ define amdgpu_kernel void @r2d_lds(ptr addrspace(3) %l, float %a, float %b) {
   store <4 x float> %c, ptr addrspace(3) %l
   ret void
 }
+declare float @llvm.amdgcn.exp2.f32(float)
+define amdgpu_kernel void @r5(ptr addrspace(1) %p, float %a) {
+  %e = call float @llvm.amdgcn.exp2.f32(float %a)
+  %f = fadd float %e, 1.0
+  store float %f, ptr addrspace(1) %p
+  ret void
+}
 define amdgpu_kernel void @r1(ptr addrspace(1) %p, float %a, float %b) {
   %x = fadd float %a, %b
   %c = call <4 x float> @llvm.amdgcn.mfma.f32.16x16x4f32(float %x, float %b, <4 x float> zeroinitializer, i32 0, i32 0, i32 0)
@@ -414,7 +445,7 @@ define amdgpu_kernel void @r1(ptr addrspace(1) %p, float %a, float %b) {
 """
 # probe -> (rule the probe exercises, wait states the rule says the pair needs)
 EXPECT = {"r2a_16": ("R2a", 10), "r2a_4": ("R2a", 4), "r2b_4": ("R2b", 2), "r2b_16": (None, 0), "r2c_16": ("R2c", 10), "r2d_16": ("R2d", 10),
-          "r2d_4": ("R2d", 4), "r2d_32": ("R2d", 18), "r2d_lds": ("R2d", 10), "r1": ("R1", 2)}
+          "r2d_4": ("R2d", 4), "r2d_32": ("R2d", 18), "r2d_lds": ("R2d", 10), "r1": ("R1", 2), "r5": ("R5", 1)}
 
 
 def test_hazard_rules_agree_with_the_installed_compiler(tmp_path):
@@ -442,6 +473,8 @@ def test_hazard_rules_agree_with_the_installed_compiler(tmp_path):
         # the window this probe is about: between its two MFMAs, or between its MFMA and the consumer behind it; for r1 in front of the MFMA
         if rule == "R1":
             lo, hi = 0, imf[0]
+        elif rule == "R5":
+            lo, hi = 0, len(lines)                         # (no MFMA in this probe: the transcendental and its reader)
         elif len(imf) == 2:
             lo, hi = imf[0], imf[1]
         else:
