@@ -328,6 +328,16 @@ def ensure_registered(layers: Sequence[tuple], likelihood: int, verbose: bool = 
 
 if __name__ == "__main__":
     from . import _native as nat
+    if len(sys.argv) > 2 and sys.argv[1] == "--prebuild":
+        # python -m tensorbnn_amd.jit --prebuild shapes.json [processes]: compile the kernel libraries of a list of shapes (the lines a run with
+        # TBNN_JIT_LOG=<file> wrote, or a JSON list of them) into the cache -- on a build machine, for a target without a compiler: the cache
+        # directory (TBNN_JIT_DIR, default tensorbnn_amd/_jit) travels with the package
+        import json
+        txt = open(sys.argv[2]).read().strip()
+        jobs = json.loads(txt) if txt.startswith("[") else [json.loads(l) for l in txt.splitlines() if l.strip()]
+        n = prebuild(jobs, int(sys.argv[3]) if len(sys.argv) > 3 else min(8, os.cpu_count() or 4))
+        print(f"{n} of {len(jobs)} kernel libraries present in {cache_dir()}")
+        sys.exit(0)
     dims = [int(x) for x in sys.argv[1].split(",")]
     act = {"relu": nat.ACT_RELU, "tanh": nat.ACT_TANH, "sigmoid": nat.ACT_SIGMOID}[sys.argv[2] if len(sys.argv) > 2 else "relu"]
     layers = [(dims[i], dims[i + 1], act if i < len(dims) - 2 else nat.ACT_NONE, nat.PRIOR_CAUCHY) for i in range(len(dims) - 1)]
