@@ -512,7 +512,7 @@ def _short_roof(r):
         import re
         hc = r["hazard_check"]
         fixed = sum(int(x) for x in re.findall(r"[(](\d+) repaired", hc))
-        out["hazard_check"] = f"{hc.count('listing checked')} units checked in the compile, {fixed} pairs repaired"
+        out["hazard_check"] = f"{hc.count('listing checked')} units checked, {fixed} pairs repaired"
     if out.get("rocprof_source"):
         out["rocprof_source"] = out["rocprof_source"].replace("profiles/", "")
     if "launch latency" in str(out.get("bound", "")):
@@ -564,7 +564,7 @@ def compact_line(line):
                 e["hyper_step"] = float("%.3g" % r["hyper_step_size"]["last"]) if r.get("hyper_step_size") else None
             sec[key.replace(" with GaussianDenseLayer priors", "g").replace("docs example 784-20-20-1", "docs784")] = e
         out["secondary"] = sec
-        out["secondary_note"] = "[4]: Cauchy priors (improper hyper target, Q1); [4]g: Gaussian priors; [0]x64: 64 chains, 1 GPU; docs784: reference tutorial shape; all: gpurun_out/bench_full.json"
+        out["secondary_note"] = "[4]: Cauchy priors (Q1); [4]g: Gaussian priors; [0]x64: 64 chains, 1 GPU; docs784: tutorial shape; all: gpurun_out/bench_full.json"
     return out
 
 

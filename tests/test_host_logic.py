@@ -520,6 +520,6 @@ def test_bench_line_says_what_the_hazard_check_did():
     full = ("tbnn_api.hip: listing checked (0 repaired); disassembly clean; tbnn_mid.hip: listing checked (2 repaired: R2c:2); disassembly clean; "
             "wait states inside the asm MFMAs: on (off in tbnn_tall.hip: left to the check)")
     short = bench._short_roof({"bound": "mfma", "achieved": 1.0, "peak": 2.0, "unit": "TFLOP/s", "frac": 0.5, "traffic": None, "hazard_check": full})
-    assert short["hazard_check"] == "2 units checked in the compile, 2 pairs repaired"
+    assert short["hazard_check"] == "2 units checked, 2 pairs repaired"
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(short)
     assert "hazard_check" not in bench._short_roof({"bound": "mfma"})
