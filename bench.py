@@ -514,7 +514,7 @@ def _short_roof(r):
         fixed = sum(int(x) for x in re.findall(r"[(](\d+) repaired", hc))
         out["hazard_check"] = f"{hc.count('listing checked')} units checked, {fixed} pairs repaired"
     if out.get("rocprof_source"):
-        out["rocprof_source"] = out["rocprof_source"].replace("profiles/", "")
+        out["rocprof_source"] = out["rocprof_source"].replace("profiles/", "").split(" + per-dispatch trace")[0] + " (medians)"
     if "launch latency" in str(out.get("bound", "")):
         out["bound"] = "launch latency"
     return out
