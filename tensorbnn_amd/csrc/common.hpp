@@ -4,6 +4,10 @@
 #include <stdint.h>
 #include "../../include/tbnn.h"
 
+// a fused kernel's hidden activations as ONE int: a TBNN_ACT_* value (every hidden layer the same), or this flag + 3 bits per hidden layer
+// (kernels_fast.hpp: Shape::act; fused_ops.hpp)
+#define TBNN_ACT_PACKED 0x40000000
+
 #define TBNN_WAVE 64
 #define PSTAT_CAP 512                     // entries of the per-workgroup statistic buffer (tbnn_api.hip): >= the grid of every fused pass
 

@@ -42,7 +42,7 @@ static inline bool fused_ops_match(const FusedOps& o, const NetDev& nd) {
     if (o.nl != nd.nl || (nd.lik == TBNN_LIK_BERNOULLI) != (o.bern != 0)) return false;
     for (int l = 0; l < nd.nl; ++l) {
         if (nd.in[l] != o.dims[l] || nd.out[l] != o.dims[l + 1]) return false;
-        if (nd.act[l] != (l == nd.nl - 1 ? o.lact : o.hact)) return false;
+        if (nd.act[l] != (l == nd.nl - 1 ? o.lact : ((o.hact & TBNN_ACT_PACKED) ? (o.hact >> (3 * l)) & 7 : o.hact))) return false;
     }
     return true;
 }
@@ -52,9 +52,13 @@ static inline void fused_ops_shape(FusedOps* o, const char* prefix) {
     o->abi = TBNN_JIT_ABI;
     o->nl = S::NL;
     for (int i = 0; i <= S::NL; ++i) o->dims[i] = S::D[i];
-    o->hact = S::HACT; o->lact = S::LACT; o->bern = S::BERN ? 1 : 0;
-    static const char* an[] = {"none", "relu", "tanh", "sigmoid", "exp", "elu"};
-    int k = snprintf(o->name, sizeof(o->name), "%s<%s,%s%s;", prefix, an[S::HACT], an[S::LACT], S::BERN ? ",bernoulli" : "");
+    o->hact = S::HCODE; o->lact = S::LACT; o->bern = S::BERN ? 1 : 0;      // (hact: one activation, or the packed per-layer code: Shape)
+    static const char* an[] = {"none", "relu", "tanh", "sigmoid", "exp", "elu", "?", "?"};
+    int k = snprintf(o->name, sizeof(o->name), "%s<", prefix);
+    if (S::HCODE & TBNN_ACT_PACKED) {
+        for (int l = 0; l + 1 < S::NL && k < (int)sizeof(o->name) - 16; ++l) k += snprintf(o->name + k, sizeof(o->name) - k, l ? "+%s" : "%s", an[S::act(l) & 7]);
+    } else k += snprintf(o->name + k, sizeof(o->name) - k, "%s", an[S::HCODE & 7]);
+    k += snprintf(o->name + k, sizeof(o->name) - k, ",%s%s;", an[S::LACT], S::BERN ? ",bernoulli" : "");
     for (int i = 0; i <= S::NL && k < (int)sizeof(o->name) - 8; ++i) k += snprintf(o->name + k, sizeof(o->name) - k, i ? ",%d" : "%d", S::D[i]);
     snprintf(o->name + k, sizeof(o->name) - k, ">");
 }

@@ -32,13 +32,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // HACT: activation after every hidden layer, LACT: after the last layer,
 // BERN: Bernoulli likelihood (else the Gaussian family) -- all compile-time so
 // the tile body is one straight-line block the scheduler can interleave.
+// Round 6: network.add takes any sequence of layers and activations (tensorBNN/network.py:173-191) -- a stack whose hidden layers do NOT all
+// carry the same activation has HACT = TBNN_ACT_PACKED | sum_l act_l << 3 l (hidden layer l = 0 .. NL - 2; at most 9 of them: fused_ops.hpp,
+// jit.shape_of); the kernels ask act(l) per layer and never HACT itself.
 template <int HACT_, int LACT_, bool BERN_, int... Ds>
 struct Shape {
     static constexpr int NL = sizeof...(Ds) - 1;
     static constexpr int D[sizeof...(Ds)] = {Ds...};
-    static constexpr int HACT = HACT_, LACT = LACT_;
+    static constexpr int HCODE = HACT_, LACT = LACT_;
     static constexpr bool BERN = BERN_;
-    static constexpr int act(int l) { return l == NL - 1 ? LACT_ : HACT_; }
+    static_assert((HACT_ & TBNN_ACT_PACKED) == 0 || NL - 1 <= 9, "a packed activation code holds 9 hidden layers");
+    static constexpr int act(int l) { return l == NL - 1 ? LACT_ : ((HACT_ & TBNN_ACT_PACKED) ? (HACT_ >> (3 * l)) & 7 : HACT_); }
 };
 
 #ifndef TBNN_FAST_ACT

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
     // the opaque packed instructions (pkfma*: no hazard handling by the compiler) may read hidden activations only when those
     // come out of a plain VALU instruction: relu (v_max), tanh / elu (a select).  A raw MFMA result (no activation) or a
     // transcendental result (sigmoid: v_rcp, exp: v_exp) would need wait states nobody inserts
-    constexpr bool PKA = S::HACT == TBNN_ACT_RELU || S::HACT == TBNN_ACT_TANH || S::HACT == TBNN_ACT_ELU;
+    constexpr int ALAST = S::act(C::LL - 1);          // the activation in front of the last layer
+    constexpr bool PKA = ALAST == TBNN_ACT_RELU || ALAST == TBNN_ACT_TANH || ALAST == TBNN_ACT_ELU;
     static_assert(C::LDS_FLOATS * 4 + 64 <= 160 * 1024, "LDS budget");
     static_assert(C::IMG_FLOATS % 4 == 0 && C::WAVE_FLOATS % 4 == 0, "16-B addressable sections");
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(MID_THREADS, 1) __attribute__((amdgpu_waves_per_eu(
                     if constexpr (o == 0) { d01 = pkmul_bc<0>(f32x2{w[0], w[1]}, dd); d23 = pkmul_bc<0>(f32x2{w[2], w[3]}, dd); }
                     else { d01 = pkfma_bc<o>(f32x2{w[0], w[1]}, dd, d01); d23 = pkfma_bc<o>(f32x2{w[2], w[3]}, dd, d23); }
                 });
-                if constexpr (S::HACT != TBNN_ACT_NONE) dz[t] = actc_bwd_mul4<S::HACT, true>(f32x4{d01[0], d01[1], d23[0], d23[1]}, a[t]);
+                if constexpr (ALAST != TBNN_ACT_NONE) dz[t] = actc_bwd_mul4<ALAST, true>(f32x4{d01[0], d01[1], d23[0], d23[1]}, a[t]);
                 else dz[t] = f32x4{d01[0], d01[1], d23[0], d23[1]};
             }
         }

@@ -552,7 +552,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) T.a[t][r] = actc_fwd<S::act(0)>(acc[t][r]);
-            if constexpr (S::HACT == TBNN_ACT_RELU) relu_mask_make<S, MT>(T.relu[0], T.a);
+            if constexpr (S::act(0) == TBNN_ACT_RELU) relu_mask_make<S, MT>(T.relu[0], T.a);
         }
 
         WSTAMP(1);
@@ -605,8 +605,8 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) T.a[t][r] = actc_fwd<S::HACT>(acc[t][r]);
-            if constexpr (S::HACT == TBNN_ACT_RELU && l + 1 <= NM) relu_mask_make<S, MT>(T.relu[l], T.a);
+                for (int r = 0; r < 4; ++r) T.a[t][r] = actc_fwd<S::act(l)>(acc[t][r]);
+            if constexpr (S::act(l) == TBNN_ACT_RELU && l + 1 <= NM) relu_mask_make<S, MT>(T.relu[l], T.a);
         });
 
         WSTAMP(2);
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dz[t][r] = actc_bwd_mul<S::HACT>(d[r], T.a[t][r]);
+                for (int r = 0; r < 4; ++r) dz[t][r] = actc_bwd_mul<S::act(C::NL - 2)>(d[r], T.a[t][r]);
             }
         }
 
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             constexpr int MU = C::TR(l);
             // a_l (for act') comes back from the block this lane stored in the forward pass: nothing but the
             // current layer's operand stays in registers across the chain
-            constexpr bool RELU = S::HACT == TBNN_ACT_RELU;
+            constexpr bool RELU = S::act(l - 1) == TBNN_ACT_RELU;
             // issue the re-read three chunks before the end of the segment: short live range, latency still covered
             constexpr int KGB = C::KG(C::out(l)), KG_RELOAD = KGB > 3 ? KGB - 3 : 0;
             f32x4 arel[RELU ? 1 : MU];

@@ -64,8 +64,12 @@ def _sources_stamp() -> str:
     return h.hexdigest()
 
 
+ACT_PACKED = 0x40000000          # csrc/common.hpp: TBNN_ACT_PACKED
+
+
 def shape_of(layers: Sequence[tuple], likelihood: int):
-    """(dims, hact, lact, bern) or None when the fused kernels cannot express the network"""
+    """(dims, hact, lact, bern) or None when the fused kernels cannot express the network; hact: the hidden layers' activation, or the
+    packed per-layer code when they differ"""
     from . import _native as nat
     dims = [int(layers[0][0])] + [int(l[1]) for l in layers]
     acts = [int(l[2]) for l in layers]
@@ -73,7 +77,11 @@ def shape_of(layers: Sequence[tuple], likelihood: int):
         return None
     hact = acts[0]
     if any(a != hact for a in acts[:-1]):
-        return None
+        # hidden layers with different activations (network.add takes any sequence: tensorBNN/network.py:173-191): the packed per-layer
+        # code of csrc/kernels_fast.hpp (Shape::act), 3 bits per hidden layer, 9 layers at most
+        if len(acts) - 1 > 9 or any(not 0 <= a <= 7 for a in acts[:-1]):
+            return None
+        hact = ACT_PACKED | sum(a << (3 * l) for l, a in enumerate(acts[:-1]))
     return dims, hact, acts[-1], int(likelihood == nat.LIK_BERNOULLI)
 
 
@@ -178,7 +186,7 @@ def build(layers: Sequence[tuple], likelihood: int, verbose: bool = False) -> Op
     sh = shape_of(layers, likelihood)
     if sh is None:
         _warn_generic([int(layers[0][0])] + [int(l[1]) for l in layers],
-                      "the fused kernels need >= 2 dense layers with one activation for all hidden layers")
+                      "the fused kernels need >= 2 dense layers (and at most 9 hidden layers when their activations differ)")
         return None
     dims, hact, lact, bern = sh
     extra = os.environ.get("TBNN_JIT_FLAGS", "").split()          # diagnostic builds (-DTBNN_WPAD=8 ...); part of the cache key

@@ -3,7 +3,8 @@ generators of tools/experiments/{narrow,family,tall,transition}_fuzz.py with fix
 from MFMA hazard pairs; all found by those fuzzers, none by the suite as it stood).  __graft_entry__.build() compiles the run-time instantiations of
 every case here (tensorbnn_amd/jit.prebuild), so that the GPU run finds them built and checked.
 
-A case: dict(family, dims, n, act, lik, prior, skip) -- `skip` is the TBNN_JIT_SKIP that makes the family named take the shape."""
+A case: dict(family, dims, n, act, acts, lik, prior, skip) -- `skip` is the TBNN_JIT_SKIP that makes the family named take the shape; `acts`: None
+(every hidden layer carries `act`) or one activation per hidden layer."""
 import os
 
 import numpy as np
@@ -73,7 +74,12 @@ def cases(per_family: int = None, seed: int = None):
             work = sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1)) * n
             if work > 1.5e9:                                   # (the fp64 oracle's time)
                 n = max(16, int(n * 1.5e9 / work))
-            out.append(dict(family=fam, dims=dims, n=n, act=act, lik=lik, prior=prior, skip=SKIP[fam]))
+            # hidden layers with different activations (round 6: the fused kernels take them; drawn LAST, so the other fields are round 6's)
+            acts = None
+            if len(dims) - 2 >= 2 and rng.random() < 0.35:
+                acts = [int(a) for a in rng.choice([ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_ELU, ACT_NONE], size=len(dims) - 2)]
+                acts = acts if len(set(acts)) > 1 else None
+            out.append(dict(family=fam, dims=dims, n=n, act=act, acts=acts, lik=lik, prior=prior, skip=SKIP[fam]))
             got += 1
     rng = np.random.default_rng(seed + 99)
     for fam, dims in REGRESSIONS:
@@ -110,7 +116,8 @@ def transition_cases(count: int = None, seed: int = None):
 def layers_of(case):
     d = case["dims"]
     last = ACT_SIGMOID if case["lik"] == LIK_BERNOULLI else ACT_NONE
-    return [(d[i], d[i + 1], case["act"] if i < len(d) - 2 else last, case["prior"]) for i in range(len(d) - 1)]
+    acts = case.get("acts") or [case["act"]] * (len(d) - 2)
+    return [(d[i], d[i + 1], acts[i] if i < len(d) - 2 else last, case["prior"]) for i in range(len(d) - 1)]
 
 
 def jit_jobs():

@@ -19,11 +19,14 @@ TRANS = fz.transition_cases()
 
 
 def _id(c):
-    return f"{c['family']}-{'x'.join(map(str, c['dims']))}-n{c['n']}-a{c['act']}l{c['lik']}p{c['prior']}"
+    a = "".join(map(str, c["acts"])) if c.get("acts") else c["act"]
+    return f"{c['family']}-{'x'.join(map(str, c['dims']))}-n{c['n']}-a{a}l{c['lik']}p{c['prior']}"
 
 
 def _problem(c):
     spec, X, Y, theta, eta = o.synth_problem(c["dims"], c["n"], c["act"], c["prior"], c["lik"])
+    for l, a in zip(spec.layers[:-1], c.get("acts") or []):                # one activation per hidden layer (the data stay the uniform teacher's)
+        l.act = a
     if c["dims"][0] > 64:
         X = (X / np.sqrt(c["dims"][0] / 16.0)).astype(np.float32)          # keep a long fan-in's pre-activations O(1)
     if c["lik"] == o.LIK_BERNOULLI:
@@ -104,7 +107,7 @@ def test_value_gradient_forward_vs_fp64_and_repeatable(native, family_env, c):
         d32 = max(np.abs(g32[a:b] - g64[a:b]).max() / max(np.abs(g64[a:b]).max(), 1e-3) for a, b in blocks)
         ok = e_g32 <= max(3e-6, 0.02 * d32) and e_lp32 <= 4e-6 and e_f <= 1e-4
         why = f"fp32 oracle {d32:.1e} from fp64, kernel {e_g32:.1e} from the fp32 oracle"
-    if not ok and c["act"] == o.ACT_RELU:
+    if not ok and o.ACT_RELU in (c.get("acts") or [c["act"]]):
         kk = _relu_kink(spec, theta, X)
         ok = kk < 3e-6 and e_lp <= 4e-6 and e_f <= 1e-4 and e_g <= 20.0 / max(c["n"], 1)
         why += f"; relu pre-activation within {kk:.1e} of 0"

@@ -163,13 +163,13 @@ def test_jit_second_cooperative_tile_keeps_every_register(native, monkeypatch, e
 
 
 def test_jit_unsupported_shape_falls_back(native):
-    """mixed hidden activations: no fused family -> AUTO runs on the layered MFMA kernels (TBNN_LAYERED=0: the thread-per-row
-    kernel), FAST fails loudly"""
-    layers = [(4, 8, native.ACT_RELU, native.PRIOR_CAUCHY), (8, 8, native.ACT_TANH, native.PRIOR_CAUCHY),
-              (8, 1, native.ACT_NONE, native.PRIOR_CAUCHY)]
+    """no fused family for this stack (ten hidden layers with alternating activations: the packed per-layer code holds nine; mixed activations
+    as such run on the fused kernels since round 6, tests/test_gpu_mixedact.py) -> AUTO runs on the layered MFMA kernels, FAST fails loudly"""
+    acts = [native.ACT_RELU, native.ACT_TANH] * 5
+    layers = [(4, 8, acts[0], native.PRIOR_CAUCHY)] + [(8, 8, a, native.PRIOR_CAUCHY) for a in acts[1:]] + [(8, 1, native.ACT_NONE, native.PRIOR_CAUCHY)]
     assert jit.shape_of(layers, native.LIK_GAUSSIAN) is None
     ch = native.Chain(layers, kernel=native.KERNEL_AUTO, jit=True)
-    assert ch.kernel_name == "layered<4,8,8,1>"
+    assert ch.kernel_name == "layered<4," + "8," * 10 + "1>"
     ch.close()
     with pytest.raises(native.TbnnError):
         native.Chain(layers, kernel=native.KERNEL_FAST, jit=True)

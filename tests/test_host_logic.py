@@ -232,7 +232,14 @@ def test_jit_family_choice_and_source():
     assert "Shape<1, 3, true, 8, 64, 48, 2>" in src and "JitWide<S>::fill" in src and "tbnn_jit_ops" in src
     assert "JitMid<S>::fill" in jit.source(dims, hact, lact, bern, "mid")
     mixed = [(4, 8, nat.ACT_RELU, 0), (8, 8, nat.ACT_TANH, 0), (8, 1, nat.ACT_NONE, 0)]
-    assert jit.shape_of(mixed, nat.LIK_GAUSSIAN) is None
+    # hidden layers with different activations (round 6): the packed per-layer code, 3 bits per hidden layer (csrc/kernels_fast.hpp: Shape::act)
+    dims, hact, lact, bern = jit.shape_of(mixed, nat.LIK_GAUSSIAN)
+    assert hact == jit.ACT_PACKED | nat.ACT_RELU | (nat.ACT_TANH << 3) and lact == nat.ACT_NONE
+    assert f"Shape<{hact}, 0, false, 4, 8, 8, 1>" in jit.source(dims, hact, lact, bern, "fast3")
+    same = [(4, 8, nat.ACT_TANH, 0), (8, 8, nat.ACT_TANH, 0), (8, 1, nat.ACT_NONE, 0)]
+    assert jit.shape_of(same, nat.LIK_GAUSSIAN)[1] == nat.ACT_TANH          # one activation: the plain code, the kernels of every round before
+    deep = [(4, 8, nat.ACT_RELU if i % 2 else nat.ACT_TANH, 0) for i in range(1)] + [(8, 8, nat.ACT_RELU if i % 2 else nat.ACT_TANH, 0) for i in range(9)] + [(8, 1, 0, 0)]
+    assert jit.shape_of(deep, nat.LIK_GAUSSIAN) is None                     # 10 hidden layers with mixed activations: the layered family
 
 
 def test_predictor_reweight_without_likelihood(tmp_path):
