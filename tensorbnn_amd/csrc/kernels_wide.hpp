@@ -91,10 +91,14 @@ struct WideCfg {
     static constexpr int out(int l) { return S::D[l + 1]; }
     static constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
     static constexpr int r4(int a) { return (a + 3) & ~3; }
-    static constexpr int NM = NL - 2;                 // middle layers 1 .. NM
-    static constexpr int LL = NL - 1;                 // last layer (VALU)
+    static constexpr int LL = NL - 1;                 // last layer
     static constexpr int d_in = in(0), d_out = out(LL);
-    static_assert(d_out <= 2, "last layer runs on the VALU (<= 2 outputs)");
+    // <= 2 outputs: the last layer runs on the VALU.  3 .. 16 outputs (round 6; network.add takes any stack, tensorBNN/network.py:173-191, the
+    // likelihoods sum over [d_out, n], likelihood.py:88-94, 226-236): the last layer is one more MIDDLE layer -- its weights two more segments of
+    // the stream, ONE output tile, the likelihood read off the tile, a_LL / delta_LL stored for k_dw_wide like every middle layer's
+    static constexpr bool VL = d_out <= 2;
+    static constexpr int NM = VL ? NL - 2 : NL - 1;   // middle layers 1 .. NM
+    static_assert(d_out <= 16, "the last layer is one output tile at most");
     // a_l = input of layer l (l = 1..LL): in(l) real units + the ones pseudo-unit, in the padded slot order of
     // kernels_fast.hpp (slot_of / unit_of / ones_slot: identity on full 16-unit groups, the last partial group
     // spread over the lane groups first so that it needs only ceil(rem/4) MFMA k-steps)
@@ -104,7 +108,7 @@ struct WideCfg {
     static constexpr int KG(int K) { return cdiv(K, 16); }
     static constexpr int aroff(int l) { int o = 0; for (int m = 1; m < l; ++m) o += TR(m); return o; }   // a_l in the register file
     static constexpr int ACT_TILES = aroff(LL + 1);
-    static constexpr int maxT() { int m = 0; for (int l = 1; l <= LL; ++l) m = TR(l) > m ? TR(l) : m; return m; }
+    static constexpr int maxT() { int m = 0; for (int l = 1; l <= (VL ? LL : NL); ++l) m = TR(l) > m ? TR(l) : m; return m; }
     static constexpr int MAXT = maxT();
     // layer 0
     static constexpr int KG0 = KG(d_in), NT0 = cdiv(d_in + 1, 16), MT0 = TR(1);
@@ -113,10 +117,10 @@ struct WideCfg {
     static constexpr int W0_OFF = 0;
     static constexpr int W0_FLOATS = MT0 * KG0 * 256;
     static constexpr int boff(int l) { int o = W0_OFF + W0_FLOATS; for (int m = 0; m < l; ++m) o += 16 * TR(m + 1); return o; }   // bias of layer l <= NM
-    static constexpr int WLP = 16 * TR(LL);                                   // pitch of W_LL rows
+    static constexpr int WLP = VL ? 16 * TR(LL) : 0;                          // pitch of W_LL rows (the VALU last layer's own image)
     static constexpr int WL_OFF = boff(NM + 1);
     static constexpr int BL_OFF = WL_OFF + d_out * WLP;
-    static constexpr int PERM_FLOATS = r4(BL_OFF + d_out);
+    static constexpr int PERM_FLOATS = r4(BL_OFF + (VL ? d_out : 0));
     // ---- the weight stream: chunks of one k-group each.  Segment order F(1)..F(NM), B(NM)..B(1).
     //   F(l) chunk kg: granule t < TR(l+1): lane (i, g) holds W_l[16t+i][16kg+4g+s], s = 0..3
     //   B(l) chunk kg: granule u < TR(l)  : lane (i, g) holds W_l[16kg+4g+s][16u+i]
@@ -177,7 +181,7 @@ struct WideCfg {
     static constexpr int P() { return offW(NL); }
     // compact slab of k_chain_wide: [layer 0 params][last layer params]
     static constexpr int SA_L0 = 0, SA_LL = in(0) * out(0) + out(0);
-    static constexpr int SA_FLOATS = r4(SA_LL + in(LL) * d_out + d_out);
+    static constexpr int SA_FLOATS = r4(SA_LL + (VL ? in(LL) * d_out + d_out : 0));
     // ---- HBM activation / delta arrays (per middle layer l): blocks [row tile][tile][16 rows][16 slots]
     static constexpr int TZ(int l) { return TR(l + 1); }        // tiles of delta_l (outputs of layer l)
     static constexpr long act_off(int l, long ntiles) { long o = 0; for (int m = 1; m < l; ++m) o += ntiles * (TA(m) + TZ(m)) * 256; return o; }   // a_l
@@ -195,7 +199,16 @@ struct WideCfg {
     static constexpr int DW_NGW = cdiv(maxSB(), WIDE_WAVES);
     static constexpr int slabB_off(int l) { int o = 0; for (int m = 1; m < l; ++m) o += r4(in(m) * out(m) + out(m)); return o; }   // within one WG's slab
     static constexpr int SB_FLOATS = slabB_off(NM + 1);
-    static constexpr long dw_cost(int l) { return (long)DWT(l); }
+#ifndef WIDE_LL_COST8
+#define WIDE_LL_COST8 4          // eighths of a tile per stored block (dw_cost)
+#endif
+#ifndef WIDE_DW_G
+#define WIDE_DW_G 2              // row tiles whose operands a wave of the one-tile layer requests at once (two such groups in flight)
+#endif
+    // share of k_dw_wide's workgroups: by MFMA count -- but the one-tile last layer of a 3 .. 16-output network (QM = 0: a few pair MFMAs per row
+    // tile behind TA + 1 block loads) is bound by its loads: priced by its blocks (10 -> 200 -> 200 -> 10 at 1e5 rows, k_dw_wide: 267 us with the MFMA
+    // count alone, the last layer's 8 % of the workgroups being the long pole)
+    static constexpr long dw_cost(int l) { return (!VL && l == LL) ? (DWT(l) > WIDE_LL_COST8 * SB(l) / 8 ? DWT(l) : WIDE_LL_COST8 * SB(l) / 8) : (long)DWT(l); }
     // k_dw_wide workgroups per CU: a wave that owns few accumulator tiles (configs[4]: 13 tiles, 52 MFMAs between two
     // barriers) leaves the MFMA pipe idle at every barrier / LDS round trip; a second resident workgroup fills it when
     // two rings fit in LDS and two waves fit in a SIMD's registers
@@ -475,16 +488,20 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
     f32x4 dW0[C::DW0_TILES];
 #pragma unroll
     for (int t = 0; t < C::DW0_TILES; ++t) dW0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 accL[d_out][C::TR(LL)];
-    float accbL[d_out];
+    // (the VALU last layer's per-lane partial sums; nothing when the last layer is an MFMA layer)
+    constexpr int LRO = C::VL ? d_out : 1, LRT = C::VL ? C::TR(LL) : 1;
+    f32x4 accL[LRO][LRT];
+    float accbL[LRO];
 #pragma unroll
-    for (int o = 0; o < d_out; ++o) {
+    for (int o = 0; o < LRO; ++o) {
         accbL[o] = 0.f;
 #pragma unroll
-        for (int t = 0; t < C::TR(LL); ++t) accL[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < LRT; ++t) accL[o][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    float xn[C::KG0 * 4], yn[d_out];
+    // targets of a row: <= 2 outputs: y[o] in every lane group; else the D layout of the output tile (lane (row, g): slots 4g .. 4g + 3)
+    constexpr int YN = C::VL ? d_out : 4;
+    float xn[C::KG0 * 4], yn[YN];
     auto fetch = [&](long tile) {
         const long row = tile * 16 + i16;
         const bool ok = tile < ntiles && row < n;
@@ -494,7 +511,10 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             xn[k] = (ok && u >= 0) ? X[row * d_in + u] : 0.f;
         }
 #pragma unroll
-        for (int o = 0; o < d_out; ++o) yn[o] = (!FWD && ok) ? Y[row * d_out + o] : 0.f;
+        for (int o = 0; o < YN; ++o) {
+            const int u = C::VL ? o : unit_of(d_out, 4 * g + o, false);
+            yn[o] = (!FWD && ok && u >= 0) ? Y[row * d_out + u] : 0.f;
+        }
     };
     fetch((long)blockIdx.x * WIDE_WAVES + wave);
     int base = 0;                                              // ring slot of chunk 0 of the current block
@@ -519,11 +539,11 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
 #endif
         const bool rvalid = tile * 16 + i16 < n;
         WideRegs<S> T;
-        float y[d_out];
+        float y[YN];
 #pragma unroll
         for (int k = 0; k < C::KG0 * 4; ++k) T.x[k] = xn[k];
 #pragma unroll
-        for (int o = 0; o < d_out; ++o) y[o] = yn[o];
+        for (int o = 0; o < YN; ++o) y[o] = yn[o];
         fetch((blk + gridDim.x) * WIDE_WAVES + wave);
         // x image for dW_0 (slots < d_in only: the ones column stays)
 #pragma unroll
@@ -612,7 +632,25 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
         WSTAMP(2);
         // ---- last layer on the VALU: f_o = b_o + sum_u W[o][u] a_LL[u]
         f32x4 dz[C::MAXT];
-        {
+        if constexpr (!C::VL) {
+            // MFMA last layer: T.a[0] is the output tile (lane (row i16, g): slots 4g .. 4g + 3); the likelihood reads it, every (row, output)
+            // element once, and delta_LL (w.r.t. the pre-activation) stands in the D layout the delta chain starts from
+            if constexpr (FWD) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int u = unit_of(d_out, 4 * g + r, false);
+                    if (rvalid && u >= 0) fout[(size_t)u * n + tile * 16 + i16] = T.a[0][r];      // [d_out][n]
+                }
+                base = (base + C::NCHF) & (WIDE_RING - 1);
+                continue;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int u = unit_of(d_out, 4 * g + r, false);
+                    dz[0][r] = (rvalid && u >= 0) ? lik_delta<S>(T.a[0][r], y[r], inv_var, true, stat) : 0.f;
+                }
+            }
+        } else {
             constexpr int TP = C::TR(LL);
             float dzl[d_out];
 #pragma unroll
@@ -793,7 +831,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) __attribute__((amdgpu_waves_per_eu
             __syncthreads();
         }
     }
-    {
+    if constexpr (C::VL) {
         // last layer: reduce the per-row partials over the 16 lanes of a lane group, then over the 4 waves
         constexpr int TP = C::TR(LL), inL = C::in(LL);
         float* lb = lds;                               // [wave][o][slot], then [wave][o] biases
@@ -880,6 +918,42 @@ __device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, l
         for (int e = wave * 64 + lane; e < np; e += WIDE_THREADS) slab[e] = 0.f;
         return;
     }
+    if constexpr (QM == 0) {
+        // A layer with NO whole M tile per wave -- the one-tile last layer of a network with 3 .. 16 outputs (round 6): QP <= 4 (m, u) pairs per
+        // wave and row tile, i.e. 16 MFMAs behind two block loads each.  Walked like the layers below (one row tile ahead) the loop runs at the
+        // load latency (10 -> 200 -> 200 -> 10 at 1e5 rows: k_dw_wide 267 us against 80 us for the same network with one output); here a wave
+        // asks for the operands of WIDE_DW_G row tiles at once, two such groups in flight, and reads only the blocks of its own pairs.
+        constexpr int G = WIDE_DW_G;
+        f32x4 Ag0[G][QPd], Bg0[G][QPd], Ag1[G][QPd], Bg1[G][QPd];
+        auto loadg = [&](long rt, f32x4 (&Ag)[G][QPd], f32x4 (&Bg)[G][QPd]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const long r = rt + i < rt1 ? rt + i : rt1 - 1;        // (clamped: a group past the end is loaded and not used)
+                const __amdgpu_buffer_rsrc_t rz = rsz(r), ra = rsa(r);
+#pragma unroll
+                for (int q = 0; q < QP; ++q) { Ag[i][q] = ld(rz, pm[q]); Bg[i][q] = ld(ra, pu[q]); }
+            }
+        };
+        auto mmg = [&](long rt, const f32x4 (&Ag)[G][QPd], const f32x4 (&Bg)[G][QPd]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                if (rt + i < rt1) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int q = 0; q < QP; ++q) mfma16_acc<false>(acc[q], Ag[i][q][s], Bg[i][q][s]);
+                }
+        };
+        loadg(rt0, Ag0, Bg0);
+        for (long rt = rt0; rt < rt1; rt += 2 * G) {
+            loadg(rt + G, Ag1, Bg1);
+            WIDE_FENCE();
+            mmg(rt, Ag0, Bg0);
+            loadg(rt + 2 * G, Ag0, Bg0);
+            WIDE_FENCE();
+            mmg(rt + G, Ag1, Bg1);
+        }
+    } else {
     // operand registers: B[u] = a-block u (refreshed in place), A = delta blocks of this wave's M tiles {w, w+4, ..}, Z = the
     // RM left-over delta blocks (their (m, u) pairs are dealt over the waves: pair p = u + k TA belongs to wave p % 4, its
     // accumulator is number p / 4 of that wave's left-over set -- all compile-time once the wave is known, so the pair MFMAs
@@ -969,6 +1043,7 @@ __device__ __forceinline__ void dw_wide_layer(const float* __restrict__ store, l
         body(rt, A0, Z0, A1, Z1);
         if (rt + 1 < rt1) body(rt + 1, A1, Z1, A0, Z0);
         else break;
+    }
     }
     mfma_drain_acc(acc);
     // write-out in theta order: D layout lane (n = lane & 15, g) reg j = dW[out 16m+4g+j][in 16u+n]
@@ -1140,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_reduce_wide(WideDwArgs args, const floa
         const int k = j - C::offW(l);
         const float* src; int cnt; size_t pitch;
         if (l == 0) { src = slabA + C::SA_L0 + k; cnt = nA; pitch = C::SA_FLOATS; }
-        else if (l == C::LL) { src = slabA + C::SA_LL + k; cnt = nA; pitch = C::SA_FLOATS; }
+        else if (C::VL && l == C::LL) { src = slabA + C::SA_LL + k; cnt = nA; pitch = C::SA_FLOATS; }
         else { src = slabB + (size_t)args.wg_lo[l - 1] * C::SB_FLOATS + C::slabB_off(l) + k; cnt = args.wg_lo[l] - args.wg_lo[l - 1]; pitch = C::SB_FLOATS; }
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int w = y;
@@ -1170,7 +1245,7 @@ static void wide_image_map(int* map) {
                 int m0, m1 = -1;
                 if (l == 0) {
                     m0 = C::W0_OFF + (((ri / 16) * C::KG0 + ck / 16) * 64 + ((ck % 16) / 4) * 16 + ri % 16) * 4 + ck % 4;
-                } else if (l == C::LL) {
+                } else if (C::VL && l == C::LL) {
                     m0 = C::WL_OFF + i * C::WLP + ck;
                 } else {
                     m0 = C::gran_off(C::cF(l) + ck / 16, ri / 16) + (((ck % 16) / 4) * 16 + ri % 16) * 4 + ck % 4;
@@ -1179,7 +1254,7 @@ static void wide_image_map(int* map) {
                 map[ow + i * in + k] = m0;
                 map[P + ow + i * in + k] = m1;
             }
-            map[ow + in * out + i] = l == C::LL ? C::BL_OFF + i : C::boff(l) + ri;
+            map[ow + in * out + i] = (C::VL && l == C::LL) ? C::BL_OFF + i : C::boff(l) + ri;
             map[P + ow + in * out + i] = -1;
         }
     }

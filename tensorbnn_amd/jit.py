@@ -98,7 +98,7 @@ def families(dims) -> list:
         out.append("mid")
     if nl >= 2 and dims[-1] <= 16 and dims[0] > 32 and tall_fits(dims):
         out.append("tall")
-    if nl >= 3 and dims[-1] <= 2 and dims[0] <= 32 and max(dims[1:-1]) <= 256:
+    if nl >= 3 and dims[-1] <= 16 and dims[0] <= 32 and max(dims[1:-1]) <= 256:      # (3 .. 16 outputs: the last layer as one more middle layer, round 6)
         out.append("wide")
     skip = {f for f in os.environ.get("TBNN_JIT_SKIP", "").split(",") if f}      # diagnostic / tests: e.g. "mid" forces the wide path
     return [f for f in out if f not in skip]

@@ -60,6 +60,10 @@ WORKLOADS = {
     "mc10": dict(dims=[784, 100, 100, 10], n=12_000, L=20, lik=nat.LIK_BERNOULLI, hyper=False, steps=10, warmup=2, x_scale=1.0 / 28.0,
                  text="784->100->100->10 Relu/Sigmoid BNN (Cauchy DenseLayer, BernoulliLikelihood over 10 outputs), 12k pixel-like fp32 synthetic rows, "
                       "L=20 leapfrog, 1 chain per GPU"),
+    # round 6: a network with MORE THAN TWO outputs on the wide family (its last layer one more streamed middle layer): configs[3]'s widths, ten classes
+    "wm10": dict(dims=[10, 200, 200, 10], n=100_000, L=20, lik=nat.LIK_BERNOULLI, hyper=False, steps=10, warmup=2,
+                 text="10->200->200->10 Relu/Sigmoid BNN (Cauchy DenseLayer, BernoulliLikelihood over 10 outputs), 100k-row fp32 synthetic classification, "
+                      "L=20 leapfrog, 1 chain per GPU"),
 }
 for _w in WORKLOADS.values():
     _w.setdefault("prior", nat.PRIOR_CAUCHY)

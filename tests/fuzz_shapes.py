@@ -25,7 +25,8 @@ REGRESSIONS = [("narrow", [7, 17, 33, 2]), ("wide", [15, 170, 114, 1]), ("mid", 
 UNBUILDABLE = {("tall", (362, 49, 64, 1)): "k_fwd_bwd_tall spills (32 bytes per lane): refused by the build, the layered family takes it",
                ("tall", (525, 39, 64, 22, 2)): "k_fwd_bwd_tall spills (432 bytes per lane)",
                ("wide", (19, 148, 191, 1)): "k_dw_wide spills (164 bytes per lane)",
-               ("wide", (26, 234, 229, 115, 1)): "k_dw_wide spills (140 bytes per lane)"}
+               ("wide", (26, 234, 229, 115, 1)): "k_dw_wide spills (140 bytes per lane)",
+               ("wide", (26, 234, 229, 115, 2)): "k_dw_wide spills (the same widths with two outputs: the wide shapes draw 1 .. 16 outputs since late round 6)"}
 
 
 def _families(dims):
@@ -46,7 +47,7 @@ def _dims(rng, fam):
     if fam == "tall":
         return [int(rng.integers(33, 1000))] + [_edge(rng, 3, 64) for _ in range(int(rng.integers(1, 4)))] + [int(rng.integers(1, 3))]
     if fam == "wide":
-        return [_edge(rng, 1, 32)] + [_edge(rng, 65, 256) for _ in range(int(rng.integers(2, 4)))] + [int(rng.integers(1, 3))]
+        return [_edge(rng, 1, 32)] + [_edge(rng, 65, 256) for _ in range(int(rng.integers(2, 4)))] + [int(rng.choice([1, 2, 2, 3, 5, 10, 16]))]     # (3 .. 16 outputs: round 6, late)
     return [_edge(rng, 1, 600)] + [_edge(rng, 2, 300) for _ in range(int(rng.integers(1, 4)))] + [int(rng.choice([1, 2, 3, 5, 10, 17]))]
 
 

@@ -5,7 +5,7 @@
 #   tools/collect_profiles.sh r04a
 T=$1
 S=gpurun_out/$T
-for W in c2 c4 c5 mn w300 mc10; do
+for W in c2 c4 c5 mn w300 mc10 wm10; do
   [ -f $S/${W}_kernel_stats.csv ] && cp $S/${W}_kernel_stats.csv profiles/${T}_${W}_kernel_stats.csv
   [ -f $S/${W}_pmc_summary.json ] && cp $S/${W}_pmc_summary.json profiles/${T}_${W}_pmc_summary.json
   [ -f $S/trace_$W.log ] && grep '^{"metric"' $S/trace_$W.log | tail -1 > profiles/${T}_${W}_bench_line_under_rocprof.json
