@@ -18,9 +18,10 @@ runs on the layered kernels):
   * tall (`k_fwd_bwd_tall`): a long first-layer fan-in (33 .. a few thousand columns) in front of narrow hidden layers
     (<= 64 units), <= 16 outputs (3 .. 16: the last layer is an MFMA layer too): the fan-in split over the four waves of a workgroup, W_0 and dW_0 in registers
     (`tall_fits`) -- the reference's MNIST example 784 -> 20 -> 20 -> 1;
-  * wide (`k_chain_wide` + `k_dw_wide`): >= 3 dense layers, <= 2 outputs, fan-in <= 32,
+  * wide (`k_chain_wide` + `k_dw_wide`): >= 3 dense layers, <= 16 outputs (3 .. 16: the last layer is one more streamed middle layer), fan-in <= 32,
     hidden widths <= 256.
-Requirements common to both: one activation for all hidden layers; dense layers only.
+Requirements common to all: dense layers only; hidden layers that do not all carry the same activation get a packed per-layer code (`shape_of`), nine
+hidden layers at most.
 """
 import hashlib
 import os
