@@ -9,8 +9,8 @@ that `Chain(..., kernel=KERNEL_AUTO)` runs on a FUSED kernel instead of the laye
 (The reference gets there through tf.function tracing + XLA, network.py:359-362; here the kernels
 are hand-written and only their *shape parameters* are bound at run time.)
 
-Family choice (first that compiles wins; a shape no family accepts is remembered as `.fail` and
-runs on the layered kernels):
+Family choice (first that compiles wins, in the order below -- except that a narrow network with 3 .. 16 outputs tries mid first: `families`; a shape
+no family accepts is remembered as `.fail` and runs on the layered kernels):
   * narrow (`k_fwd_bwd_fast3`, else `k_fwd_bwd_fast`): every dW accumulator in one wave's registers --
     fan-in <= 16, at most NARROW_TILES 16x16 dW tiles in total;
   * mid (`k_fwd_bwd_mid`): >= 3 dense layers, <= 16 outputs (3 .. 16: the last layer is an MFMA layer too), fan-in <= 128, at most 63 dW tiles over the MFMA
@@ -91,11 +91,18 @@ def families(dims) -> list:
     nl = len(dims) - 1
     out = []
     tiles = sum(_cdiv(dims[l + 1], 16) * _cdiv(dims[l] + 1, 16) for l in range(nl))
-    if dims[0] <= 16 and tiles <= NARROW_TILES and max(dims) <= 64:
+    narrow = dims[0] <= 16 and tiles <= NARROW_TILES and max(dims) <= 64
+    mid = nl >= 3 and dims[-1] <= 16 and dims[0] <= MID_MAX_FANIN and mid_fits(dims)
+    # 3 .. 16 outputs on a narrow network: fast3 does not take them, and the mid-width kernel (MFMA last layer, round 6) measures 7 - 13 % ahead of
+    # k_fwd_bwd_fast there (5 -> 50 -> 50 -> 50 -> 3 at 1e5 rows 65.3 against 70.4 us per step, 8 -> 40 -> 40 -> 10 34.8 against 39.8): mid first
+    mid_first = narrow and mid and dims[-1] > 2
+    if mid_first:
+        out.append("mid")
+    if narrow:
         if dims[-1] <= 2 and nl >= 2:
             out.append("fast3")
         out.append("fast")
-    if nl >= 3 and dims[-1] <= 16 and dims[0] <= MID_MAX_FANIN and mid_fits(dims):
+    if mid and not mid_first:
         out.append("mid")
     if nl >= 2 and dims[-1] <= 16 and dims[0] > 32 and tall_fits(dims):
         out.append("tall")

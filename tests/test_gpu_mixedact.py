@@ -19,7 +19,7 @@ CASES = {
     # dims, rows, hidden activations, prior, likelihood, family, kernel-name prefix
     "fast3_relu_tanh": ([5, 20, 24, 1], 3001, [R, T], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "narrow", "jit-fast3<relu+tanh,"),
     "fast3_three": ([5, 50, 50, 50, 1], 4000, [T, R, E], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "narrow", "jit-fast3<tanh+relu+elu,"),   # configs[1]'s dims
-    "fast_none_sigmoid": ([4, 17, 9, 3], 555, [N, S], o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN, "narrow", "jit-fast<none+sigmoid,"),               # MFMA last layer
+    "fast_none_sigmoid": ([4, 17, 9, 3], 555, [N, S], o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN, "fast", "jit-fast<none+sigmoid,"),                 # MFMA last layer
     "mid_tanh_relu": ([20, 64, 64, 2], 5000, [T, R], o.PRIOR_CAUCHY, o.LIK_BERNOULLI, "mid", "jit-mid<tanh+relu,"),
     "mid_relu_sigmoid_elu": ([12, 40, 33, 48, 5], 1234, [R, S, E], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "mid", "jit-mid<relu+sigmoid+elu,"),    # 5 outputs
     "tall_elu_sigmoid": ([100, 50, 50, 1], 3005, [E, S], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "tall", "jit-tall<elu+sigmoid,"),
@@ -27,7 +27,7 @@ CASES = {
     "wide_relu_sigmoid": ([10, 200, 120, 1], 4000 + 7, [R, S], o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "wide", "jit-wide<relu+sigmoid,"),
     "wide_tanh_relu_relu": ([8, 90, 130, 70, 2], 2000, [T, R, R], o.PRIOR_GAUSSIAN, o.LIK_BERNOULLI, "wide", "jit-wide<tanh+relu+relu,"),
 }
-SKIP = {"narrow": "", "mid": "fast3,fast,tall,wide", "tall": "fast3,fast,mid,wide", "wide": "fast3,fast,mid,tall"}
+SKIP = {"narrow": "", "fast": "mid,tall,wide", "mid": "fast3,fast,tall,wide", "tall": "fast3,fast,mid,wide", "wide": "fast3,fast,mid,tall"}
 
 
 def named(kernel_name, prefix):
