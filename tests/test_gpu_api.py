@@ -240,7 +240,7 @@ def test_bench_more_ranks_than_gpus_fails_fast():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout), r.stderr[-500:]
-    assert time.time() - t0 < 30
+    assert time.time() - t0 < 120          # (seconds of work; the bound leaves room for a first `import torch` on a cold box)
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
