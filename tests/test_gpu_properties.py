@@ -21,6 +21,10 @@ CASES = {
     "configs[3] wide": ([10, 200, 200, 200, 1], 1_000_000, o.LIK_GAUSSIAN, "wide<", 4e-6, 4),
     "mnist tall": ([784, 20, 20, 1], 12_000, o.LIK_BERNOULLI, "tall<", 2e-4, 8),
     "layered": ([8, 300, 300, 1], 50_000, o.LIK_GAUSSIAN, "layered<", 1e-5, 4),
+    # round 6: networks with ten outputs on the three fused families that take them (run-time instantiations; the last layer an MFMA layer)
+    "ten outputs wide": ([10, 200, 200, 10], 100_000, o.LIK_BERNOULLI, "jit-wide<", 1e-5, 4),
+    "ten outputs mid": ([30, 80, 80, 10], 100_000, o.LIK_BERNOULLI, "jit-mid<", 2e-5, 6),
+    "ten outputs tall": ([784, 20, 20, 10], 60_000, o.LIK_BERNOULLI, "jit-tall<", 1e-4, 6),
 }
 
 
@@ -31,7 +35,7 @@ def test_time_reversal_full_size(native, case):
     if dims[0] > 100:
         X = (np.abs(X) / 28.0).astype(np.float32)             # pixel-like rows (as tests/test_gpu_tall.py)
     layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
-    ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, jit=False)
+    ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, jit=family.startswith("jit-"))
     assert family in ch.kernel_name, ch.kernel_name
     ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
     p0 = np.random.default_rng(11).standard_normal(spec.n_params).astype(np.float32)
@@ -69,7 +73,7 @@ def test_row_partition_additivity_full_size(native, case):
     if dims[0] > 100:
         X = (np.abs(X) / 28.0).astype(np.float32)
     layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
-    ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, jit=False)
+    ch = native.Chain(layers, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, jit=family.startswith("jit-"))
     assert family in ch.kernel_name, ch.kernel_name
 
     def ev(a, b):
