@@ -25,13 +25,23 @@ CASES = {
     "ten outputs wide": ([10, 200, 200, 10], 100_000, o.LIK_BERNOULLI, "jit-wide<", 1e-5, 4),
     "ten outputs mid": ([30, 80, 80, 10], 100_000, o.LIK_BERNOULLI, "jit-mid<", 2e-5, 6),
     "ten outputs tall": ([784, 20, 20, 10], 60_000, o.LIK_BERNOULLI, "jit-tall<", 1e-4, 6),
+    # ... and hidden layers with different activations at configs[1]'s size (the packed per-layer activation code)
+    "mixed activations narrow": ([5, 50, 50, 50, 1], 100_000, o.LIK_GAUSSIAN, "jit-fast3<tanh+relu+elu", 2e-5, 10),
 }
+MIXED = {"mixed activations narrow": [o.ACT_TANH, o.ACT_RELU, o.ACT_ELU]}
+
+
+def _spec_with_acts(case, spec):
+    for l, a in zip(spec.layers[:-1], MIXED.get(case, [])):
+        l.act = a
+    return spec
 
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_time_reversal_full_size(native, case):
     dims, n, lik, family, eps, L = CASES[case]
     spec, X, Y, theta, eta = o.synth_problem(dims, n, o.ACT_RELU, o.PRIOR_CAUCHY, lik)
+    spec = _spec_with_acts(case, spec)
     if dims[0] > 100:
         X = (np.abs(X) / 28.0).astype(np.float32)             # pixel-like rows (as tests/test_gpu_tall.py)
     layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
@@ -70,6 +80,7 @@ def test_row_partition_additivity_full_size(native, case):
     the per-workgroup slabs and their reduction at BASELINE's row counts."""
     dims, n, lik, family, eps, L = CASES[case]
     spec, X, Y, theta, eta = o.synth_problem(dims, n, o.ACT_RELU, o.PRIOR_CAUCHY, lik)
+    spec = _spec_with_acts(case, spec)
     if dims[0] > 100:
         X = (np.abs(X) / 28.0).astype(np.float32)
     layers = [(l.in_dim, l.out_dim, l.act, l.prior) for l in spec.layers]
