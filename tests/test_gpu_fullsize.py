@@ -40,7 +40,7 @@ def layers_of(spec):
 
 def check_full_size(native, dims, n, lik, eps, L, family):
     spec, X, Y, theta, eta = o.synth_problem(dims, n, o.ACT_RELU, o.PRIOR_CAUCHY, lik)
-    ch = native.Chain(layers_of(spec), likelihood=spec.likelihood)
+    ch = native.Chain(layers_of(spec), likelihood=spec.likelihood, jit=family.startswith("jit-"))
     assert ch.kernel_name.startswith(family), ch.kernel_name
     ch.set_data(X, Y); ch.set_state(theta); ch.set_hypers(eta)
     co = c_oracle.COracle(spec, X, Y)
@@ -71,6 +71,12 @@ def check_full_size(native, dims, n, lik, eps, L, family):
 def test_configs3_full_size_vs_c_restatement(native):
     """BASELINE configs[3]: 10->200->200->200->1, n = 1e6 on k_chain_wide + k_dw_wide"""
     check_full_size(native, [10, 200, 200, 200, 1], 1_000_000, o.LIK_GAUSSIAN, eps=1e-6, L=2, family="wide<")
+
+
+def test_ten_outputs_on_the_wide_family_full_size_vs_c_restatement(native):
+    """round 6: 10->200->200->10 + Sigmoid, BernoulliLikelihood over ten outputs, n = 1e5 (bench workload wm10) on k_chain_wide + k_dw_wide with the last
+    layer as one more streamed middle layer -- value, statistic, gradient per tensor and a three-step transition against oracle/c"""
+    check_full_size(native, [10, 200, 200, 10], 100_000, o.LIK_BERNOULLI, eps=2e-5, L=3, family="jit-wide<")
 
 
 def test_configs4_full_size_vs_c_restatement(native):
