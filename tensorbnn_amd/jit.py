@@ -15,7 +15,7 @@ no family accepts is remembered as `.fail` and runs on the layered kernels):
     fan-in <= 16, at most NARROW_TILES 16x16 dW tiles in total;
   * mid (`k_fwd_bwd_mid`): >= 3 dense layers, <= 16 outputs (3 .. 16: the last layer is an MFMA layer too), fan-in <= 128, at most 63 dW tiles over the MFMA
     layers and weight images + operand blocks within 160 KB of LDS (`mid_fits`): one fused kernel, nothing through HBM;
-  * tall (`k_fwd_bwd_tall`): a long first-layer fan-in (33 .. a few thousand columns) in front of narrow hidden layers
+  * tall (`k_fwd_bwd_tall`): a first-layer fan-in above the narrow family's 16 (.. a few thousand columns) in front of narrow hidden layers
     (<= 64 units), <= 16 outputs (3 .. 16: the last layer is an MFMA layer too): the fan-in split over the four waves of a workgroup, W_0 and dW_0 in registers
     (`tall_fits`) -- the reference's MNIST example 784 -> 20 -> 20 -> 1;
   * wide (`k_chain_wide` + `k_dw_wide`): >= 3 dense layers, <= 16 outputs (3 .. 16: the last layer is one more streamed middle layer), fan-in <= 32,
@@ -91,7 +91,10 @@ def families(dims) -> list:
     nl = len(dims) - 1
     out = []
     tiles = sum(_cdiv(dims[l + 1], 16) * _cdiv(dims[l] + 1, 16) for l in range(nl))
-    narrow = dims[0] <= 16 and tiles <= NARROW_TILES and max(dims) <= 64
+    # (widths: 64, the widest layer the hand-threaded dW phases of deeper networks were written and fuzzed for; a network with ONE hidden layer has
+    # none of those phases between two wide layers and instantiates up to 8 tiles = 128 units -- 1 -> 100 -> 1, the canonical BNN regression demo,
+    # ran on the layered family until late round 6: 73 us per step at 1e5 rows against 17 for 1 -> 64 -> 1)
+    narrow = dims[0] <= 16 and tiles <= NARROW_TILES and (max(dims) <= 64 or (nl == 2 and max(dims) <= 128))
     mid = nl >= 3 and dims[-1] <= 16 and dims[0] <= MID_MAX_FANIN and mid_fits(dims)
     # 3 .. 16 outputs on a narrow network: fast3 does not take them, and the mid-width kernel (MFMA last layer, round 6) measures 7 - 13 % ahead of
     # k_fwd_bwd_fast there (5 -> 50 -> 50 -> 50 -> 3 at 1e5 rows 65.3 against 70.4 us per step, 8 -> 40 -> 40 -> 10 34.8 against 39.8): mid first
@@ -104,7 +107,9 @@ def families(dims) -> list:
         out.append("fast")
     if mid and not mid_first:
         out.append("mid")
-    if nl >= 2 and dims[-1] <= 16 and dims[0] > 32 and tall_fits(dims):
+    # (fan-in 17 .. 32: behind mid / wide in the order, the tall kernel is what a ONE-hidden-layer network of that fan-in has -- the narrow family stops
+    # at 16 inputs, mid and wide need two hidden layers; late round 6, measured against the layered family)
+    if nl >= 2 and dims[-1] <= 16 and dims[0] > 16 and tall_fits(dims):
         out.append("tall")
     if nl >= 3 and dims[-1] <= 16 and dims[0] <= 32 and max(dims[1:-1]) <= 256:      # (3 .. 16 outputs: the last layer as one more middle layer, round 6)
         out.append("wide")

@@ -1,0 +1,132 @@
+"""GPU: networks with ONE hidden layer on fused kernels where they used to fall through to the layered family (late round 6): 65 .. 128 hidden units on
+the narrow kernels, and fan-in 17 .. 32 on the tall kernel (CASES below).  1 -> 100 -> 1 is the canonical BNN regression demo
+(the reference's Examples/trainRegression.py builds its networks with network.add, tensorBNN/network.py:173-191: any width); jit.families kept the narrow
+family to widths <= 64 -- the widest layer its hand-threaded dW phases between two hidden layers were fuzzed for -- and a one-hidden-layer network wider than
+that fell through every fused family (mid / wide need two hidden layers, tall a long fan-in) to the layered one: 73 us per leapfrog step at 1e5 rows, 29 us
+at 1,000 rows, against 17 / 8 for 1 -> 64 -> 1.  Such a network has no dW phase between two wide layers; the templates instantiate up to 8 tiles.
+Against the fp64 oracle through the C ABI: value, gradient per tensor, forward, every launch three times bit for bit; injected transitions with both
+decisions, a hyper transition, free-running epochs on the device's draws (oracle set back on the device's state each epoch)."""
+import numpy as np
+import pytest
+
+import tbnn_oracle as o
+from test_gpu_freerun import Tally, draws, layers_of, SEED
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # dims, rows, activation, prior, likelihood, kernel
+    "demo_1_100_1": ([1, 100, 1], 1000, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "jit-fast3<"),
+    "demo_1_100_1_many_rows": ([1, 100, 1], 40_000 + 3, o.ACT_TANH, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "jit-fast3<"),
+    "full_8_tiles": ([1, 128, 1], 777, o.ACT_TANH, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN, "jit-fast3<"),
+    "bern_8_100_2": ([8, 100, 2], 3001, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI, "jit-fast3<"),
+    "bern_16_128_2": ([16, 128, 2], 5000, o.ACT_ELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI, "jit-fast3<"),
+    "sigmoid_10_65_1": ([10, 65, 1], 2000, o.ACT_SIGMOID, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "jit-fast3<"),
+    "few_rows_2_113_1": ([2, 113, 1], 17, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "jit-fast3<"),
+    "seven_outputs": ([3, 100, 7], 1500, o.ACT_TANH, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "jit-fast<"),           # MFMA last layer: k_fwd_bwd_fast
+    "sixteen_outputs": ([5, 81, 16], 999, o.ACT_RELU, o.PRIOR_GAUSSIAN, o.LIK_BERNOULLI, "jit-fast<"),
+    # fan-in 17 .. 32 in front of ONE hidden layer (<= 64 units): beyond the narrow family's 16 inputs, and mid / wide need two hidden layers -- the tall
+    # kernel takes them since late round 6 (it was reserved for fan-in above 32): 14 against 33 us per step at 1,000 rows, 43 against 63 at 1e5
+    "fanin_20_50_1": ([20, 50, 1], 1000, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "jit-tall<"),
+    "fanin_24_64_2": ([24, 64, 2], 3000 + 5, o.ACT_TANH, o.PRIOR_CAUCHY, o.LIK_BERNOULLI, "jit-tall<"),
+    "fanin_30_40_5": ([30, 40, 5], 2000, o.ACT_ELU, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN, "jit-tall<"),
+    "fanin_17_33_1_few_rows": ([17, 33, 1], 21, o.ACT_SIGMOID, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "jit-tall<"),
+}
+
+
+def problem(name):
+    dims, n, act, prior, lik, _k = CASES[name]
+    spec, X, Y, theta, eta = o.synth_problem(dims, n, act, prior, lik)
+    if lik == o.LIK_BERNOULLI:
+        theta = (theta * 0.3).astype(np.float32)          # outputs off saturation: a well-conditioned fp32 problem
+    return spec, X, Y, theta, eta
+
+
+def chain(native, name, spec, **kw):
+    ch = native.Chain(layers_of(spec), likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, jit=True, **kw)
+    assert ch.kernel_name.startswith(CASES[name][5]), ch.kernel_name
+    return ch
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_value_gradient_forward(native, name):
+    spec, X, Y, theta, eta = problem(name)
+    assert len(spec.layers) == 2 and (64 < spec.layers[0].out_dim <= 128 or 16 < spec.layers[0].in_dim <= 32)
+    ch = chain(native, name, spec)
+    ch.set_data(X, Y)
+    lp, g, st = ch.logp_grad(theta, eta)
+    for _ in range(2):
+        lp2, g2, _s = ch.logp_grad(theta, eta)
+        assert lp2 == lp and np.array_equal(g, g2)
+    m = min(500, X.shape[0])
+    f = ch.forward(X[:m], theta)
+    assert np.array_equal(f, ch.forward(X[:m], theta))
+    ch.close()
+    lp64, g64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)[:2]
+    assert abs(lp - lp64) <= 4e-6 * max(abs(lp64), 1.0), (lp, lp64)
+    for l, (ow, ob) in zip(spec.layers, spec.offsets()):
+        for a, b in ((ow, ob), (ob, ob + l.out_dim)):
+            assert np.abs(g[a:b] - g64[a:b]).max() <= 1e-4 * max(np.abs(g64[a:b]).max(), 1e-3), (name, a, b)
+    f64 = o.forward(spec, theta, X[:m], np.float64)
+    assert np.abs(f - f64).max() <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["demo_1_100_1", "bern_8_100_2", "full_8_tiles", "seven_outputs", "fanin_20_50_1", "fanin_24_64_2", "fanin_30_40_5"])
+def test_transitions(native, name):
+    spec, X, Y, theta, eta = problem(name)
+    rng = np.random.default_rng(4)
+    p0 = rng.standard_normal(spec.n_params).astype(np.float32)
+    ch = chain(native, name, spec, seed=SEED, chain_id=2)
+    ch.set_data(X, Y)
+    lp64 = o.target_log_prob_and_grad(spec, theta, eta, X, Y, np.float64)[0]
+    for log_u in (-1e30, 1e30):
+        ch.set_state(theta); ch.set_hypers(eta)
+        out = ch.hmc_step(3e-5, 4, p0=p0, log_u=log_u)
+        ref = o.weight_step(spec, theta, eta, X, Y, 3e-5, 4, p0, log_u, np.float64)
+        assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-4 * abs(ref.log_accept_ratio) + 4e-7 * abs(lp64)
+        assert bool(out["accepted"]) == ref.accepted
+        assert np.abs(ch.get_state() - ref.theta).max() <= 1e-5 * max(1.0, np.abs(ref.theta).max())
+    ph = rng.standard_normal(spec.n_hypers).astype(np.float32)
+    ch.set_state(theta); ch.set_hypers(eta)
+    ch.logp_grad(theta, eta)
+    out = ch.hyper_step(1e-4, 9, p0=ph, log_u=-1e30)
+    ref = o.hyper_step(spec, eta, theta, X, Y, 1e-4, 9, ph, -1e30, np.float64)
+    assert abs(out["log_accept_ratio"] - ref.log_accept_ratio) <= 2e-2 + 1e-3 * abs(ref.log_accept_ratio)
+    assert np.allclose(ch.get_hypers(), ref.theta, rtol=1e-4, atol=1e-5)
+    # free-running epochs on the device's own draws (a small problem may run its L steps in the trajectory kernel), the oracle set back each epoch
+    ch.set_state(theta); ch.set_hypers(eta); ch.set_epoch(0)
+    t, th = Tally(), theta.astype(np.float64)
+    with np.errstate(all="ignore"):
+        for ep in range(12):
+            rec = ch.hmc_run(2e-4, 5, 1)[0]
+            p0e, lu = draws(spec.n_params, 2, ep)
+            ref = o.weight_step(spec, th, eta, X, Y, 2e-4, 5, p0e, lu, np.float64)
+            took = t.add(rec, ref.log_accept_ratio, lu, ref.logp_old)
+            want = ref.theta_proposed.astype(np.float64) if took else th
+            got = ch.get_state().astype(np.float64)
+            assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max(), ep
+            th = got
+    ch.close()
+    t.check(f"one hidden layer [{name}]")
+
+
+def test_chain_group_equals_solo_chains(native):
+    name = "demo_1_100_1"
+    spec, X, Y, theta, eta = problem(name)
+    C, eps, L, E = 4, 2e-4, 5, 6
+    rng = np.random.default_rng(8)
+    thetas = (theta[None, :] * (1.0 + 0.03 * rng.standard_normal((C, theta.size)))).astype(np.float32)
+    etas = np.tile(eta, (C, 1)).astype(np.float32)
+    grp = native.ChainGroup(layers_of(spec), C, likelihood=spec.likelihood, fixed_sd=spec.fixed_sd, seed=SEED, chain_id=4, jit=True)
+    assert grp.kernel_name.startswith(CASES[name][5]), grp.kernel_name
+    grp.set_data(X, Y); grp.set_state(thetas); grp.set_hypers(etas)
+    recs = grp.hmc_run(eps, L, E)
+    states = grp.get_state()
+    grp.close()
+    for c in range(C):
+        ch = chain(native, name, spec, seed=SEED, chain_id=4 + c)
+        ch.set_data(X, Y); ch.set_state(thetas[c]); ch.set_hypers(etas[c])
+        solo = ch.hmc_run(eps, L, E)
+        assert [r["log_accept_ratio"] for r in solo] == [r["log_accept_ratio"] for r in recs[c]]
+        assert np.array_equal(ch.get_state(), states[c])
+        ch.close()
