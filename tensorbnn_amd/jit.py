@@ -12,7 +12,7 @@ are hand-written and only their *shape parameters* are bound at run time.)
 Family choice (first that compiles wins, in the order below -- except that a narrow network with 3 .. 16 outputs tries mid first: `families`; a shape
 no family accepts is remembered as `.fail` and runs on the layered kernels):
   * narrow (`k_fwd_bwd_fast3`, else `k_fwd_bwd_fast`): every dW accumulator in one wave's registers --
-    fan-in <= 16, at most NARROW_TILES 16x16 dW tiles in total;
+    fan-in <= 16, widths <= 64 (a network with ONE hidden layer: <= 128), at most NARROW_TILES 16x16 dW tiles in total;
   * mid (`k_fwd_bwd_mid`): >= 3 dense layers, <= 16 outputs (3 .. 16: the last layer is an MFMA layer too), fan-in <= 128, at most 63 dW tiles over the MFMA
     layers and weight images + operand blocks within 160 KB of LDS (`mid_fits`): one fused kernel, nothing through HBM;
   * tall (`k_fwd_bwd_tall`): a first-layer fan-in above the narrow family's 16 (.. a few thousand columns) in front of narrow hidden layers
