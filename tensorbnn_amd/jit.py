@@ -142,7 +142,7 @@ def tall_fits(dims) -> bool:
     layers' images, the exchange buffers and the per-wave operand blocks in 160 KB of LDS (an estimate: the build refuses a
     kernel that spills and the next family takes the shape).  <= 2 outputs: the last layer on the VALU; 3 .. 16: one more MFMA layer"""
     nl = len(dims) - 1
-    if max(dims[1:-1]) > 64:
+    if max(dims[1:-1]) > (128 if nl == 2 else 64):      # (one hidden layer: up to 128 units where the estimates below hold -- late round 6, as `families`)
         return False
     vl = dims[-1] <= 2
     nm = nl - 2 if vl else nl - 1               # MFMA layers behind layer 0: 1 .. nm

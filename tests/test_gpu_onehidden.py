@@ -31,12 +31,21 @@ CASES = {
     "fanin_24_64_2": ([24, 64, 2], 3000 + 5, o.ACT_TANH, o.PRIOR_CAUCHY, o.LIK_BERNOULLI, "jit-tall<"),
     "fanin_30_40_5": ([30, 40, 5], 2000, o.ACT_ELU, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN, "jit-tall<"),
     "fanin_17_33_1_few_rows": ([17, 33, 1], 21, o.ACT_SIGMOID, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "jit-tall<"),
+    # ... and a hidden layer of 65 .. ~112 units behind ANY fan-in above 16 (jit.tall_fits kept the tall kernel to <= 64 hidden units; with one hidden
+    # layer its register and LDS plan holds further): 20 -> 100 -> 1 at 1e5 rows 60.6 against 83.1 us per step, 100 -> 100 -> 1 85.8 against 117.2
+    "wide_hidden_20_100_1": ([20, 100, 1], 1000, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "jit-tall<"),
+    "wide_hidden_100_100_1": ([100, 100, 1], 2000 + 9, o.ACT_TANH, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "jit-tall<"),
+    "wide_hidden_300_100_1": ([300, 100, 1], 1500, o.ACT_RELU, o.PRIOR_GAUSSIAN, o.LIK_GAUSSIAN, "jit-tall<"),
+    "wide_hidden_50_112_2": ([50, 112, 2], 4000, o.ACT_ELU, o.PRIOR_CAUCHY, o.LIK_BERNOULLI, "jit-tall<"),
+    "wide_hidden_40_80_10": ([40, 80, 10], 3000, o.ACT_RELU, o.PRIOR_CAUCHY, o.LIK_GAUSSIAN, "jit-tall<"),
 }
 
 
 def problem(name):
     dims, n, act, prior, lik, _k = CASES[name]
     spec, X, Y, theta, eta = o.synth_problem(dims, n, act, prior, lik)
+    if dims[0] > 64:
+        X = (X / np.sqrt(dims[0] / 16.0)).astype(np.float32)          # keep a long fan-in's pre-activations O(1)
     if lik == o.LIK_BERNOULLI:
         theta = (theta * 0.3).astype(np.float32)          # outputs off saturation: a well-conditioned fp32 problem
     return spec, X, Y, theta, eta
@@ -71,7 +80,8 @@ def test_value_gradient_forward(native, name):
     assert np.abs(f - f64).max() <= 1e-4
 
 
-@pytest.mark.parametrize("name", ["demo_1_100_1", "bern_8_100_2", "full_8_tiles", "seven_outputs", "fanin_20_50_1", "fanin_24_64_2", "fanin_30_40_5"])
+@pytest.mark.parametrize("name", ["demo_1_100_1", "bern_8_100_2", "full_8_tiles", "seven_outputs", "fanin_20_50_1", "fanin_24_64_2", "fanin_30_40_5",
+                                  "wide_hidden_20_100_1", "wide_hidden_100_100_1", "wide_hidden_50_112_2", "wide_hidden_40_80_10"])
 def test_transitions(native, name):
     spec, X, Y, theta, eta = problem(name)
     rng = np.random.default_rng(4)
@@ -96,11 +106,14 @@ def test_transitions(native, name):
     # free-running epochs on the device's own draws (a small problem may run its L steps in the trajectory kernel), the oracle set back each epoch
     ch.set_state(theta); ch.set_hypers(eta); ch.set_epoch(0)
     t, th = Tally(), theta.astype(np.float64)
+    # (20 -> 100 -> 1 at 2e-4: one epoch's log accept ratio is 8.4 from fp64 -- and so is the fp32 NumPy oracle's, -8.404 against -8.398: a relu kink of
+    # that trajectory, tools/experiments/onehidden_dlar.py; a smaller step keeps the comparison about the kernel)
+    eps = 5e-5 if name.startswith("wide_hidden") else 2e-4
     with np.errstate(all="ignore"):
         for ep in range(12):
-            rec = ch.hmc_run(2e-4, 5, 1)[0]
+            rec = ch.hmc_run(eps, 5, 1)[0]
             p0e, lu = draws(spec.n_params, 2, ep)
-            ref = o.weight_step(spec, th, eta, X, Y, 2e-4, 5, p0e, lu, np.float64)
+            ref = o.weight_step(spec, th, eta, X, Y, eps, 5, p0e, lu, np.float64)
             took = t.add(rec, ref.log_accept_ratio, lu, ref.logp_old)
             want = ref.theta_proposed.astype(np.float64) if took else th
             got = ch.get_state().astype(np.float64)
