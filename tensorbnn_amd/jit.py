@@ -12,7 +12,7 @@ are hand-written and only their *shape parameters* are bound at run time.)
 Family choice (first that compiles wins, in the order below -- except that a narrow network with 3 .. 16 outputs tries mid first: `families`; a shape
 no family accepts is remembered as `.fail` and runs on the layered kernels):
   * narrow (`k_fwd_bwd_fast3`, else `k_fwd_bwd_fast`): every dW accumulator in one wave's registers --
-    fan-in <= 16, widths <= 64 (a network with ONE hidden layer: <= 128), at most NARROW_TILES 16x16 dW tiles in total;
+    fan-in <= 16, widths <= 64 (a network with ONE hidden layer: <= 256 units, <= 160 with more than two outputs), at most NARROW_TILES 16x16 dW tiles in total;
   * mid (`k_fwd_bwd_mid`): >= 3 dense layers, <= 16 outputs (3 .. 16: the last layer is an MFMA layer too), fan-in <= 128, at most 63 dW tiles over the MFMA
     layers and weight images + operand blocks within 160 KB of LDS (`mid_fits`): one fused kernel, nothing through HBM;
   * tall (`k_fwd_bwd_tall`): a first-layer fan-in above the narrow family's 16 (.. a few thousand columns) in front of narrow hidden layers
@@ -92,9 +92,11 @@ def families(dims) -> list:
     out = []
     tiles = sum(_cdiv(dims[l + 1], 16) * _cdiv(dims[l] + 1, 16) for l in range(nl))
     # (widths: 64, the widest layer the hand-threaded dW phases of deeper networks were written and fuzzed for; a network with ONE hidden layer has
-    # none of those phases between two wide layers and instantiates up to 8 tiles = 128 units -- 1 -> 100 -> 1, the canonical BNN regression demo,
-    # ran on the layered family until late round 6: 73 us per step at 1e5 rows against 17 for 1 -> 64 -> 1)
-    narrow = dims[0] <= 16 and tiles <= NARROW_TILES and (max(dims) <= 64 or (nl == 2 and max(dims) <= 128))
+    # none of those phases between two wide layers and instantiates well beyond that -- 1 -> 100 -> 1, the canonical BNN regression demo, ran on the
+    # layered family until late round 6: 73 us per step at 1e5 rows against 17 for 1 -> 64 -> 1)
+    # (one hidden layer: 256 units with one or two outputs, 160 with 3 .. 16 -- beyond those a random draw of 60 such shapes had 9 refused by the build:
+    # fast3 spills from ~300 units, k_fwd_bwd_fast's LDS plan overflows with many outputs behind > 200 units)
+    narrow = dims[0] <= 16 and tiles <= NARROW_TILES and (max(dims) <= 64 or (nl == 2 and max(dims) <= (256 if dims[-1] <= 2 else 160)))
     mid = nl >= 3 and dims[-1] <= 16 and dims[0] <= MID_MAX_FANIN and mid_fits(dims)
     # 3 .. 16 outputs on a narrow network: fast3 does not take them, and the mid-width kernel (MFMA last layer, round 6) measures 7 - 13 % ahead of
     # k_fwd_bwd_fast there (5 -> 50 -> 50 -> 50 -> 3 at 1e5 rows 65.3 against 70.4 us per step, 8 -> 40 -> 40 -> 10 34.8 against 39.8): mid first

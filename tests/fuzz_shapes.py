@@ -26,7 +26,8 @@ UNBUILDABLE = {("tall", (362, 49, 64, 1)): "k_fwd_bwd_tall spills (32 bytes per 
                ("tall", (525, 39, 64, 22, 2)): "k_fwd_bwd_tall spills (432 bytes per lane)",
                ("wide", (19, 148, 191, 1)): "k_dw_wide spills (164 bytes per lane)",
                ("wide", (26, 234, 229, 115, 1)): "k_dw_wide spills (140 bytes per lane)",
-               ("wide", (26, 234, 229, 115, 2)): "k_dw_wide spills (the same widths with two outputs: the wide shapes draw 1 .. 16 outputs since late round 6)"}
+               ("wide", (26, 234, 229, 115, 2)): "k_dw_wide spills (the same widths with two outputs: the wide shapes draw 1 .. 16 outputs since late round 6)",
+               ("onehidden", (9, 210, 16)): "k_fwd_bwd_fast's LDS plan does not fit (173,312 bytes: 16 outputs behind 210 units); the layered family takes it"}
 
 
 def _families(dims):
@@ -49,10 +50,10 @@ def _dims(rng, fam):
     if fam == "wide":
         return [_edge(rng, 1, 32)] + [_edge(rng, 65, 256) for _ in range(int(rng.integers(2, 4)))] + [int(rng.choice([1, 2, 2, 3, 5, 10, 16]))]     # (3 .. 16 outputs: round 6, late)
     if fam == "onehidden":
-        # ONE hidden layer beyond what the families took before late round 6 (narrow: 65 .. 128 units behind <= 16 inputs; tall: fan-in 17 .. 32, or
+        # ONE hidden layer beyond what the families took before late round 6 (narrow: 65 .. 256 units behind <= 16 inputs; tall: fan-in 17 .. 32, or
         # 65 .. 128 hidden units behind any fan-in its estimates admit): whatever fused kernel jit.families names serves it
         d_in = int(rng.choice([rng.integers(1, 17), rng.integers(17, 33), _edge(rng, 33, 300)]))
-        return [d_in] + [_edge(rng, 17, 128)] + [int(rng.choice([1, 2, 2, 3, 5, 10, 16]))]
+        return [d_in] + [int(rng.choice([_edge(rng, 17, 128), _edge(rng, 129, 256)]))] + [int(rng.choice([1, 2, 2, 3, 5, 10, 16]))]
     return [_edge(rng, 1, 600)] + [_edge(rng, 2, 300) for _ in range(int(rng.integers(1, 4)))] + [int(rng.choice([1, 2, 3, 5, 10, 17]))]
 
 
