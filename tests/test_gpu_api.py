@@ -11,6 +11,50 @@ import tbnn_oracle as o
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("arch", ["one_hidden_100", "mixed_activations"])
+def test_train_flow_on_run_time_instantiated_kernels(tmp_path, monkeypatch, native, arch):
+    """the example problem (11 rows) through the Python API on architectures that reach their fused kernel through jit.py since late round 6:
+    1->100->1 (one wide hidden layer: narrow kernels) and 1->10 Relu->10 Tanh->1 (hidden layers with different activations)"""
+    import math
+    from tensorbnn_amd.activationFunctions import Relu, Tanh
+    from tensorbnn_amd.layer import GaussianDenseLayer
+    from tensorbnn_amd.likelihood import FixedGaussianLikelihood
+    from tensorbnn_amd.metrics import SquaredError
+    from tensorbnn_amd.network import network
+    from tensorbnn_amd.predictor import predictor
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("TBNN_JIT", "1")
+    trainIn = np.linspace(-2, 2, num=11)
+    valIn = np.linspace(-2 + 2 / 30, 2.0 - 2 / 30, num=30)
+    trainOut = np.sin(trainIn * math.pi * 2) * trainIn - np.cos(trainIn * math.pi)
+    valOut = np.sin(valIn * math.pi * 2) * valIn - np.cos(valIn * math.pi)
+    net = network(np.float32, 1, trainIn, trainOut.T, valIn, valOut.T)
+    if arch == "one_hidden_100":
+        net.add(GaussianDenseLayer(1, 100, seed=1000)); net.add(Tanh())
+        net.add(GaussianDenseLayer(100, 1, seed=2000))
+        dims, acts, want = [1, 100, 1], [o.ACT_TANH], "fast3<tanh,"
+    else:
+        net.add(GaussianDenseLayer(1, 10, seed=1000)); net.add(Relu())
+        net.add(GaussianDenseLayer(10, 10, seed=2000)); net.add(Tanh())
+        net.add(GaussianDenseLayer(10, 1, seed=3000))
+        dims, acts, want = [1, 10, 10, 1], [o.ACT_RELU, o.ACT_TANH], "fast3<relu+tanh,"
+    net.setupMCMC(stepSizeStart=1e-3, stepSizeMin=1e-4, stepSizeMax=1e-2, stepSizeOptions=20, leapfrogStart=20,
+                  leapfogMin=10, leapFrogMax=50, leapfrogIncrement=10, hyperStepSize=0.001, hyperLeapfrog=20,
+                  burnin=10, averagingSteps=5)
+    rec = net.train(31, 10, FixedGaussianLikelihood(sd=0.1), metricList=[SquaredError()], adjustHypers=True, folderName="Run",
+                    networksPerFile=2, displaySkip=30)
+    assert len(rec) == 31 and want in net._chain.kernel_name, net._chain.kernel_name
+    assert np.mean([r["main"]["accept_prob"] for r in rec]) > 0.1
+    p = predictor(str(tmp_path / "Run") + "/")
+    assert p.numNetworks == 2
+    preds = p.predict(valIn.reshape(-1, 1))
+    spec = o.make_spec(dims, acts[0], o.PRIOR_GAUSSIAN, o.LIK_FIXED_GAUSSIAN)
+    for l, a in zip(spec.layers[:-1], acts):
+        l.act = a
+    ref = o.forward(spec, p.vectors[0], valIn.reshape(-1, 1).astype(np.float32), np.float64)
+    np.testing.assert_allclose(preds[0], ref, rtol=2e-5, atol=2e-5)
+
+
 def test_train_regression_script_flow(tmp_path, monkeypatch, native):
     """the literal example problem: 11 rows, 1->10->10->10->1 Tanh, GaussianDenseLayer, FixedGaussianLikelihood"""
     import math
