@@ -113,10 +113,24 @@ def families(dims) -> list:
     # at 16 inputs, mid and wide need two hidden layers; late round 6, measured against the layered family)
     if nl >= 2 and dims[-1] <= 16 and dims[0] > 16 and tall_fits(dims):
         out.append("tall")
-    if nl >= 3 and dims[-1] <= 16 and dims[0] <= 32 and max(dims[1:-1]) <= 256:      # (3 .. 16 outputs: the last layer as one more middle layer, round 6)
+    # (3 .. 16 outputs: the last layer as one more middle layer, round 6.  Fan-in: 32 was round 1's choice -- x in registers, W_0 in LDS, dW_0 in AccVGPRs --;
+    # the kernels build and hold for fan-in up to 128 wherever W_0 fits the LDS next to the ring: late round 6, `wide_fits`)
+    if nl >= 3 and dims[-1] <= 16 and dims[0] <= 128 and max(dims[1:-1]) <= 256 and wide_fits(dims):
         out.append("wide")
     skip = {f for f in os.environ.get("TBNN_JIT_SKIP", "").split(",") if f}      # diagnostic / tests: e.g. "mid" forces the wide path
     return [f for f in out if f not in skip]
+
+
+def wide_fits(dims) -> bool:
+    """fan-in above 32 on the wide family (kernels_wide.hpp, WideCfg): W_0's operand granules (ceil(out_0 / 16) x ceil(d_in / 16) KB) in LDS next to the
+    weight ring (4 slots of the widest layer's granules) and the per-wave scratch, and dW_0's ceil(out_0 / 16) x ceil((d_in + 1) / 16) accumulator
+    tiles beside the chain's registers (an estimate: the build refuses what does not fit or spills, and the next family takes the shape)"""
+    if dims[0] <= 32:
+        return True
+    mt0, kg0, nt0 = _cdiv(dims[1], 16), _cdiv(dims[0], 16), _cdiv(dims[0] + 1, 16)
+    maxgran = 4 * _cdiv(max(_cdiv(d, 16) for d in dims[1:-1]), 4)
+    lds = (mt0 * kg0 * 256 + 4 * maxgran * 256 + 4 * (16 * (16 * nt0 + 4) + 16 * 68) + 16 * sum(_cdiv(d, 16) for d in dims[1:])) * 4
+    return lds <= 156 * 1024 and mt0 * nt0 <= 63
 
 
 def mid_fits(dims) -> bool:

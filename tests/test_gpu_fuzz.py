@@ -68,7 +68,7 @@ def test_value_gradient_forward_vs_fp64_and_repeatable(native, family_env, c):
     try:
         name = ch.kernel_name
         want = {"narrow": ("fast3", "fast<"), "mid": ("mid",), "tall": ("tall",), "wide": ("wide",), "layered": ("layered",),
-                "onehidden": ("fast3", "fast<", "tall")}[c["family"]]
+                "onehidden": ("fast3", "fast<", "tall"), "widefanin": ("wide",)}[c["family"]]
         if not any(w in name for w in want):
             from tensorbnn_amd import jit
             if os.environ.get("TBNN_FUZZ_SEED") and jit.build(layers, spec.likelihood) is None:
