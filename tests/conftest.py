@@ -34,6 +34,22 @@ def _has_gpu():
         return False
 
 
+def pytest_collection_finish(session):
+    """A GPU run on a tree that arrives WITHOUT its ahead-of-time kernel cache (tensorbnn_amd/_jit, which __graft_entry__.build() fills and which travels
+    with the tree like libtbnn.so): compile the suite's run-time instantiations now, side by side on the box's CPUs (~2 min for ~140 libraries), instead
+    of one by one inside the tests (~20 min).  With the cache in place every job is a cache hit (a second or two).  Before any test has touched the GPU:
+    the workers are forked and only drive compiler subprocesses.  TBNN_PREBUILD_JIT=0 skips it."""
+    if getattr(session.config.option, "collectonly", False) or os.environ.get("TBNN_PREBUILD_JIT", "1") == "0":
+        return
+    if not any(item.get_closest_marker("gpu") for item in session.items):
+        return
+    try:
+        import __graft_entry__ as ge
+        ge.prebuild_jit()
+    except Exception as e:          # never fails the run: the tests compile what is missing
+        print("run-time kernel libraries not prebuilt:", e)
+
+
 def pytest_collection_modifyitems(config, items):
     # -m gpu on a box without a GPU must fail loudly, not skip: the product has no fallback.
     pass
