@@ -109,9 +109,9 @@ def families(dims) -> list:
         out.append("fast")
     if mid and not mid_first:
         out.append("mid")
-    # (fan-in 17 .. 32: behind mid / wide in the order, the tall kernel is what a ONE-hidden-layer network of that fan-in has -- the narrow family stops
-    # at 16 inputs, mid and wide need two hidden layers; late round 6, measured against the layered family)
-    if nl >= 2 and dims[-1] <= 16 and dims[0] > 16 and tall_fits(dims):
+    # (fan-in 17 .. 32 with ONE hidden layer: the narrow family stops at 16 inputs, mid and wide need two hidden layers -- the tall kernel is what such a
+    # network has; late round 6, measured against the layered family.  Deeper networks of that fan-in keep their round-4 order: mid, then wide)
+    if nl >= 2 and dims[-1] <= 16 and dims[0] > (16 if nl == 2 else 32) and tall_fits(dims):
         out.append("tall")
     # (3 .. 16 outputs: the last layer as one more middle layer, round 6.  Fan-in: 32 was round 1's choice -- x in registers, W_0 in LDS, dW_0 in AccVGPRs --;
     # the kernels build and hold for fan-in up to 128 wherever W_0 fits the LDS next to the ring: late round 6, `wide_fits`)
