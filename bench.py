@@ -41,10 +41,10 @@ PEAK_HBM_GBPS = 8000.0       # HBM3E spec; a float4 copy measures 6.29 TB/s (sam
 MEASURED_HBM_GBPS = 6290.0
 CONFIG_KEY = {"c1": "configs[0]", "c2": "configs[1]", "c4": "configs[3]", "c5": "configs[4]",
               "c5g": "configs[4] with GaussianDenseLayer priors", "mn": "docs example 784-20-20-1",
-              "w300": "8-300-300-1", "mc10": "784-100-100-10", "wm10": "10-200-200-10"}
+              "w300": "8-300-300-1", "mc10": "784-100-100-10", "wm10": "10-200-200-10", "oh100": "1-100-1", "wf50": "50-100-100-1"}
 # CPU sample per workload: (max epochs, leapfrog steps per epoch, wall cap in s) for the all-threads run
 CPU_SAMPLE = {"c1": (20, 100, 10.0), "c2": (20, 50, 30.0), "c4": (1, 3, 30.0), "c5": (1, 20, 30.0), "mn": (4, 50, 15.0),
-              "w300": (1, 5, 15.0), "mc10": (1, 5, 15.0), "wm10": (1, 5, 15.0)}
+              "w300": (1, 5, 15.0), "mc10": (1, 5, 15.0), "wm10": (1, 5, 15.0), "oh100": (2, 20, 10.0), "wf50": (1, 5, 15.0)}
 
 
 def algorithmic_flops(dims, n):
@@ -627,7 +627,7 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c4", "c5", "c5g", "mn", "w300", "mc10", "wm10"],
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c4", "c5", "c5g", "mn", "w300", "mc10", "wm10", "oh100", "wf50"],
                     help="measure this workload alone (default: c2 = BASELINE configs[1], + the others as `secondary` at N = 1)")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)

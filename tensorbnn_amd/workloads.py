@@ -64,6 +64,12 @@ WORKLOADS = {
     "wm10": dict(dims=[10, 200, 200, 10], n=100_000, L=20, lik=nat.LIK_BERNOULLI, hyper=False, steps=10, warmup=2,
                  text="10->200->200->10 Relu/Sigmoid BNN (Cauchy DenseLayer, BernoulliLikelihood over 10 outputs), 100k-row fp32 synthetic classification, "
                       "L=20 leapfrog, 1 chain per GPU"),
+    # late round 6: two shapes that reach a fused kernel through limits of jit.py that were relaxed: the canonical one-hidden-layer demo on
+    # the narrow kernels, and the wide family behind 50 inputs
+    "oh100": dict(dims=[1, 100, 1], n=100_000, L=20, lik=nat.LIK_GAUSSIAN, hyper=False, steps=10, warmup=2,
+                  text="1->100->1 Relu BNN (Cauchy DenseLayer, GaussianLikelihood), 100k-row fp32 synthetic regression, L=20 leapfrog, 1 chain per GPU"),
+    "wf50": dict(dims=[50, 100, 100, 1], n=100_000, L=20, lik=nat.LIK_GAUSSIAN, hyper=False, steps=10, warmup=2,
+                 text="50->100->100->1 Relu BNN (Cauchy DenseLayer, GaussianLikelihood), 100k-row fp32 synthetic regression, L=20 leapfrog, 1 chain per GPU"),
 }
 for _w in WORKLOADS.values():
     _w.setdefault("prior", nat.PRIOR_CAUCHY)

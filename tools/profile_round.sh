@@ -18,6 +18,8 @@ CMD[mn]="python3 bench.py --workload mn --no-cpu-baseline"
 CMD[w300]="python3 bench.py --workload w300 --eps 1e-6 --no-cpu-baseline"
 CMD[mc10]="python3 bench.py --workload mc10 --eps 1e-6 --no-cpu-baseline"
 CMD[wm10]="python3 bench.py --workload wm10 --eps 1e-6 --no-cpu-baseline"
+CMD[oh100]="python3 bench.py --workload oh100 --eps 1e-6 --no-cpu-baseline"
+CMD[wf50]="python3 bench.py --workload wf50 --eps 1e-6 --no-cpu-baseline"
 for W in ${PROFILE_WORKLOADS:-c2 c4 c5 mn w300 mc10 wm10}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -- ${CMD[$W]} > $OUT/trace_$W.log 2>&1 || echo "trace $W failed"
   f=$(find $OUT/trace_$W -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${W}_kernel_stats.csv

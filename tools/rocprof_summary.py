@@ -16,7 +16,8 @@ tag = os.path.basename(os.path.normpath(out))
 PASS = {"c2": ["k_fwd_bwd_fast3"], "c4": ["k_chain_wide", "k_dw_wide", "k_reduce_wide"], "c5": ["k_fwd_bwd_mid", "k_chain_wide", "k_dw_wide", "k_reduce_wide"],
         "mn": ["k_fwd_bwd_tall"],
         # the layered family (any architecture): every launch of one gradient, counted per leapfrog step through launches / passes
-        "w300": ["k_lay_"], "mc10": ["k_lay_", "k_fwd_bwd_tall", "k_fwd_bwd_mid"], "wm10": ["k_chain_wide", "k_dw_wide", "k_reduce_wide", "k_lay_"]}
+        "w300": ["k_lay_"], "mc10": ["k_lay_", "k_fwd_bwd_tall", "k_fwd_bwd_mid"], "wm10": ["k_chain_wide", "k_dw_wide", "k_reduce_wide", "k_lay_"],
+        "oh100": ["k_fwd_bwd_fast3", "k_fwd_bwd_fast", "k_lay_"], "wf50": ["k_chain_wide", "k_dw_wide", "k_reduce_wide", "k_lay_"]}
 PASS = {w: PASS[w] for w in os.environ.get("PROFILE_WORKLOADS", "c2 c4 c5 mn w300 mc10 wm10").split() if w in PASS}
 KNOWN = ("k_fwd_bwd_fast3", "k_fwd_bwd_fast", "k_fwd_bwd_mid", "k_fwd_bwd_tall", "k_chain_wide", "k_dw_wide", "k_reduce_wide", "k_update", "k_hyper",
          "k_energy", "k_begin")
