@@ -25,6 +25,11 @@ CASES = {
     "ten outputs wide": ([10, 200, 200, 10], 100_000, o.LIK_BERNOULLI, "jit-wide<", 1e-5, 4),
     "ten outputs mid": ([30, 80, 80, 10], 100_000, o.LIK_BERNOULLI, "jit-mid<", 2e-5, 6),
     "ten outputs tall": ([784, 20, 20, 10], 60_000, o.LIK_BERNOULLI, "jit-tall<", 1e-4, 6),
+    # late round 6: shapes that reach their fused kernel through the relaxed limits of jit.families (one hidden layer on the narrow / tall kernels, the wide
+    # family behind 100 inputs)
+    "one hidden layer narrow": ([1, 100, 1], 100_000, o.LIK_GAUSSIAN, "jit-fast3<", 2e-6, 10),      # (gradients of 1e9 at the initial state: at 1e-4 the kicks are 1e5 x |p_0| and fp32 momenta cannot come back to 4e-3 of it)
+    "one hidden layer tall": ([100, 100, 1], 100_000, o.LIK_GAUSSIAN, "jit-tall<", 2e-5, 6),
+    "wide behind 100 inputs": ([100, 100, 100, 1], 100_000, o.LIK_GAUSSIAN, "jit-wide", 1e-5, 4),
     # ... and hidden layers with different activations at configs[1]'s size (the packed per-layer activation code)
     "mixed activations narrow": ([5, 50, 50, 50, 1], 100_000, o.LIK_GAUSSIAN, "jit-fast3<tanh+relu+elu", 2e-5, 10),
 }
